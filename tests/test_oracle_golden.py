@@ -1,0 +1,117 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz, produced by
+tests/golden/make_golden.py) and against the literals the reference's own tests/tutorial hold."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torchmd_oracle as orc
+
+from _golden import GoldenParameters, PREC, box_tensor, energies, load, pos_tensor
+
+ALL_TERMS = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+
+
+def _check(g, tag, par, pos, box, terms, R=1, etol=0.0, ftol=0.0, **kw):
+    pots, F, _ = orc.compute(par, pos, box, terms, **kw)
+    for r in range(R):
+        ref = energies(g, tag, r)
+        for t in terms:
+            assert abs(pots[r][t] - ref[t]) <= etol * max(1.0, abs(ref[t])), (tag, t, pots[r][t], ref[t])
+    ref_f = g[tag + "_forces"]
+    assert np.abs(F.numpy() - ref_f).max() <= ftol, tag
+    return pots, F
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("rfa", [False, True])
+def test_water291_bitexact(prec, rfa):
+    g = load("water291")
+    par = GoldenParameters(g, PREC[prec])
+    pos, box = pos_tensor(g["pos"], 2, PREC[prec]), box_tensor(g["box"], 2, PREC[prec])
+    _check(g, f"{prec}_full_rfa{int(rfa)}", par, pos, box, ["lj", "bonds", "angles", "electrostatics"], R=2,
+           cutoff=7.3, rfa=rfa)
+    _check(g, f"{prec}_nb_rfa{int(rfa)}", par, pos, box, ["lj", "electrostatics"], R=2, cutoff=7.3, rfa=rfa)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_ala2_bitexact(prec):
+    g = load("ala2")
+    par = GoldenParameters(g, PREC[prec])
+    pos = pos_tensor(g["pos"], 1, PREC[prec])
+    pbc, box0 = box_tensor(g["box"], 1, PREC[prec]), box_tensor(np.zeros(3), 1, PREC[prec])
+    sw = dict(cutoff=9.0, switch_dist=7.5, rfa=True)
+    for label, terms in (("full", ALL_TERMS), ("nb", ["electrostatics", "lj"])):
+        _check(g, f"{prec}_{label}_pbc", par, pos, pbc, terms, **sw)
+        _check(g, f"{prec}_{label}_box0", par, pos, box0, terms, **sw)
+        _check(g, f"{prec}_{label}_nocut", par, pos, box0, terms)
+    _check(g, f"{prec}_nb_pbc_noswitch", par, pos, pbc, ["electrostatics", "lj"], cutoff=9.0, rfa=True)
+    _check(g, f"{prec}_repulsion_pbc", par, pos, pbc, ["repulsion"], cutoff=9.0)
+    _check(g, f"{prec}_repulsioncg_pbc", par, pos, pbc, ["repulsioncg"], cutoff=9.0)
+
+
+def test_sparse_candidates_equal_dense():
+    """A cKDTree candidate list (superset of in-cutoff pairs, same order) gives bit-identical results."""
+    g = load("ala2")
+    par = GoldenParameters(g, torch.float64)
+    pos, pbc = pos_tensor(g["pos"], 1, torch.float64), box_tensor(g["box"], 1, torch.float64)
+    pairs = orc.candidate_pairs(g["pos"], g["box"], 9.5, orc.exclusion_pairs(par))
+    _check(g, "f64_nb_pbc", par, pos, pbc, ["electrostatics", "lj"], pairs=pairs, cutoff=9.0, switch_dist=7.5, rfa=True)
+
+
+def test_reference_literals():
+    """Known answers in the reference's own tests / tutorial."""
+    g = load("ala2")
+    par = GoldenParameters(g, torch.float64)
+    pos = pos_tensor(g["pos"], 1, torch.float64)
+    box0 = box_tensor(np.zeros(3), 1, torch.float64)
+    pots, _, _ = orc.compute(par, pos, box0, ALL_TERMS, cutoff=9.0, switch_dist=7.5, rfa=True)
+    assert abs(sum(pots[0].values()) - (-1722.3569)) < 3e-4  # tests/test_torchmd.py:516-517
+    pots, _, _ = orc.compute(par, pos, box0, ALL_TERMS)
+    assert abs(sum(pots[0].values()) - (-1768.8915)) < 3e-4  # tests/test_torchmd.py:605
+    # examples/tutorial.ipynb:105-106 (fp32, periodic)
+    par32 = GoldenParameters(g, torch.float32)
+    pots, F, _ = orc.compute(par32, pos_tensor(g["pos"], 1, torch.float32), box_tensor(g["box"], 1, torch.float32),
+                             ALL_TERMS, cutoff=9.0, switch_dist=7.5, rfa=True)
+    tut = {"electrostatics": -2568.498046875, "lj": 359.2510986328125, "bonds": 3.957749366760254,
+           "angles": 2.8445725440979004, "dihedrals": 10.57987117767334, "impropers": 1.2417081594467163}
+    for k, v in tut.items():
+        assert abs(pots[0][k] - v) < 2e-3, (k, pots[0][k], v)
+    assert np.allclose(F[0, 0].numpy(), [3.0404, 1.7028, 3.8141], atol=2e-3)
+
+
+def test_water291_survey_literals():
+    g = load("water291")
+    e = energies(g, "f64_full_rfa0")
+    assert abs(e["lj"] - 72.32724504093386) < 1e-9
+    assert abs(e["electrostatics"] - 244.7022824776028) < 1e-9
+    assert abs(energies(g, "f64_full_rfa1")["electrostatics"] - (-755.0535968663128)) < 1e-9
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_trajectory_bitexact(prec):
+    """5 NVE steps of the reference Integrator on tests/water (integrator.py:112-125)."""
+    g = load("water291")
+    dt = PREC[prec]
+    par = GoldenParameters(g, dt)
+    terms = ["lj", "bonds", "angles", "electrostatics"]
+    pos, box = pos_tensor(g["pos"], 2, dt), box_tensor(g["box"], 2, dt)
+    vel = torch.tensor(g["traj_vel0"]).to(dt)
+    masses = par.masses.to(dt).view(-1, 1)
+    step, _, _ = orc.integrator_constants(1.0, None, None, masses)
+    kw = dict(cutoff=7.3, rfa=True)
+    _, forces, _ = orc.compute(par, pos, box, terms, **kw)
+    for _ in range(5):
+        pots, _ = orc.md_step(par, pos, vel, forces, box, masses, step, terms, **kw)
+    assert np.array_equal(pos.numpy(), g[f"{prec}_traj_pos"])
+    assert np.array_equal(vel.numpy(), g[f"{prec}_traj_vel"])
+    ek = orc.kinetic_energy(masses, vel).flatten().numpy()
+    assert np.allclose(ek, g[f"{prec}_traj_ekin"], rtol=1e-6)
+    assert np.allclose([sum(p.values()) for p in pots], g[f"{prec}_traj_pot"], rtol=1e-6)
+
+
+def test_thrombin_nocut():
+    g = load("thrombin")
+    par = GoldenParameters(g, torch.float64)
+    pos, box0 = pos_tensor(g["pos"], 1, torch.float64), box_tensor(np.zeros(3), 1, torch.float64)
+    _check(g, "f64_nb_nocut", par, pos, box0, ["electrostatics", "lj"], etol=1e-12, ftol=1e-9)
