@@ -1,0 +1,188 @@
+/*
+ * tmdhip.h — C ABI of the MI355X (gfx950) nonbonded / integrator engine for TorchMD.
+ *
+ * This is the drop-in boundary of the hot path.  The reference has no native
+ * layer at all: its hot path is Python/PyTorch.  Each entry point below therefore cites the
+ * reference *Python* function whose arithmetic it replaces; the host-side mirror of the reference
+ * API (`torchmd_amd.forces.Forces`, `torchmd_amd.integrator.Integrator`, `torchmd_amd.systems.System`)
+ * binds these symbols through ctypes.
+ *
+ * Conventions
+ *   - plain C types only; no torch / C++ types cross the boundary
+ *   - `*_dev` pointers are device (HBM) pointers owned by the caller (torch tensors' data_ptr());
+ *     `*_host` pointers are host memory, only read during the call
+ *   - `real` = float (dtype 0) or double (dtype 1); positions/forces/velocities are [N,3] AoS
+ *     contiguous exactly like the reference's `System` tensors (systems.py:12-16)
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream); no call synchronises the device unless documented
+ *   - return 0 on success, negative on error; tmdhip_last_error() gives a thread-local message
+ *   - one host thread per context (contexts are not re-entrant)
+ */
+#ifndef TMDHIP_H
+#define TMDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMDHIP_ABI_VERSION 1
+
+/* dtype */
+#define TMDHIP_F32 0
+#define TMDHIP_F64 1
+
+/* nonbonded term mask — names of reference Forces.nonbonded (forces.py:24) */
+#define TMDHIP_TERM_LJ 1u
+#define TMDHIP_TERM_ELECTROSTATICS 2u
+#define TMDHIP_TERM_REPULSION 4u
+#define TMDHIP_TERM_REPULSIONCG 8u
+
+/* layout of the energy accumulator double[TMDHIP_NENERGY] (per replica) */
+#define TMDHIP_E_LJ 0
+#define TMDHIP_E_ELECTROSTATICS 1
+#define TMDHIP_E_REPULSION 2
+#define TMDHIP_E_REPULSIONCG 3
+#define TMDHIP_E_BONDS 4
+#define TMDHIP_E_ANGLES 5
+#define TMDHIP_E_DIHEDRALS 6
+#define TMDHIP_E_IMPROPERS 7
+#define TMDHIP_NENERGY 8
+
+/* compute flags */
+#define TMDHIP_WANT_ENERGY 1 /* accumulate (+=) per-term energies into energies_dev          */
+#define TMDHIP_WANT_FORCES 2 /* accumulate (+=) forces into forces_dev                        */
+#define TMDHIP_COUNT_PAIRS 4 /* also count non-excluded i<j pairs with r <= cutoff (stats)    */
+
+/* pair-search algorithm */
+#define TMDHIP_ALGO_AUTO 0
+#define TMDHIP_ALGO_ALLPAIRS 1 /* tiled O(N^2) kernel: small / non-periodic / no-cutoff systems */
+#define TMDHIP_ALGO_CELLLIST 2 /* cell binning + Verlet list + list pair kernel                  */
+
+/* switching-force mode (forces.py:403-413) */
+#define TMDHIP_SWITCH_REFERENCE 0 /* explicit force = S*f + E*S'/r  (upstream's extra 1/r kept) */
+#define TMDHIP_SWITCH_EXACT 1     /* explicit force = S*f + E*S'    (-dE/dr)                      */
+
+typedef struct tmdhip_ctx tmdhip_ctx;
+
+/* Static description of one system's nonbonded interactions.
+ * Replaces the state reference `Forces.__init__` derives (forces.py:27-74): the A/B tables
+ * (parameters.py:449-457), charges, mapped atom types, and the exclusion set that
+ * `_make_indeces` (forces.py:348-357) bakes into its dense pair tensor. */
+typedef struct tmdhip_nonbonded_desc {
+  int32_t struct_size; /* = sizeof(tmdhip_nonbonded_desc) */
+  int32_t dtype;       /* TMDHIP_F32 / TMDHIP_F64: type of pos/forces and of the real-valued arrays below */
+  int32_t natoms;
+  int32_t ntypes;
+  int32_t nreplicas;           /* independent copies of the system (own neighbour lists)  */
+  int32_t device;              /* HIP device ordinal                                       */
+  const int32_t *types_host;   /* [natoms] index into the A/B tables                       */
+  const void *charges_host;    /* real [natoms], units of e                                */
+  const void *lj_A_host;       /* real [ntypes*ntypes] or NULL                             */
+  const void *lj_B_host;       /* real [ntypes*ntypes] or NULL                             */
+  const int32_t *excl_offsets_host; /* CSR [natoms+1]; row i = sorted partners of i (both directions stored) */
+  const int32_t *excl_index_host;   /* [excl_offsets[natoms]]                              */
+  uint32_t terms;              /* TMDHIP_TERM_* mask                                       */
+  int32_t rfa;                 /* reaction field on/off (needs cutoff)                     */
+  double cutoff;               /* Angstrom; <= 0: no cutoff                                */
+  double switch_dist;          /* Angstrom; <= 0: no switching                             */
+  double solvent_dielectric;   /* reference default 78.5                                   */
+  int32_t switch_mode;         /* TMDHIP_SWITCH_*                                          */
+  int32_t algorithm;           /* TMDHIP_ALGO_*                                            */
+  double skin;                 /* Verlet skin in Angstrom; <= 0: library default           */
+} tmdhip_nonbonded_desc;
+
+/* Bonded topology (already expanded: one parameter row per instance).  Replaces the per-call
+ * gathers of forces.py:122-258.  All index arrays are int32 host arrays; params are real. */
+typedef struct tmdhip_bonded_desc {
+  int32_t struct_size;
+  int32_t nbonds;
+  const int32_t *bond_idx_host;   /* [nbonds*2]                          */
+  const void *bond_prm_host;      /* real [nbonds*2] = (k0, d0)          */
+  int32_t nangles;
+  const int32_t *angle_idx_host;  /* [nangles*3]                         */
+  const void *angle_prm_host;     /* real [nangles*2] = (k0, theta0)     */
+  int32_t ndihedrals;             /* distinct proper torsions            */
+  const int32_t *dihedral_idx_host;   /* [ndihedrals*4]                  */
+  int32_t ndihedral_terms;
+  const int32_t *dihedral_term_of_host; /* [nterms] torsion each term belongs to, ascending */
+  const void *dihedral_prm_host;        /* real [nterms*3] = (k0, phi0, per)                */
+  int32_t nimpropers;
+  const int32_t *improper_idx_host;
+  int32_t nimproper_terms;
+  const int32_t *improper_term_of_host;
+  const void *improper_prm_host;
+  int32_t n14;
+  const int32_t *pair14_idx_host; /* [n14*2]                             */
+  const void *pair14_prm_host;    /* real [n14*4] = (A, B, scnb, scee)   */
+  uint32_t terms14;               /* TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS: which 1-4 parts are on */
+  int32_t bonds_use_cutoff;       /* reference filters bonds by `cutoff` when one is set (forces.py:128-136) */
+} tmdhip_bonded_desc;
+
+typedef struct tmdhip_stats {
+  int64_t n_compute;        /* tmdhip_compute calls on this replica                         */
+  int64_t n_rebuilds;       /* neighbour-list rebuilds                                      */
+  int64_t list_entries;     /* entries in the current (full) Verlet list                    */
+  int64_t pairs_in_cutoff;  /* result of the last TMDHIP_COUNT_PAIRS call                   */
+  int32_t algorithm;        /* algorithm in use                                             */
+  int32_t max_neighbours;   /* list capacity per atom                                       */
+  int32_t overflow;         /* != 0: a list is currently truncated (see tmdhip_check)       */
+  int32_t ncell[3];
+} tmdhip_stats;
+
+int tmdhip_abi_version(void);
+const char *tmdhip_last_error(void);
+
+/* Lifetime.  create copies every host array to the device. */
+int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc);
+int tmdhip_set_bonded(tmdhip_ctx *ctx, const tmdhip_bonded_desc *desc);
+void tmdhip_destroy(tmdhip_ctx *ctx);
+
+/* Nonbonded block of Forces.compute (forces.py:260-319) for one replica: minimum-image distances
+ * (360-372), `dist <= cutoff` filter (76-81), LJ (+switch) / Coulomb / reaction field / repulsion
+ * (381-491), force scatter and per-term energy sums (316-319).
+ * box_host = the three box edge lengths (diagonal of box[r], forces.py:118); all zero = no wrapping. */
+int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, const double *box_host,
+                             void *forces_dev, double *energies_dev, int flags, void *stream);
+
+/* Bonded block of Forces.compute (forces.py:122-258, 494-605). */
+int tmdhip_compute_bonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, const double *box_host,
+                          void *forces_dev, double *energies_dev, int flags, void *stream);
+
+/* Synchronises `stream` and verifies that no device-side neighbour-list rebuild since the last check
+ * ran out of list capacity.  Returns 0 = results valid, 1 = a list was truncated: the capacity has been
+ * grown, the next compute rebuilds, and the caller must repeat the evaluation; negative = error. */
+int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream);
+
+/* Host-synchronising query (copies a few words back). */
+int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out);
+
+/* HIP-event timing of the dominant (pair) kernel, recorded on the launch stream. */
+int tmdhip_timing_enable(tmdhip_ctx *ctx, int on);
+int tmdhip_timing_read(tmdhip_ctx *ctx, double *pair_kernel_ms, int64_t *launches, int reset);
+
+/* Integrator kernels (stateless).  n = nreplicas*natoms rows; mass_dev is real [natoms] and is
+ * indexed by (row % natoms) exactly like the broadcast of masses [N,1] in integrator.py:61-69. */
+/* _first_VV (integrator.py:61-64): pos += vel*dt + 0.5*(F/m)*dt*dt ; vel += 0.5*dt*(F/m) */
+int tmdhip_first_vv(int dtype, int64_t nreplicas, int64_t natoms, void *pos_dev, void *vel_dev,
+                    const void *forces_dev, const void *mass_dev, double dt, void *stream);
+/* _second_VV (integrator.py:67-69): vel += 0.5*dt*(F/m) */
+int tmdhip_second_vv(int dtype, int64_t nreplicas, int64_t natoms, void *vel_dev, const void *forces_dev,
+                     const void *mass_dev, double dt, void *stream);
+/* langevin (integrator.py:72-74) fused with _second_VV:
+ *   vel += -gamma*vel*dt + N(0,1)*vcoeff ; vel += 0.5*dt*(F/m)
+ * N(0,1) from a counter-based Philox4x32-10 stream keyed by (seed, step, row). */
+int tmdhip_langevin_second_vv(int dtype, int64_t nreplicas, int64_t natoms, void *vel_dev,
+                              const void *forces_dev, const void *mass_dev, const void *vcoeff_dev,
+                              double dt, double gamma, uint64_t seed, uint64_t step, void *stream);
+/* kinetic_energy (integrator.py:8-31, batch=None): ke_dev[r] = sum_i 0.5*m_i*|v_ri|^2 (overwrites) */
+int tmdhip_kinetic_energy(int dtype, int64_t nreplicas, int64_t natoms, const void *vel_dev,
+                          const void *mass_dev, double *ke_dev, void *stream);
+/* Fill `out_dev` (real [n]) with the N(0,1) stream used by tmdhip_langevin_second_vv (for tests). */
+int tmdhip_normal_fill(int dtype, int64_t n, void *out_dev, uint64_t seed, uint64_t step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMDHIP_H */

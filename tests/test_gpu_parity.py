@@ -1,0 +1,274 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI by
+`torchmd_amd.forces.Forces`, against (a) golden outputs of the reference itself and (b) the CPU oracle
+on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): forces within 1e-4 kcal/mol/A in fp64 and 1e-2 in fp32.
+The asserted bounds below are much tighter where the arithmetic allows it.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import GoldenParameters, PREC, box_tensor, energies, load, pos_tensor
+
+pytestmark = pytest.mark.gpu
+
+FTOL = {"f64": 1e-8, "f32": 2e-3}  # north-star bars: 1e-4 / 1e-2
+ERTOL = {"f64": 1e-10, "f32": 2e-5}
+ALL_TERMS = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _run(par, pos, box, terms, R=1, prec="f64", **kw):
+    from torchmd_amd.forces import Forces
+
+    dev = _dev()
+    dt = PREC[prec]
+    f = Forces(par, terms=terms, **kw)
+    p = pos_tensor(pos, R, dt, dev)
+    b = box_tensor(box, R, dt, dev)
+    F = torch.full_like(p, 7.0)  # must be overwritten, not accumulated
+    pots = f.compute(p, b, F, returnDetails=True)
+    return pots, F.cpu().numpy(), f, p, b
+
+
+def _compare(g, tag, pots, F, terms, prec, R=1):
+    for r in range(R):
+        ref = energies(g, tag, r)
+        for t in terms:
+            if t == "1-4":
+                assert pots[r][t] == 0.0
+                continue
+            scale = max(1.0, abs(ref[t]))
+            assert abs(pots[r][t] - ref[t]) <= ERTOL[prec] * scale * 50, (tag, t, pots[r][t], ref[t])
+        assert "external" in pots[r]
+    err = np.abs(F - g[tag + "_forces"]).max()
+    assert err <= FTOL[prec], (tag, err)
+    return err
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("rfa", [False, True])
+def test_water291(prec, rfa):
+    """C1: tests/water, 291 atoms, R=2, cutoff 7.3 (box too small for cells -> all-pairs kernel)."""
+    g = load("water291")
+    par = GoldenParameters(g, PREC[prec])
+    full = ["lj", "bonds", "angles", "electrostatics"]
+    for label, terms in (("full", full), ("nb", ["lj", "electrostatics"])):
+        pots, F, f, p, b = _run(par, g["pos"], g["box"], terms, R=2, prec=prec, cutoff=7.3, rfa=rfa)
+        _compare(g, f"{prec}_{label}_rfa{int(rfa)}", pots, F, terms, prec, R=2)
+        assert f.stats(p)["algorithm"] == "allpairs"
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_ala2_all_variants(prec):
+    """C2: alanine dipeptide, all 7 terms, cutoff 9 / switch 7.5 / reaction field, periodic and box=0,
+    plus no-cutoff Coulomb, the no-switch variant and the repulsion terms."""
+    g = load("ala2")
+    par = GoldenParameters(g, PREC[prec])
+    sw = dict(cutoff=9.0, switch_dist=7.5, rfa=True)
+    zero = np.zeros(3)
+    worst = 0.0
+    for label, terms in (("full", ALL_TERMS), ("nb", ["electrostatics", "lj"])):
+        for tag, box, kw in (("pbc", g["box"], sw), ("box0", zero, sw), ("nocut", zero, {})):
+            pots, F, *_ = _run(par, g["pos"], box, terms, prec=prec, **kw)
+            worst = max(worst, _compare(g, f"{prec}_{label}_{tag}", pots, F, terms, prec))
+    pots, F, *_ = _run(par, g["pos"], g["box"], ["electrostatics", "lj"], prec=prec, cutoff=9.0, rfa=True)
+    _compare(g, f"{prec}_nb_pbc_noswitch", pots, F, ["electrostatics", "lj"], prec)
+    for t in ("repulsion", "repulsioncg"):
+        pots, F, *_ = _run(par, g["pos"], g["box"], [t], prec=prec, cutoff=9.0)
+        _compare(g, f"{prec}_{t}_pbc", pots, F, [t], prec)
+    print(f"ala2 {prec}: max |dF| over variants = {worst:.3e}")
+
+
+def test_ala2_pair_count_matches_reference_filter():
+    """The number of pairs passing `dist <= cutoff` is the reference's (decision arithmetic)."""
+    from oracle import torchmd_oracle as orc
+
+    g = load("ala2")
+    for prec in ("f64", "f32"):
+        par = GoldenParameters(g, PREC[prec])
+        _, _, npairs = orc.compute(par, pos_tensor(g["pos"], 1, PREC[prec]), box_tensor(g["box"], 1, PREC[prec]),
+                                   ["lj"], cutoff=9.0)
+        _, _, f, p, b = _run(par, g["pos"], g["box"], ["lj"], prec=prec, cutoff=9.0)
+        assert f.count_pairs(p, b) == npairs
+
+
+def test_switch_modes():
+    """Explicit forces keep upstream's switching quirk; explicit_forces=False gives -dE/dr."""
+    from torchmd_amd.forces import Forces
+
+    g = load("ala2")
+    dev = _dev()
+    par = GoldenParameters(g, torch.float64)
+    p = pos_tensor(g["pos"], 1, torch.float64, dev)
+    b = box_tensor(g["box"], 1, torch.float64, dev)
+    f = Forces(par, terms=["lj"], cutoff=9.0, switch_dist=7.5)
+    F_ref = torch.zeros_like(p)
+    f.compute(p, b, F_ref)
+    F_auto = torch.zeros_like(p)
+    pg = p.clone().requires_grad_(True)
+    f.compute(pg, b, F_auto, explicit_forces=False)
+    assert (F_ref - F_auto).abs().max() > 1e-3  # the quirk is visible (SURVEY: 0.014 on this system)
+    # finite-difference check of the exact mode on one coordinate
+    h = 1e-4
+    e = []
+    for s in (+h, -h):
+        q = p.clone()
+        q[0, 5, 1] += s
+        e.append(f.compute(q, b, None, calculateForces=False)[0])
+    fd = -(e[0] - e[1]) / (2 * h)
+    assert abs(fd - F_auto[0, 5, 1].item()) < 1e-5
+    # differentiable potential
+    pot = f.compute(pg, b, None, explicit_forces=False, toNumpy=False)
+    (grad,) = torch.autograd.grad(pot.sum(), pg)
+    assert torch.allclose(-grad, F_auto, atol=1e-12)
+
+
+def test_thrombin_nocut_and_celllist():
+    """4 676-atom non-periodic complex: no-cutoff all-pairs vs the reference golden, then the same
+    system with a 9 A cutoff through the cell-list path vs the all-pairs kernel and the oracle."""
+    from oracle import torchmd_oracle as orc
+
+    g = load("thrombin")
+    par = GoldenParameters(g, torch.float64)
+    zero = np.zeros(3)
+    terms = ["electrostatics", "lj"]
+    pots, F, *_ = _run(par, g["pos"], zero, terms, prec="f64")
+    _compare(g, "f64_nb_nocut", pots, F, terms, "f64")
+    pots, F, *_ = _run(par, g["pos"], zero, ALL_TERMS, prec="f64")
+    _compare(g, "f64_full_nocut", pots, F, ALL_TERMS, "f64")
+
+    kw = dict(cutoff=9.0, rfa=True, switch_dist=7.5)
+    pots_c, F_c, fc, p, b = _run(par, g["pos"], zero, terms, prec="f64", algorithm="celllist", **kw)
+    pots_a, F_a, fa, _, _ = _run(par, g["pos"], zero, terms, prec="f64", algorithm="allpairs", **kw)
+    assert fc.stats(p)["algorithm"] == "celllist" and fa.stats(p)["algorithm"] == "allpairs"
+    assert np.abs(F_c - F_a).max() < 1e-9
+    pairs = orc.candidate_pairs(g["pos"], zero, 9.5, orc.exclusion_pairs(par))
+    po, Fo, npairs = orc.compute(par, pos_tensor(g["pos"], 1, torch.float64), box_tensor(zero, 1, torch.float64),
+                                 terms, pairs=pairs, **kw)
+    assert np.abs(F_c - Fo.numpy()).max() < 1e-8
+    for t in terms:
+        assert abs(pots_c[0][t] - po[0][t]) < 1e-8 * max(1, abs(po[0][t]))
+    assert fc.count_pairs(p, b) == npairs
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_water_box_celllist_vs_oracle(prec):
+    """Synthetic TIP3P box (12^3 molecules = 5 184 atoms, L = 37.3 A): cell-list path vs all-pairs
+    kernel vs oracle, incl. the in-cutoff pair count and list rebuilds after moving atoms."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev = _dev()
+    dt = PREC[prec]
+    mol, pos, box = tip3p_box(12, seed=3)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    kw = dict(cutoff=9.0, rfa=True)
+    p32 = pos_tensor(pos, 1, dt)
+    pairs = orc.candidate_pairs(pos, box, 9.6, orc.exclusion_pairs(par))
+    po, Fo, npairs = orc.compute(par, p32, box_tensor(box, 1, dt), terms, pairs=pairs, **kw)
+    res = {}
+    for algo in ("celllist", "allpairs"):
+        f = Forces(par, terms=terms, algorithm=algo, **kw)
+        p, b = p32.to(dev), box_tensor(box, 1, dt, dev)
+        F = torch.zeros_like(p)
+        pots = f.compute(p, b, F, returnDetails=True)
+        assert f.stats(p)["algorithm"] == algo
+        assert f.count_pairs(p, b) == npairs, algo
+        err = (F.cpu() - Fo).abs().max().item()
+        assert err < FTOL[prec], (algo, err)
+        for t in terms:
+            assert abs(pots[0][t] - po[0][t]) <= ERTOL[prec] * 50 * max(1, abs(po[0][t])), (algo, t)
+        res[algo] = F.cpu()
+    assert (res["celllist"] - res["allpairs"]).abs().max() < FTOL[prec]
+
+    # move atoms: small displacement (no rebuild needed), then a large one (device-side rebuild)
+    f = Forces(par, terms=["lj", "electrostatics"], algorithm="celllist", **kw)
+    p, b = p32.to(dev), box_tensor(box, 1, dt, dev)
+    F = torch.zeros_like(p)
+    f.compute(p, b, F)
+    rebuilds0 = f.stats(p)["n_rebuilds"]
+    rng = np.random.default_rng(1)
+    for scale, expect_rebuild in ((0.2, False), (1.5, True)):
+        d = torch.tensor(rng.uniform(-1, 1, size=pos.shape) * scale / np.sqrt(3), dtype=dt)
+        pm = (p32[0] + d)[None].contiguous()
+        f.compute(pm.to(dev), b, F)
+        _, Fm, _ = orc.compute(par, pm, box_tensor(box, 1, dt), ["lj", "electrostatics"],
+                               pairs=orc.candidate_pairs(pm[0].double().numpy(), box, 9.6, orc.exclusion_pairs(par)),
+                               **kw)
+        assert (F.cpu() - Fm).abs().max().item() < FTOL[prec] * 5
+        assert (f.stats(p)["n_rebuilds"] > rebuilds0) == expect_rebuild
+        rebuilds0 = f.stats(p)["n_rebuilds"]
+    # atoms translated by whole box vectors keep the list valid and the forces identical
+    shift = torch.tensor(rng.integers(-2, 3, size=pos.shape), dtype=dt) * torch.tensor(box, dtype=dt)
+    F2 = torch.zeros_like(F)
+    f.compute((pm[0] + shift)[None].contiguous().to(dev), b, F2)
+    # (fp32 positions lose ~1e-5 A when shifted by two box lengths, hence the looser fp32 bound)
+    assert (F2 - F).abs().max().item() < (5e-2 if prec == "f32" else 1e-8)
+    assert f.stats(p)["n_rebuilds"] == rebuilds0
+
+
+def test_replicas_independent_lists():
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev = _dev()
+    mol, pos, box = tip3p_box(12, seed=5)
+    par = Parameters(water_forcefield(mol), mol, ["lj", "electrostatics"], precision=torch.float32)
+    f = Forces(par, terms=["lj", "electrostatics"], cutoff=9.0, rfa=True, algorithm="celllist")
+    rng = np.random.default_rng(0)
+    p = torch.tensor(np.stack([pos, pos + rng.normal(scale=0.3, size=pos.shape)]), dtype=torch.float32, device=dev)
+    b = box_tensor(box, 2, torch.float32, dev)
+    F = torch.zeros_like(p)
+    e2 = f.compute(p, b, F)
+    F1 = torch.zeros_like(p[1:2])
+    e1 = f.compute(p[1:2].contiguous(), b[1:2], F1)
+    assert abs(e2[1] - e1[0]) < 1e-4 * abs(e1[0])
+    assert (F[1:2] - F1).abs().max().item() < 1e-3
+    assert abs(e2[0] - e2[1]) > 1.0  # replicas really differ
+
+
+def test_errors_and_api_surface():
+    from torchmd_amd.forces import Forces
+
+    g = load("water291")
+    par = GoldenParameters(g, torch.float32)
+    with pytest.raises(RuntimeError):
+        Forces(par)
+    with pytest.raises(ValueError):
+        Forces(par, terms=["nope"])
+    with pytest.raises(RuntimeError):
+        Forces(par, terms=["1-4"])
+    f = Forces(par, terms=["LJ", "Electrostatics"], cutoff=7.3)
+    assert f.energies == ["lj", "electrostatics"] and f.natoms == 291
+    assert f.ava_idx.shape == (41904, 2)  # P_all of tests/water
+    dev = _dev()
+    p = pos_tensor(g["pos"], 1, torch.float32, dev)
+    b = box_tensor(g["box"], 1, torch.float32, dev)
+    with pytest.raises(RuntimeError):
+        f.compute(p, b, torch.zeros_like(p), explicit_forces=False)  # pos does not require grad
+    out = f.compute(p, b, torch.zeros_like(p))
+    assert isinstance(out, list) and isinstance(out[0], float)
+    out = f.compute(p, b, torch.zeros_like(p), toNumpy=False)
+    assert torch.is_tensor(out) and out.shape == (1,) and out.dtype == torch.float32
+
+    class Ext:  # the reference's plugin hook (forces.py:321-326)
+        def calculate(self, pos, box):
+            return torch.full((pos.shape[0],), 2.5, device=pos.device), torch.ones_like(pos)
+
+    fe = Forces(par, terms=["lj"], cutoff=7.3, external=Ext())
+    F0, F1 = torch.zeros_like(p), torch.zeros_like(p)
+    d0 = Forces(par, terms=["lj"], cutoff=7.3).compute(p, b, F0, returnDetails=True)
+    d1 = fe.compute(p, b, F1, returnDetails=True)
+    assert d1[0]["external"] == 2.5 and abs(d1[0]["lj"] - d0[0]["lj"]) < 1e-6
+    assert torch.allclose(F1 - F0, torch.ones_like(F0), atol=1e-5)

@@ -1,0 +1,218 @@
+"""ctypes binding of `libtmdhip.so` (C ABI declared in include/tmdhip.h).
+
+The library is the product; there is no fallback.  If it cannot be loaded every entry point raises
+`RuntimeError` with build instructions.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(PKG, "lib", "libtmdhip.so")
+
+ABI_VERSION = 1
+F32, F64 = 0, 1
+TERM_LJ, TERM_ELECTROSTATICS, TERM_REPULSION, TERM_REPULSIONCG = 1, 2, 4, 8
+E_LJ, E_ELECTROSTATICS, E_REPULSION, E_REPULSIONCG, E_BONDS, E_ANGLES, E_DIHEDRALS, E_IMPROPERS = range(8)
+NENERGY = 8
+WANT_ENERGY, WANT_FORCES, COUNT_PAIRS = 1, 2, 4
+ALGO_AUTO, ALGO_ALLPAIRS, ALGO_CELLLIST = 0, 1, 2
+SWITCH_REFERENCE, SWITCH_EXACT = 0, 1
+
+ENERGY_SLOT = {
+    "lj": E_LJ,
+    "electrostatics": E_ELECTROSTATICS,
+    "repulsion": E_REPULSION,
+    "repulsioncg": E_REPULSIONCG,
+    "bonds": E_BONDS,
+    "angles": E_ANGLES,
+    "dihedrals": E_DIHEDRALS,
+    "impropers": E_IMPROPERS,
+}
+TERM_BIT = {
+    "lj": TERM_LJ,
+    "electrostatics": TERM_ELECTROSTATICS,
+    "repulsion": TERM_REPULSION,
+    "repulsioncg": TERM_REPULSIONCG,
+}
+
+
+class NonbondedDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("dtype", C.c_int32),
+        ("natoms", C.c_int32),
+        ("ntypes", C.c_int32),
+        ("nreplicas", C.c_int32),
+        ("device", C.c_int32),
+        ("types_host", C.c_void_p),
+        ("charges_host", C.c_void_p),
+        ("lj_A_host", C.c_void_p),
+        ("lj_B_host", C.c_void_p),
+        ("excl_offsets_host", C.c_void_p),
+        ("excl_index_host", C.c_void_p),
+        ("terms", C.c_uint32),
+        ("rfa", C.c_int32),
+        ("cutoff", C.c_double),
+        ("switch_dist", C.c_double),
+        ("solvent_dielectric", C.c_double),
+        ("switch_mode", C.c_int32),
+        ("algorithm", C.c_int32),
+        ("skin", C.c_double),
+    ]
+
+
+class BondedDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("nbonds", C.c_int32),
+        ("bond_idx_host", C.c_void_p),
+        ("bond_prm_host", C.c_void_p),
+        ("nangles", C.c_int32),
+        ("angle_idx_host", C.c_void_p),
+        ("angle_prm_host", C.c_void_p),
+        ("ndihedrals", C.c_int32),
+        ("dihedral_idx_host", C.c_void_p),
+        ("ndihedral_terms", C.c_int32),
+        ("dihedral_term_of_host", C.c_void_p),
+        ("dihedral_prm_host", C.c_void_p),
+        ("nimpropers", C.c_int32),
+        ("improper_idx_host", C.c_void_p),
+        ("nimproper_terms", C.c_int32),
+        ("improper_term_of_host", C.c_void_p),
+        ("improper_prm_host", C.c_void_p),
+        ("n14", C.c_int32),
+        ("pair14_idx_host", C.c_void_p),
+        ("pair14_prm_host", C.c_void_p),
+        ("terms14", C.c_uint32),
+        ("bonds_use_cutoff", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_compute", C.c_int64),
+        ("n_rebuilds", C.c_int64),
+        ("list_entries", C.c_int64),
+        ("pairs_in_cutoff", C.c_int64),
+        ("algorithm", C.c_int32),
+        ("max_neighbours", C.c_int32),
+        ("overflow", C.c_int32),
+        ("ncell", C.c_int32 * 3),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/tmdhip.h declares
+SIGNATURES = {
+    "tmdhip_abi_version": (C.c_int, []),
+    "tmdhip_last_error": (C.c_char_p, []),
+    "tmdhip_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NonbondedDesc)]),
+    "tmdhip_set_bonded": (C.c_int, [C.c_void_p, C.POINTER(BondedDesc)]),
+    "tmdhip_destroy": (None, [C.c_void_p]),
+    "tmdhip_compute_nonbonded": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    ),
+    "tmdhip_compute_bonded": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    ),
+    "tmdhip_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "tmdhip_get_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Stats)]),
+    "tmdhip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "tmdhip_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "tmdhip_first_vv": (
+        C.c_int,
+        [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p],
+    ),
+    "tmdhip_second_vv": (
+        C.c_int,
+        [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p],
+    ),
+    "tmdhip_langevin_second_vv": (
+        C.c_int,
+        [
+            C.c_int,
+            C.c_int64,
+            C.c_int64,
+            C.c_void_p,
+            C.c_void_p,
+            C.c_void_p,
+            C.c_void_p,
+            C.c_double,
+            C.c_double,
+            C.c_uint64,
+            C.c_uint64,
+            C.c_void_p,
+        ],
+    ),
+    "tmdhip_kinetic_energy": (
+        C.c_int,
+        [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "tmdhip_normal_fill": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return LIBPATH
+
+
+def load():
+    """Load (once) and return the ctypes handle.  torch is imported first so that the HIP runtime the
+    library resolves against (SONAME libamdhip64.so.7) is the one torch already mapped."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps torch's libamdhip64 before ours is resolved)
+
+    if not os.path.exists(LIBPATH):
+        raise RuntimeError(
+            f"{LIBPATH} is missing: the HIP extension has not been built. Run "
+            "`python -m torchmd_amd._build` (needs hipcc, cross-compiles for gfx950 without a GPU). "
+            "torchmd_amd has no CPU or PyTorch fallback."
+        )
+    try:
+        lib = C.CDLL(LIBPATH, mode=C.RTLD_GLOBAL)
+    except OSError as exc:  # pragma: no cover
+        raise RuntimeError(f"could not load {LIBPATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tmdhip_abi_version() != ABI_VERSION:
+        raise RuntimeError("libtmdhip.so ABI version mismatch: rebuild with `python -m torchmd_amd._build --force`")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().tmdhip_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "tmdhip"):
+    if rc < 0:
+        raise RuntimeError(f"{what}: {last_error()}")
+    return rc
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+
+    if torch_dtype == torch.float32:
+        return F32
+    if torch_dtype == torch.float64:
+        return F64
+    raise TypeError(f"torchmd_amd supports float32 and float64 tensors, got {torch_dtype}")
+
+
+def require_device_tensor(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"`{name}` lives on '{t.device}': torchmd_amd evaluates the hot path with HIP kernels on a ROCm "
+            "device only (device='cuda'); there is no CPU fallback. Use the reference torchmd for CPU runs."
+        )

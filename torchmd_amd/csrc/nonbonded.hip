@@ -1,0 +1,1010 @@
+// Nonbonded force/energy engine for gfx950 (MI355X): tiled all-pairs kernel, cell binning,
+// Verlet-list build and the list pair kernel, plus the C-ABI context that owns their buffers.
+//
+// Reference semantics: torchmd/forces.py:260-319 (nonbonded block of Forces.compute) with
+// 348-357 (pair set = all i<j minus exclusions), 360-372 (minimum image, distances), 76-81
+// (cutoff filter) and 381-491 (pair potentials).  The reference evaluates a dense [P,2] pair tensor
+// every step; here the same pair set is produced by an O(N) cell list + Verlet list with a skin,
+// and each unique pair is evaluated from both of its atoms (full list, no atomics, no j-force
+// reduction) — a gather/stream kernel bound by HBM/L2 traffic of the neighbour indices and by the
+// fp32 vector ALU, not an MFMA problem.
+//
+// Data layout in HBM (per replica):
+//   sorted_xyzq  real4[N]   positions in cell-sorted order + scaled charge q*sqrt(k_e)
+//   sorted_type  int32[N]
+//   order        int32[N]   cell-sorted slot -> original atom index
+//   nlist        uint32[G * maxn * APW]   G = ceil(N/APW) wave groups, APW = 64/LPA atoms per wave;
+//                entry k of the a-th atom of group g lives at  g*maxn*APW + (k/LPA)*64 + a*LPA + k%LPA
+//                so that one wave-wide load of iteration kk reads 64 consecutive words (256 B).
+//                entry = j (24 bit, sorted slot) | type_j << 24
+//   nneigh       int32[N]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "common.h"
+#include "pair_math.h"
+
+namespace tmd {
+
+std::string &last_error() {
+  static thread_local std::string s;
+  return s;
+}
+int fail(const std::string &msg) {
+  last_error() = msg;
+  return -1;
+}
+
+// =============================================================================================
+// device kernels
+// =============================================================================================
+
+// ---- K4: tiled all-pairs ----------------------------------------------------------------------
+// grid = (ceil(N/64), nsplit); one wave per block.  Lane = one i atom, the j range of this block is
+// streamed through LDS in tiles of 64 (broadcast reads).  Every (i,j) with i != j is evaluated from
+// i's side only, so forces need no cross-lane reduction; blocks with different j ranges combine
+// through one atomic add per atom.
+template <typename R, bool ENERGY>
+__global__ __launch_bounds__(64) void allpairs_kernel(
+    int n, const R *__restrict__ pos, const R *__restrict__ qs, const int *__restrict__ types, int ntypes,
+    const typename Vec<R>::T2 *__restrict__ tab, const int *__restrict__ excl_off,
+    const int *__restrict__ excl_idx, PairConsts<R> c, int jchunk, R *__restrict__ forces,
+    double *__restrict__ energies, unsigned long long *__restrict__ paircount) {
+  using R4 = typename Vec<R>::T4;
+  __shared__ R4 sj[64];
+  __shared__ int st[64];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * 64 + lane;
+  const bool active = i < n;
+  const int jbeg = blockIdx.y * jchunk;
+  const int jend = min(n, jbeg + jchunk);
+
+  R xi = 0, yi = 0, zi = 0, qi = 0;
+  int trow = 0;
+  int e = 0, eend = 0;
+  if (active) {
+    xi = pos[3 * i + 0];
+    yi = pos[3 * i + 1];
+    zi = pos[3 * i + 2];
+    qi = qs[i];
+    trow = types[i] * ntypes;
+    e = excl_off[i];
+    eend = excl_off[i + 1];
+    while (e < eend && excl_idx[e] < jbeg) ++e;
+  }
+  R fx = 0, fy = 0, fz = 0;
+  R en[4] = {0, 0, 0, 0};
+  unsigned long long cnt = 0;
+
+  for (int j0 = jbeg; j0 < jend; j0 += 64) {
+    __syncthreads();
+    const int jl = j0 + lane;
+    if (jl < jend) {
+      R4 v;
+      v.x = pos[3 * jl + 0];
+      v.y = pos[3 * jl + 1];
+      v.z = pos[3 * jl + 2];
+      v.w = qs[jl];
+      sj[lane] = v;
+      st[lane] = types[jl];
+    }
+    __syncthreads();
+    // exclusion mask of this tile for atom i (rows of the CSR are sorted)
+    unsigned long long skip = 0;
+    while (e < eend && excl_idx[e] < j0 + 64) {
+      skip |= 1ull << (excl_idx[e] - j0);
+      ++e;
+    }
+    if (i >= j0 && i < j0 + 64) skip |= 1ull << (i - j0);
+    const int tile = min(64, jend - j0);
+    for (int k = 0; k < tile; ++k) {
+      const R4 pj = sj[k];
+      const R dx = min_image(xi - pj.x, c.box[0], c.invbox[0]);
+      const R dy = min_image(yi - pj.y, c.box[1], c.invbox[1]);
+      const R dz = min_image(zi - pj.z, c.box[2], c.invbox[2]);
+      const R r2 = norm2(dx, dy, dz);
+      const bool hit = active && !((skip >> k) & 1ull) && (r2 <= c.r2max);
+      if (hit) {
+        const typename Vec<R>::T2 ab = tab[trow + st[k]];
+        const R fs = pair_terms<R, ENERGY>(c, r2, qi * pj.w, ab.x, ab.y, en);
+        fx -= dx * fs;
+        fy -= dy * fs;
+        fz -= dz * fs;
+        if (j0 + k > i) ++cnt;
+      }
+    }
+  }
+  if (active && forces) {
+    unsafeAtomicAdd(&forces[3 * i + 0], fx);
+    unsafeAtomicAdd(&forces[3 * i + 1], fy);
+    unsafeAtomicAdd(&forces[3 * i + 2], fz);
+  }
+  if (ENERGY) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double s = wave_sum((double)en[t]);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energies[t], 0.5 * s);
+    }
+  }
+  if (paircount) {
+    const unsigned long long s = wave_sum(cnt);
+    if (lane == 0 && s) atomicAdd(paircount, s);
+  }
+}
+
+// ---- cell grid ----------------------------------------------------------------------------------
+struct Grid {
+  int nc[3];
+  int m;          // stencil half-width in cells
+  int periodic;   // 1: wrap cell coordinates, 0: clamp (open boundaries)
+  double origin[3];
+  double inv_edge[3];  // cells per Angstrom
+};
+
+template <typename R>
+__device__ __forceinline__ int cell_coord(R x, const Grid &g, int d) {
+  double f = ((double)x - g.origin[d]) * g.inv_edge[d];
+  int nc = g.nc[d];
+  if (g.periodic) {
+    f -= floor(f / nc) * nc;
+    int cidx = (int)f;
+    return cidx >= nc ? nc - 1 : (cidx < 0 ? 0 : cidx);
+  }
+  int cidx = (int)floor(f);
+  return cidx < 0 ? 0 : (cidx >= nc ? nc - 1 : cidx);
+}
+
+// flags[p] = "rebuild requested in the step with parity p".  The check kernel of parity p may only
+// SET flags[p] and CLEAR flags[p^1]; every other kernel of that step only reads flags[p].
+template <typename R>
+__global__ void check_displacement_kernel(int n, const R *__restrict__ pos, const R *__restrict__ ref,
+                                          PairConsts<R> c, R thresh2, int *flags, int parity, int force) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    flags[parity ^ 1] = 0;
+    if (force) flags[parity] = 1;
+  }
+  if (i >= n || force) return;
+  const R dx = min_image(pos[3 * i + 0] - ref[3 * i + 0], c.box[0], c.invbox[0]);
+  const R dy = min_image(pos[3 * i + 1] - ref[3 * i + 1], c.box[1], c.invbox[1]);
+  const R dz = min_image(pos[3 * i + 2] - ref[3 * i + 2], c.box[2], c.invbox[2]);
+  const R d2 = dx * dx + dy * dy + dz * dz;
+  if (!(d2 <= thresh2)) flags[parity] = 1;  // NaN positions also force a rebuild
+}
+
+template <typename R>
+__global__ void bin_count_kernel(int n, const R *__restrict__ pos, Grid g, int *__restrict__ cell_of,
+                                 int *__restrict__ slot, int *__restrict__ count, const int *flag) {
+  if (*flag == 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cx = cell_coord(pos[3 * i + 0], g, 0);
+  const int cy = cell_coord(pos[3 * i + 1], g, 1);
+  const int cz = cell_coord(pos[3 * i + 2], g, 2);
+  const int cidx = (cx * g.nc[1] + cy) * g.nc[2] + cz;
+  cell_of[i] = cidx;
+  slot[i] = atomicAdd(&count[cidx], 1);
+}
+
+// single block; cell_start[ncell] = n afterwards; counts are zeroed for the next rebuild
+__global__ void scan_cells_kernel(int ncell, int *__restrict__ count, int *__restrict__ cell_start,
+                                  const int *flag) {
+  if (*flag == 0) return;
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int t = threadIdx.x;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ncell; base += 1024) {
+    const int idx = base + t;
+    const int v = idx < ncell ? count[idx] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int add = t >= o ? part[t - o] : 0;
+      __syncthreads();
+      part[t] += add;
+      __syncthreads();
+    }
+    if (idx < ncell) {
+      cell_start[idx] = carry + part[t] - v;
+      count[idx] = 0;
+    }
+    __syncthreads();
+    if (t == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (t == 0) cell_start[ncell] = carry;
+}
+
+__global__ void fill_cells_kernel(int n, const int *__restrict__ cell_of, const int *__restrict__ slot,
+                                  const int *__restrict__ cell_start, int *__restrict__ order_tmp,
+                                  const int *flag) {
+  if (*flag == 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  order_tmp[cell_start[cell_of[i]] + slot[i]] = i;
+}
+
+// deterministic order inside a cell: rank by original index
+__global__ void sort_in_cell_kernel(int n, const int *__restrict__ cell_of, const int *__restrict__ cell_start,
+                                    const int *__restrict__ order_tmp, int *__restrict__ order,
+                                    const int *flag) {
+  if (*flag == 0) return;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const int me = order_tmp[a];
+  const int cidx = cell_of[me];
+  const int s = cell_start[cidx], e = cell_start[cidx + 1];
+  int rank = 0;
+  for (int k = s; k < e; ++k) rank += order_tmp[k] < me;
+  order[s + rank] = me;
+}
+
+// every step: refresh the cell-sorted coordinate copy; on rebuild steps also types and the
+// reference positions of the displacement test
+template <typename R>
+__global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const R *__restrict__ qs,
+                                     const int *__restrict__ types, const int *__restrict__ order,
+                                     typename Vec<R>::T4 *__restrict__ sorted, int *__restrict__ stype,
+                                     R *__restrict__ ref, const int *flag) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const int i = order[a];
+  typename Vec<R>::T4 v;
+  v.x = pos[3 * i + 0];
+  v.y = pos[3 * i + 1];
+  v.z = pos[3 * i + 2];
+  v.w = qs[i];
+  sorted[a] = v;
+  if (*flag) {
+    stype[a] = types[i];
+    ref[3 * i + 0] = v.x;
+    ref[3 * i + 1] = v.y;
+    ref[3 * i + 2] = v.z;
+  }
+}
+
+struct ListGeom {
+  int lpa;   // lanes per atom in the pair kernel (power of two, 1..64)
+  int apw;   // atoms per wave = 64 / lpa
+  int maxn;  // capacity per atom (multiple of lpa)
+};
+
+__device__ __forceinline__ size_t list_slot(const ListGeom &lg, int a, int k) {
+  const int g = a / lg.apw, ain = a % lg.apw;
+  return (size_t)g * lg.maxn * lg.apw + (size_t)(k / lg.lpa) * 64 + ain * lg.lpa + (k % lg.lpa);
+}
+
+// ---- K2: Verlet list build ---------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(256) void build_list_kernel(
+    int n, const typename Vec<R>::T4 *__restrict__ sorted, const int *__restrict__ stype,
+    const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2,
+    const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
+    unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag) {
+  if (*flag == 0) return;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  int cnt = 0;
+  if (a < n) {
+    const typename Vec<R>::T4 pi = sorted[a];
+    const int oi = order[a];
+    const int eb = excl_off[oi], ee = excl_off[oi + 1];
+    const int cx = cell_coord(pi.x, g, 0), cy = cell_coord(pi.y, g, 1), cz = cell_coord(pi.z, g, 2);
+    for (int ox = -g.m; ox <= g.m; ++ox) {
+      int x = cx + ox;
+      if (g.periodic) x = (x + g.nc[0]) % g.nc[0];
+      else if (x < 0 || x >= g.nc[0]) continue;
+      for (int oy = -g.m; oy <= g.m; ++oy) {
+        int y = cy + oy;
+        if (g.periodic) y = (y + g.nc[1]) % g.nc[1];
+        else if (y < 0 || y >= g.nc[1]) continue;
+        for (int oz = -g.m; oz <= g.m; ++oz) {
+          int z = cz + oz;
+          if (g.periodic) z = (z + g.nc[2]) % g.nc[2];
+          else if (z < 0 || z >= g.nc[2]) continue;
+          const int cidx = (x * g.nc[1] + y) * g.nc[2] + z;
+          const int s = cell_start[cidx], e = cell_start[cidx + 1];
+          for (int j = s; j < e; ++j) {
+            if (j == a) continue;
+            const typename Vec<R>::T4 pj = sorted[j];
+            const R dx = min_image(pi.x - pj.x, c.box[0], c.invbox[0]);
+            const R dy = min_image(pi.y - pj.y, c.box[1], c.invbox[1]);
+            const R dz = min_image(pi.z - pj.z, c.box[2], c.invbox[2]);
+            const R r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 <= rlist2) {
+              const int oj = order[j];
+              bool ex = false;
+              for (int q = eb; q < ee; ++q) ex |= (excl_idx[q] == oj);
+              if (!ex) {
+                if (cnt < lg.maxn) nlist[list_slot(lg, a, cnt)] = (unsigned)j | ((unsigned)stype[j] << 24);
+                ++cnt;
+              }
+            }
+          }
+        }
+      }
+    }
+    nneigh[a] = min(cnt, lg.maxn);
+    if (a == 0) status[1] += 1;  // flags[3]: number of rebuilds
+  }
+  // flags[2] = largest neighbour count ever seen; > maxn means a list was truncated (overflow)
+  int wmax = cnt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+  if ((threadIdx.x & 63) == 0 && wmax > 0) atomicMax(status, wmax);
+}
+
+// ---- K3: list pair kernel ------------------------------------------------------------------------
+// LPA lanes cooperate on one atom (strided over its list), APW = 64/LPA atoms per wave.
+template <typename R, bool ENERGY, int LPA>
+__global__ __launch_bounds__(256) void list_pair_kernel(
+    int n, const typename Vec<R>::T4 *__restrict__ sorted, const int *__restrict__ stype,
+    const int *__restrict__ order, int ntypes, const typename Vec<R>::T2 *__restrict__ tab,
+    const unsigned *__restrict__ nlist, const int *__restrict__ nneigh, int maxn, PairConsts<R> c,
+    R *__restrict__ forces, double *__restrict__ energies, unsigned long long *__restrict__ paircount) {
+  using R4 = typename Vec<R>::T4;
+  using R2 = typename Vec<R>::T2;
+  constexpr int APW = 64 / LPA;
+  extern __shared__ __align__(16) unsigned char smem[];
+  R2 *stab = reinterpret_cast<R2 *>(smem);
+  for (int t = threadIdx.x; t < ntypes * ntypes; t += blockDim.x) stab[t] = tab[t];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int a = wave * APW + lane / LPA;
+  const int sub = lane % LPA;
+  const bool active = a < n;
+  R4 pi;
+  pi.x = pi.y = pi.z = pi.w = 0;
+  int nn = 0, trow = 0;
+  if (active) {
+    pi = sorted[a];
+    nn = nneigh[a];
+    trow = stype[a] * ntypes;
+  }
+  int nmax = nn;
+#pragma unroll
+  for (int o = 32; o >= LPA; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  const unsigned *row = nlist + (size_t)wave * maxn * APW + lane;
+
+  R fx = 0, fy = 0, fz = 0;
+  R en[4] = {0, 0, 0, 0};
+  unsigned cnt = 0;
+  for (int k = sub, kk = 0; kk * LPA < nmax; ++kk, k += LPA) {
+    const unsigned entry = row[(size_t)kk * 64];
+    const bool valid = k < nn;
+    const int j = valid ? (int)(entry & 0xFFFFFFu) : (active ? a : 0);
+    const int tj = valid ? (int)(entry >> 24) : 0;
+    const R4 pj = sorted[j];
+    const R dx = min_image(pi.x - pj.x, c.box[0], c.invbox[0]);
+    const R dy = min_image(pi.y - pj.y, c.box[1], c.invbox[1]);
+    const R dz = min_image(pi.z - pj.z, c.box[2], c.invbox[2]);
+    const R r2 = norm2(dx, dy, dz);
+    if (valid && r2 <= c.r2max) {
+      const R2 ab = stab[trow + tj];
+      const R fs = pair_terms<R, ENERGY>(c, r2, pi.w * pj.w, ab.x, ab.y, en);
+      fx -= dx * fs;
+      fy -= dy * fs;
+      fz -= dz * fs;
+      ++cnt;
+    }
+  }
+#pragma unroll
+  for (int o = LPA >> 1; o > 0; o >>= 1) {
+    fx += __shfl_xor(fx, o, 64);
+    fy += __shfl_xor(fy, o, 64);
+    fz += __shfl_xor(fz, o, 64);
+  }
+  if (active && sub == 0 && forces) {
+    const int oi = order[a];
+    forces[3 * oi + 0] += fx;
+    forces[3 * oi + 1] += fy;
+    forces[3 * oi + 2] += fz;
+  }
+  if (ENERGY) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double s = wave_sum((double)en[t]);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energies[t], 0.5 * s);
+    }
+  }
+  if (paircount) {
+    const unsigned long long s = wave_sum((unsigned long long)cnt);
+    if (lane == 0 && s) atomicAdd(paircount, s);
+  }
+}
+
+__global__ void halve_count_kernel(unsigned long long *c) { *c >>= 1; }
+
+}  // namespace tmd
+
+// =============================================================================================
+// host side: context
+// =============================================================================================
+using namespace tmd;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return 0;
+    if (p) TMD_HIP(hipFree(p));
+    p = nullptr;
+    bytes = 0;
+    TMD_HIP(hipMalloc(&p, need));
+    bytes = need;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T *as() const {
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+struct Replica {
+  int64_t step = 0;
+  int64_t n_compute = 0;
+  bool have_list = false;
+  double box[3] = {-1, -1, -1};
+  Grid grid{};
+  int ncell = 0;
+  ListGeom lg{1, 64, 0};
+  int64_t host_rebuilds = 0;
+  DevBuf cell_of, slot, order_tmp, order, count, cell_start, sorted, stype, ref, nlist, nneigh;
+  DevBuf flags;  // int[4]: flags[0..1] rebuild parity, [2] overflow, [3] rebuild counter
+  DevBuf paircount;  // unsigned long long
+  void release() {
+    for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &count, &cell_start, &sorted, &stype, &ref,
+                      &nlist, &nneigh, &flags, &paircount})
+      b->release();
+  }
+};
+
+}  // namespace
+
+struct tmdhip_ctx {
+  tmdhip_nonbonded_desc d{};
+  int real_size = 4;
+  int algorithm = TMDHIP_ALGO_ALLPAIRS;
+  double skin = 1.0;
+  double rlist = 0;
+  DevBuf types, qs, tab, excl_off, excl_idx;
+  int max_excl = 0;
+  std::vector<Replica> rep;
+  // bonded part lives in bonded.hip
+  void *bonded = nullptr;
+  // timing of the dominant kernel
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  double timing_ms = 0;
+  int64_t timing_launches = 0;
+};
+
+namespace tmd {
+void bonded_release(tmdhip_ctx *ctx);  // bonded.hip
+void *&ctx_bonded_slot(tmdhip_ctx *ctx) { return ctx->bonded; }
+const tmdhip_nonbonded_desc &ctx_desc(const tmdhip_ctx *ctx) { return ctx->d; }
+const void *ctx_scaled_charges(const tmdhip_ctx *ctx) { return ctx->qs.p; }
+int ctx_nreplicas(const tmdhip_ctx *ctx) { return (int)ctx->rep.size(); }
+}  // namespace tmd
+
+namespace {
+
+template <typename R>
+R cutoff_r2max(double cutoff) {
+  if (!(cutoff > 0)) return std::numeric_limits<R>::infinity();
+  const R c = (R)cutoff;  // the reference compares against the cutoff cast to the tensor dtype
+  R r2 = c * c;
+  const R inf = std::numeric_limits<R>::infinity();
+  while (std::sqrt(r2) <= c) r2 = std::nextafter(r2, inf);
+  while (std::sqrt(r2) > c) r2 = std::nextafter(r2, (R)0);
+  return r2;
+}
+
+template <typename R>
+PairConsts<R> make_consts(const tmdhip_ctx *ctx, const double *box) {
+  const auto &d = ctx->d;
+  PairConsts<R> c;
+  for (int k = 0; k < 3; ++k) {
+    c.box[k] = (R)box[k];
+    c.invbox[k] = c.box[k] != R(0) ? R(1) / c.box[k] : R(0);
+  }
+  const bool allzero = box[0] == 0 && box[1] == 0 && box[2] == 0;
+  if (allzero)
+    for (int k = 0; k < 3; ++k) c.invbox[k] = 0;
+  c.r2max = cutoff_r2max<R>(d.cutoff);
+  c.terms = d.terms;
+  c.switch_on = (d.switch_dist > 0 && d.cutoff > 0) ? 1 : 0;
+  c.switch_dist = (R)d.switch_dist;
+  c.inv_switch_range = c.switch_on ? (R)(1.0 / (d.cutoff - d.switch_dist)) : R(0);
+  c.switch_reference_mode = d.switch_mode == TMDHIP_SWITCH_REFERENCE;
+  c.rfa = d.rfa ? 1 : 0;
+  if (d.rfa) {
+    const double eps = d.solvent_dielectric, den = 2 * eps + 1;
+    c.krf = (R)((1.0 / (d.cutoff * d.cutoff * d.cutoff)) * (eps - 1) / den);
+    c.crf = (R)((1.0 / d.cutoff) * (3 * eps) / den);
+  } else {
+    c.krf = c.crf = 0;
+  }
+  return c;
+}
+
+int pick_lpa(int n) {
+  // aim for >= 8192 waves (32 per CU) so list/gather latency is hidden
+  int lpa = 1;
+  while (lpa < 64 && (int64_t)n * lpa < 8192ll * 64) lpa <<= 1;
+  return lpa;
+}
+
+// choose grid for the current box; returns false if the cell path cannot be used
+bool plan_grid(const tmdhip_ctx *ctx, const double *box, const double *lo, const double *hi, Grid &g) {
+  const bool periodic = !(box[0] == 0 && box[1] == 0 && box[2] == 0);
+  g.periodic = periodic ? 1 : 0;
+  double len[3];
+  for (int k = 0; k < 3; ++k) {
+    if (periodic) {
+      if (!(box[k] > 0)) return false;
+      len[k] = box[k];
+      g.origin[k] = 0;
+    } else {
+      len[k] = std::max(hi[k] - lo[k], 1e-3);
+      g.origin[k] = lo[k];
+    }
+  }
+  // try stencil half-width 2 (cell edge >= rlist/2), else 1 (cell edge >= rlist)
+  for (int m = 2; m >= 1; --m) {
+    bool ok = true;
+    int nc[3];
+    for (int k = 0; k < 3; ++k) {
+      nc[k] = (int)std::floor(len[k] / (ctx->rlist / m));
+      if (nc[k] < 1) nc[k] = 1;
+      if (periodic && nc[k] < 2 * m + 1) ok = false;
+      if (nc[k] > 1024) nc[k] = 1024;
+    }
+    if (!ok) continue;
+    g.m = m;
+    for (int k = 0; k < 3; ++k) {
+      g.nc[k] = nc[k];
+      g.inv_edge[k] = nc[k] / len[k];
+    }
+    return true;
+  }
+  return false;
+}
+
+template <typename R>
+int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *forces, double *energies,
+                    int flags, unsigned long long *paircount, hipStream_t st) {
+  const int n = ctx->d.natoms;
+  const PairConsts<R> c = make_consts<R>(ctx, box);
+  const int nb = (n + 63) / 64;
+  int nsplit = std::max(1, std::min(nb, 2048 / std::max(nb, 1)));
+  int jchunk = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
+  nsplit = (n + jchunk - 1) / jchunk;
+  dim3 grid(nb, nsplit);
+  R *f = (flags & TMDHIP_WANT_FORCES) ? (R *)forces : nullptr;
+  using R2 = typename Vec<R>::T2;
+  if (flags & TMDHIP_WANT_ENERGY)
+    hipLaunchKernelGGL((allpairs_kernel<R, true>), grid, dim3(64), 0, st, n, (const R *)pos,
+                       ctx->qs.as<R>(), ctx->types.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),
+                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, energies, paircount);
+  else
+    hipLaunchKernelGGL((allpairs_kernel<R, false>), grid, dim3(64), 0, st, n, (const R *)pos,
+                       ctx->qs.as<R>(), ctx->types.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),
+                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, energies, paircount);
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename R, bool ENERGY>
+int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, double *energies,
+                     unsigned long long *paircount, hipStream_t st) {
+  using R4 = typename Vec<R>::T4;
+  using R2 = typename Vec<R>::T2;
+  const int n = ctx->d.natoms;
+  const int apw = rp.lg.apw;
+  const int waves = (n + apw - 1) / apw;
+  const int blocks = (waves + 3) / 4;
+  const size_t shmem = (size_t)ctx->d.ntypes * ctx->d.ntypes * sizeof(R2);
+#define TMD_LAUNCH_LPA(L)                                                                              \
+  hipLaunchKernelGGL((list_pair_kernel<R, ENERGY, L>), dim3(blocks), dim3(256), shmem, st, n,         \
+                     rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,        \
+                     ctx->tab.as<R2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, \
+                     energies, paircount)
+  switch (rp.lg.lpa) {
+    case 1: TMD_LAUNCH_LPA(1); break;
+    case 2: TMD_LAUNCH_LPA(2); break;
+    case 4: TMD_LAUNCH_LPA(4); break;
+    case 8: TMD_LAUNCH_LPA(8); break;
+    case 16: TMD_LAUNCH_LPA(16); break;
+    case 32: TMD_LAUNCH_LPA(32); break;
+    default: TMD_LAUNCH_LPA(64); break;
+  }
+#undef TMD_LAUNCH_LPA
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename R>
+int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
+  using R4 = typename Vec<R>::T4;
+  const int n = ctx->d.natoms;
+  TMD_TRY(rp.cell_of.ensure(sizeof(int) * n));
+  TMD_TRY(rp.slot.ensure(sizeof(int) * n));
+  TMD_TRY(rp.order_tmp.ensure(sizeof(int) * n));
+  TMD_TRY(rp.order.ensure(sizeof(int) * n));
+  TMD_TRY(rp.sorted.ensure(sizeof(R4) * n));
+  TMD_TRY(rp.stype.ensure(sizeof(int) * n));
+  TMD_TRY(rp.ref.ensure(sizeof(R) * 3 * n));
+  TMD_TRY(rp.nneigh.ensure(sizeof(int) * n));
+  rp.lg.lpa = pick_lpa(n);
+  rp.lg.apw = 64 / rp.lg.lpa;
+  maxn = (maxn + rp.lg.lpa - 1) / rp.lg.lpa * rp.lg.lpa;
+  rp.lg.maxn = maxn;
+  const size_t groups = (n + rp.lg.apw - 1) / rp.lg.apw;
+  TMD_TRY(rp.nlist.ensure(sizeof(unsigned) * groups * maxn * rp.lg.apw));
+  return 0;
+}
+
+// Enqueue: displacement check -> conditional rebuild chain -> gather.  `force` forces a rebuild.
+template <typename R>
+int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force,
+                        hipStream_t st) {
+  using R4 = typename Vec<R>::T4;
+  const int n = ctx->d.natoms;
+  const int parity = (int)(rp.step & 1);
+  int *flags = rp.flags.as<int>();
+  const int *flag = flags + parity;
+  const int nb = (n + 255) / 256;
+  const R half_skin = (R)(0.5 * ctx->skin);
+  hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.ref.as<R>(), c,
+                     half_skin * half_skin, flags, parity, force);
+  hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, rp.cell_of.as<int>(),
+                     rp.slot.as<int>(), rp.count.as<int>(), flag);
+  hipLaunchKernelGGL(scan_cells_kernel, dim3(1), dim3(1024), 0, st, rp.ncell, rp.count.as<int>(),
+                     rp.cell_start.as<int>(), flag);
+  hipLaunchKernelGGL(fill_cells_kernel, dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(), rp.slot.as<int>(),
+                     rp.cell_start.as<int>(), rp.order_tmp.as<int>(), flag);
+  hipLaunchKernelGGL(sort_in_cell_kernel, dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(),
+                     rp.cell_start.as<int>(), rp.order_tmp.as<int>(), rp.order.as<int>(), flag);
+  hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, ctx->qs.as<R>(),
+                     ctx->types.as<int>(), rp.order.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(),
+                     rp.ref.as<R>(), flag);
+  const R rl = (R)ctx->rlist;
+  hipLaunchKernelGGL((build_list_kernel<R>), dim3(nb), dim3(256), 0, st, n, rp.sorted.as<R4>(),
+                     rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
+                     ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
+                     rp.nneigh.as<int>(), flags + 2, flag);
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename R>
+int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces,
+                 double *energies, int flags, hipStream_t st) {
+  const int n = ctx->d.natoms;
+  const R *pos = (const R *)pos_v;
+  const PairConsts<R> c = make_consts<R>(ctx, box);
+  const bool box_changed = box[0] != rp.box[0] || box[1] != rp.box[1] || box[2] != rp.box[2];
+  int force = 0;
+  if (!rp.have_list || box_changed) {
+    // (re)plan the grid — host-synchronising path, taken on the first call and when the box changes
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    const bool periodic = !(box[0] == 0 && box[1] == 0 && box[2] == 0);
+    double volume;
+    if (!periodic) {
+      std::vector<R> h(3 * (size_t)n);
+      TMD_HIP(hipMemcpyAsync(h.data(), pos, sizeof(R) * 3 * n, hipMemcpyDeviceToHost, st));
+      TMD_HIP(hipStreamSynchronize(st));
+      for (int k = 0; k < 3; ++k) lo[k] = 1e300, hi[k] = -1e300;
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+          lo[k] = std::min(lo[k], (double)h[3 * i + k]);
+          hi[k] = std::max(hi[k], (double)h[3 * i + k]);
+        }
+      for (int k = 0; k < 3; ++k) lo[k] -= 1e-3, hi[k] += 1e-3;
+      volume = std::max(hi[0] - lo[0], ctx->rlist) * std::max(hi[1] - lo[1], ctx->rlist) *
+               std::max(hi[2] - lo[2], ctx->rlist);
+    } else {
+      volume = box[0] * box[1] * box[2];
+    }
+    if (!plan_grid(ctx, box, lo, hi, rp.grid))
+      return fail("cell list cannot be used for this box (fewer than 3 cells of cutoff+skin per edge); use "
+                  "TMDHIP_ALGO_ALLPAIRS");
+    rp.ncell = rp.grid.nc[0] * rp.grid.nc[1] * rp.grid.nc[2];
+    TMD_TRY(rp.count.ensure(sizeof(int) * (size_t)rp.ncell));
+    TMD_TRY(rp.cell_start.ensure(sizeof(int) * ((size_t)rp.ncell + 1)));
+    TMD_HIP(hipMemsetAsync(rp.count.p, 0, sizeof(int) * (size_t)rp.ncell, st));
+    if (!rp.have_list) {
+      const double dens = n / volume;
+      int est = (int)(dens * 4.18879 * ctx->rlist * ctx->rlist * ctx->rlist * 1.3) + 32;
+      est = std::min(est, std::max(n - 1, 1));
+      TMD_TRY(alloc_replica<R>(ctx, rp, est));
+    }
+    for (int k = 0; k < 3; ++k) rp.box[k] = box[k];
+    force = 1;
+  }
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st));
+    rp.step++;
+    if (!force) break;
+    // forced builds are host-visible: size the list from the observed maximum so that later
+    // device-side rebuilds have headroom (density fluctuations) without host involvement
+    int h[4];
+    TMD_HIP(hipMemcpyAsync(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    TMD_HIP(hipStreamSynchronize(st));
+    rp.host_rebuilds++;
+    const int want = (int)(h[2] * 1.2) + 8;
+    if (h[2] <= rp.lg.maxn && (rp.have_list || want <= rp.lg.maxn)) {
+      rp.have_list = true;
+      break;
+    }
+    rp.have_list = true;
+    TMD_TRY(alloc_replica<R>(ctx, rp, std::max(want, rp.lg.maxn)));
+  }
+  R *f = (flags & TMDHIP_WANT_FORCES) ? (R *)forces : nullptr;
+  unsigned long long *pc = nullptr;
+  if (flags & TMDHIP_COUNT_PAIRS) {
+    pc = rp.paircount.as<unsigned long long>();
+    TMD_HIP(hipMemsetAsync(pc, 0, sizeof(unsigned long long), st));
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->timing) {
+    if (ctx->events_used >= 4096) TMD_TRY(tmdhip_timing_read(ctx, nullptr, nullptr, 0));
+    if (ctx->events_used == ctx->events.size()) {
+      hipEvent_t a, b;
+      TMD_HIP(hipEventCreate(&a));
+      TMD_HIP(hipEventCreate(&b));
+      ctx->events.emplace_back(a, b);
+    }
+    e0 = ctx->events[ctx->events_used].first;
+    e1 = ctx->events[ctx->events_used].second;
+    ctx->events_used++;
+    TMD_HIP(hipEventRecord(e0, st));
+  }
+  if (flags & TMDHIP_WANT_ENERGY)
+    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, energies, pc, st)));
+  else
+    TMD_TRY((launch_list_pair<R, false>(ctx, rp, c, f, energies, pc, st)));
+  if (ctx->timing) TMD_HIP(hipEventRecord(e1, st));
+  if (pc) hipLaunchKernelGGL(halve_count_kernel, dim3(1), dim3(1), 0, st, pc);
+  return 0;
+}
+
+template <typename R>
+int upload_params(tmdhip_ctx *ctx) {
+  using R2 = typename Vec<R>::T2;
+  const auto &d = ctx->d;
+  const int n = d.natoms, T = d.ntypes;
+  std::vector<R> qs(n);
+  const double s = std::sqrt(kElecFactor);
+  const R *q = (const R *)d.charges_host;
+  for (int i = 0; i < n; ++i) qs[i] = q ? (R)((double)q[i] * s) : R(0);
+  TMD_TRY(ctx->qs.ensure(sizeof(R) * std::max(n, 1)));
+  TMD_HIP(hipMemcpy(ctx->qs.p, qs.data(), sizeof(R) * n, hipMemcpyHostToDevice));
+  std::vector<R2> tab((size_t)T * T);
+  const R *A = (const R *)d.lj_A_host, *B = (const R *)d.lj_B_host;
+  for (size_t k = 0; k < tab.size(); ++k) {
+    tab[k].x = A ? A[k] : R(0);
+    tab[k].y = B ? B[k] : R(0);
+  }
+  TMD_TRY(ctx->tab.ensure(sizeof(R2) * tab.size()));
+  TMD_HIP(hipMemcpy(ctx->tab.p, tab.data(), sizeof(R2) * tab.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int tmdhip_abi_version(void) { return TMDHIP_ABI_VERSION; }
+const char *tmdhip_last_error(void) { return tmd::last_error().c_str(); }
+
+int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
+  if (!out || !desc) return fail("tmdhip_create: null argument");
+  if (desc->struct_size != (int32_t)sizeof(tmdhip_nonbonded_desc))
+    return fail("tmdhip_create: tmdhip_nonbonded_desc size mismatch (ABI)");
+  if (desc->natoms <= 0 || desc->ntypes <= 0 || desc->nreplicas <= 0)
+    return fail("tmdhip_create: natoms, ntypes and nreplicas must be positive");
+  if (desc->dtype != TMDHIP_F32 && desc->dtype != TMDHIP_F64) return fail("tmdhip_create: bad dtype");
+  if (!desc->types_host || !desc->excl_offsets_host) return fail("tmdhip_create: types/exclusions missing");
+  if ((desc->terms & TMDHIP_TERM_ELECTROSTATICS) && !desc->charges_host)
+    return fail("tmdhip_create: electrostatics requested without charges");
+  if ((desc->terms & (TMDHIP_TERM_LJ | TMDHIP_TERM_REPULSION)) && !desc->lj_A_host)
+    return fail("tmdhip_create: LJ/repulsion requested without the A table");
+  if ((desc->terms & (TMDHIP_TERM_LJ | TMDHIP_TERM_REPULSIONCG)) && !desc->lj_B_host)
+    return fail("tmdhip_create: LJ/repulsioncg requested without the B table");
+  if (desc->rfa && !(desc->cutoff > 0)) return fail("tmdhip_create: reaction field needs a cutoff");
+  for (int i = 0; i < desc->natoms; ++i)
+    if (desc->types_host[i] < 0 || desc->types_host[i] >= desc->ntypes)
+      return fail("tmdhip_create: atom type index out of range");
+  int ndev = 0;
+  TMD_HIP(hipGetDeviceCount(&ndev));
+  if (desc->device < 0 || desc->device >= ndev) return fail("tmdhip_create: no such HIP device");
+  TMD_HIP(hipSetDevice(desc->device));
+
+  tmdhip_ctx *ctx = new tmdhip_ctx();
+  ctx->d = *desc;
+  ctx->real_size = desc->dtype == TMDHIP_F32 ? 4 : 8;
+  ctx->skin = desc->skin > 0 ? desc->skin : 1.0;
+  ctx->rlist = desc->cutoff > 0 ? desc->cutoff + ctx->skin : 0;
+  const int n = desc->natoms;
+  auto cleanup = [&](int rc) {
+    tmdhip_destroy(ctx);
+    return rc;
+  };
+  if (ctx->types.ensure(sizeof(int) * n)) return cleanup(-1);
+  if (hipMemcpy(ctx->types.p, desc->types_host, sizeof(int) * n, hipMemcpyHostToDevice) != hipSuccess)
+    return cleanup(fail("tmdhip_create: copy of types failed"));
+  const int nex = desc->excl_offsets_host[n];
+  if (nex > 0 && !desc->excl_index_host) return cleanup(fail("tmdhip_create: exclusion indices missing"));
+  for (int i = 0; i < n; ++i) {
+    const int b = desc->excl_offsets_host[i], e = desc->excl_offsets_host[i + 1];
+    if (e < b) return cleanup(fail("tmdhip_create: exclusion offsets not monotonic"));
+    ctx->max_excl = std::max(ctx->max_excl, e - b);
+    for (int k = b; k < e; ++k) {
+      if (desc->excl_index_host[k] < 0 || desc->excl_index_host[k] >= n)
+        return cleanup(fail("tmdhip_create: exclusion index out of range"));
+      if (k > b && desc->excl_index_host[k] <= desc->excl_index_host[k - 1])
+        return cleanup(fail("tmdhip_create: exclusion rows must be sorted and unique"));
+    }
+  }
+  if (ctx->excl_off.ensure(sizeof(int) * (n + 1))) return cleanup(-1);
+  if (ctx->excl_idx.ensure(sizeof(int) * std::max(nex, 1))) return cleanup(-1);
+  (void)hipMemcpy(ctx->excl_off.p, desc->excl_offsets_host, sizeof(int) * (n + 1), hipMemcpyHostToDevice);
+  if (nex) (void)hipMemcpy(ctx->excl_idx.p, desc->excl_index_host, sizeof(int) * nex, hipMemcpyHostToDevice);
+  int rc = desc->dtype == TMDHIP_F32 ? upload_params<float>(ctx) : upload_params<double>(ctx);
+  if (rc) return cleanup(rc);
+
+  // algorithm choice: the list path needs a cutoff; without one every pair interacts anyway
+  int algo = desc->algorithm;
+  if (algo == TMDHIP_ALGO_AUTO) algo = (desc->cutoff > 0 && n >= 2048) ? TMDHIP_ALGO_CELLLIST : TMDHIP_ALGO_ALLPAIRS;
+  if (algo == TMDHIP_ALGO_CELLLIST) {
+    if (!(desc->cutoff > 0)) return cleanup(fail("tmdhip_create: the cell-list path needs a cutoff"));
+    if (n >= (1 << 24)) return cleanup(fail("tmdhip_create: cell-list path supports < 2^24 atoms per context"));
+    if (desc->ntypes > 256) return cleanup(fail("tmdhip_create: cell-list path supports <= 256 atom types"));
+    const size_t tabbytes = (size_t)desc->ntypes * desc->ntypes * 2 * ctx->real_size;
+    if (tabbytes > 64 * 1024) return cleanup(fail("tmdhip_create: LJ table does not fit in LDS (too many atom types)"));
+  }
+  ctx->algorithm = algo;
+  ctx->rep.resize(desc->nreplicas);
+  for (auto &rp : ctx->rep) {
+    if (rp.flags.ensure(sizeof(int) * 4)) return cleanup(-1);
+    (void)hipMemset(rp.flags.p, 0, sizeof(int) * 4);
+    if (rp.paircount.ensure(sizeof(unsigned long long))) return cleanup(-1);
+    (void)hipMemset(rp.paircount.p, 0, sizeof(unsigned long long));
+  }
+  // host arrays are not referenced after create
+  ctx->d.types_host = nullptr;
+  ctx->d.charges_host = ctx->d.lj_A_host = ctx->d.lj_B_host = nullptr;
+  ctx->d.excl_offsets_host = ctx->d.excl_index_host = nullptr;
+  *out = ctx;
+  return 0;
+}
+
+void tmdhip_destroy(tmdhip_ctx *ctx) {
+  if (!ctx) return;
+  for (auto &rp : ctx->rep) rp.release();
+  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx}) b->release();
+  for (auto &ev : ctx->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  tmd::bonded_release(ctx);
+  delete ctx;
+}
+
+int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, const double *box_host,
+                             void *forces_dev, double *energies_dev, int flags, void *stream) {
+  if (!ctx || !pos_dev || !box_host) return fail("tmdhip_compute_nonbonded: null argument");
+  if (replica < 0 || replica >= (int)ctx->rep.size()) return fail("tmdhip_compute_nonbonded: bad replica index");
+  if ((flags & TMDHIP_WANT_FORCES) && !forces_dev) return fail("tmdhip_compute_nonbonded: forces requested without a buffer");
+  if ((flags & TMDHIP_WANT_ENERGY) && !energies_dev) return fail("tmdhip_compute_nonbonded: energies requested without a buffer");
+  if (ctx->d.terms == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  Replica &rp = ctx->rep[replica];
+  rp.n_compute++;
+  const bool f32 = ctx->d.dtype == TMDHIP_F32;
+  if (ctx->algorithm == TMDHIP_ALGO_CELLLIST) {
+    return f32 ? compute_list<float>(ctx, rp, pos_dev, box_host, forces_dev, energies_dev, flags, st)
+               : compute_list<double>(ctx, rp, pos_dev, box_host, forces_dev, energies_dev, flags, st);
+  }
+  unsigned long long *pc = nullptr;
+  if (flags & TMDHIP_COUNT_PAIRS) {
+    pc = rp.paircount.as<unsigned long long>();
+    TMD_HIP(hipMemsetAsync(pc, 0, sizeof(unsigned long long), st));
+  }
+  return f32 ? launch_allpairs<float>(ctx, pos_dev, box_host, forces_dev, energies_dev, flags, pc, st)
+             : launch_allpairs<double>(ctx, pos_dev, box_host, forces_dev, energies_dev, flags, pc, st);
+}
+
+int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
+  if (!ctx || !out) return fail("tmdhip_get_stats: null argument");
+  if (replica < 0 || replica >= (int)ctx->rep.size()) return fail("tmdhip_get_stats: bad replica index");
+  Replica &rp = ctx->rep[replica];
+  std::memset(out, 0, sizeof(*out));
+  TMD_HIP(hipDeviceSynchronize());
+  int h[4] = {0, 0, 0, 0};
+  TMD_HIP(hipMemcpy(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost));
+  unsigned long long pc = 0;
+  TMD_HIP(hipMemcpy(&pc, rp.paircount.p, sizeof(pc), hipMemcpyDeviceToHost));
+  out->n_compute = rp.n_compute;
+  out->n_rebuilds = h[3];
+  out->pairs_in_cutoff = (int64_t)pc;
+  out->algorithm = ctx->algorithm;
+  out->max_neighbours = rp.lg.maxn;
+  out->overflow = (rp.have_list && h[2] > rp.lg.maxn) ? h[2] : 0;
+  for (int k = 0; k < 3; ++k) out->ncell[k] = rp.grid.nc[k];
+  if (rp.have_list) {
+    std::vector<int> nn(ctx->d.natoms);
+    TMD_HIP(hipMemcpy(nn.data(), rp.nneigh.p, sizeof(int) * nn.size(), hipMemcpyDeviceToHost));
+    int64_t s = 0;
+    for (int v : nn) s += v;
+    out->list_entries = s;
+  }
+  return 0;
+}
+
+int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream) {
+  if (!ctx) return fail("tmdhip_check: null ctx");
+  if (replica < 0 || replica >= (int)ctx->rep.size()) return fail("tmdhip_check: bad replica index");
+  Replica &rp = ctx->rep[replica];
+  if (ctx->algorithm != TMDHIP_ALGO_CELLLIST || !rp.have_list) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int h[4];
+  TMD_HIP(hipMemcpyAsync(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  TMD_HIP(hipStreamSynchronize(st));
+  if (h[2] <= rp.lg.maxn) return 0;
+  // a device-side rebuild truncated a list: grow the capacity and force a rebuild on the next call
+  const int want = (int)(h[2] * 1.25) + 16;
+  const int rc = ctx->d.dtype == TMDHIP_F32 ? alloc_replica<float>(ctx, rp, want) : alloc_replica<double>(ctx, rp, want);
+  if (rc) return rc;
+  rp.box[0] = -1;  // forces the re-plan + rebuild path
+  last_error() = "neighbour list overflowed (capacity grown, results since the last check are invalid)";
+  return 1;
+}
+
+int tmdhip_timing_enable(tmdhip_ctx *ctx, int on) {
+  if (!ctx) return fail("tmdhip_timing_enable: null ctx");
+  ctx->timing = on != 0;
+  return 0;
+}
+
+int tmdhip_timing_read(tmdhip_ctx *ctx, double *pair_kernel_ms, int64_t *launches, int reset) {
+  if (!ctx) return fail("tmdhip_timing_read: null ctx");
+  for (size_t k = 0; k < ctx->events_used; ++k) {
+    TMD_HIP(hipEventSynchronize(ctx->events[k].second));
+    float ms = 0;
+    TMD_HIP(hipEventElapsedTime(&ms, ctx->events[k].first, ctx->events[k].second));
+    ctx->timing_ms += ms;
+    ctx->timing_launches++;
+  }
+  ctx->events_used = 0;
+  if (pair_kernel_ms) *pair_kernel_ms = ctx->timing_ms;
+  if (launches) *launches = ctx->timing_launches;
+  if (reset) {
+    ctx->timing_ms = 0;
+    ctx->timing_launches = 0;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,489 @@
+"""`Forces` — host-side mirror of the reference force/energy engine, backed by HIP kernels.
+
+Same constructor, attributes, `compute()` signature, return types and error behaviour as the
+reference class (`torchmd/forces.py:7-346`), so `torchmd/run.py`, the minimizers and the
+`Integrator` can use it unchanged.  All arithmetic runs in `libtmdhip.so` (see include/tmdhip.h):
+
+* nonbonded block (forces.py:260-319)  -> tmdhip_compute_nonbonded  (tiled all-pairs kernel, or cell
+  list + Verlet list + list pair kernel instead of the reference's dense [P,2] pair tensor)
+* bonded block (forces.py:122-258)      -> tmdhip_compute_bonded
+* the `external` plugin hook (forces.py:321-326) is kept as is (a torch module on the device).
+
+There is no CPU path: tensors must live on a ROCm device, otherwise `compute()` raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _np_real(t, dtype):
+    return np.ascontiguousarray(t.detach().to("cpu", dtype).numpy())
+
+
+def build_exclusion_csr(natoms, pairs):
+    """Symmetric, per-row sorted, duplicate-free CSR of the excluded pairs returned by
+    `Parameters.get_exclusions` (reference parameters.py:89-107).  This replaces the N x N boolean
+    matrix of `_make_indeces` (forces.py:348-357)."""
+    pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    if len(pairs) == 0:
+        return np.zeros(natoms + 1, dtype=np.int32), np.zeros(0, dtype=np.int32)
+    if pairs.min() < 0 or pairs.max() >= natoms:
+        raise ValueError("exclusion index out of range")
+    both = np.concatenate([pairs, pairs[:, ::-1]], axis=0)
+    key = np.unique(both[:, 0] * np.int64(natoms) + both[:, 1])
+    rows = (key // natoms).astype(np.int64)
+    cols = (key % natoms).astype(np.int32)
+    offsets = np.zeros(natoms + 1, dtype=np.int64)
+    np.add.at(offsets, rows + 1, 1)
+    offsets = np.cumsum(offsets).astype(np.int32)
+    return offsets, cols
+
+
+class _Engine:
+    """One tmdhip context = (device, dtype, nreplicas) instance of a Forces object."""
+
+    def __init__(self, owner: "Forces", device: torch.device, dtype: torch.dtype, nreplicas: int, exact: bool):
+        lib = L.load()
+        self.lib = lib
+        self.ctx = C.c_void_p()
+        self.nreplicas = nreplicas
+        par = owner.par
+        n = owner.natoms
+        keep = []  # numpy arrays that must outlive the create call
+
+        def ptr(a):
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+
+        d = L.NonbondedDesc()
+        d.struct_size = C.sizeof(L.NonbondedDesc)
+        d.dtype = L.dtype_code(dtype)
+        d.natoms = n
+        d.nreplicas = nreplicas
+        d.device = device.index if device.index is not None else torch.cuda.current_device()
+        terms = 0
+        for t in owner.energies:
+            terms |= L.TERM_BIT.get(t, 0)
+        d.terms = terms
+        need_tab = terms & (L.TERM_LJ | L.TERM_REPULSION | L.TERM_REPULSIONCG)
+        if need_tab:
+            A, B = owner._lj_tables()
+            d.ntypes = int(A.shape[0])
+            d.types_host = ptr(np.ascontiguousarray(par.mapped_atom_types.detach().cpu().numpy().astype(np.int32)))
+            d.lj_A_host = ptr(_np_real(A, dtype))
+            d.lj_B_host = ptr(_np_real(B, dtype))
+        else:
+            d.ntypes = 1
+            d.types_host = ptr(np.zeros(n, dtype=np.int32))
+        d.charges_host = ptr(_np_real(par.charges, dtype))
+        off, idx = owner._excl_csr
+        d.excl_offsets_host = ptr(off)
+        d.excl_index_host = ptr(idx if len(idx) else np.zeros(1, dtype=np.int32))
+        d.rfa = 1 if owner.rfa else 0
+        d.cutoff = float(owner.cutoff) if owner.cutoff is not None else 0.0
+        d.switch_dist = float(owner.switch_dist) if owner.switch_dist is not None else 0.0
+        d.solvent_dielectric = float(owner.solventDielectric)
+        d.switch_mode = L.SWITCH_EXACT if exact else L.SWITCH_REFERENCE
+        d.algorithm = {"auto": L.ALGO_AUTO, "allpairs": L.ALGO_ALLPAIRS, "celllist": L.ALGO_CELLLIST}[owner.algorithm]
+        d.skin = float(owner.skin) if owner.skin else 0.0
+        L.check(lib.tmdhip_create(C.byref(self.ctx), C.byref(d)), "tmdhip_create")
+
+        b = L.BondedDesc()
+        b.struct_size = C.sizeof(L.BondedDesc)
+        have = False
+        en = owner.energies
+
+        def table(tab, width):
+            idx = np.ascontiguousarray(tab["idx"].detach().cpu().numpy().astype(np.int32)).reshape(-1, width)
+            mp = tab["map"].detach().cpu().numpy()
+            prm = _np_real(tab["params"], dtype)
+            return idx, mp, prm
+
+        if "bonds" in en and par.bond_params is not None:
+            idx, mp, prm = table(par.bond_params, 2)
+            b.nbonds = len(idx)
+            b.bond_idx_host = ptr(idx)
+            b.bond_prm_host = ptr(np.ascontiguousarray(prm[mp[:, 1]]))
+            b.bonds_use_cutoff = 1 if owner.cutoff is not None else 0
+            have = True
+        if "angles" in en and par.angle_params is not None:
+            idx, mp, prm = table(par.angle_params, 3)
+            b.nangles = len(idx)
+            b.angle_idx_host = ptr(idx)
+            b.angle_prm_host = ptr(np.ascontiguousarray(prm[mp[:, 1]]))
+            have = True
+        if "dihedrals" in en and par.dihedral_params is not None:
+            idx, mp, prm = table(par.dihedral_params, 4)
+            order = np.argsort(mp[:, 0], kind="stable")
+            b.ndihedrals = len(idx)
+            b.dihedral_idx_host = ptr(idx)
+            b.ndihedral_terms = len(mp)
+            b.dihedral_term_of_host = ptr(np.ascontiguousarray(mp[order, 0].astype(np.int32)))
+            b.dihedral_prm_host = ptr(np.ascontiguousarray(prm[mp[order, 1]]))
+            have = True
+        if "impropers" in en and par.improper_params is not None:
+            idx, mp, prm = table(par.improper_params, 4)
+            order = np.argsort(mp[:, 0], kind="stable")
+            b.nimpropers = len(idx)
+            b.improper_idx_host = ptr(idx)
+            b.nimproper_terms = len(mp)
+            b.improper_term_of_host = ptr(np.ascontiguousarray(mp[order, 0].astype(np.int32)))
+            b.improper_prm_host = ptr(np.ascontiguousarray(prm[mp[order, 1]]))
+            have = True
+        p14 = par.nonbonded_14_params
+        if "1-4" in en and p14 is not None and torch.is_tensor(p14.get("idx")) and len(p14["idx"]):
+            idx, mp, prm = table(p14, 2)
+            b.n14 = len(idx)
+            b.pair14_idx_host = ptr(idx)
+            b.pair14_prm_host = ptr(np.ascontiguousarray(prm[mp[:, 1]]))
+            t14 = 0
+            if "lj" in en:
+                t14 |= L.TERM_LJ
+            if "electrostatics" in en:
+                t14 |= L.TERM_ELECTROSTATICS
+            b.terms14 = t14
+            have = have or bool(t14)
+        self.has_bonded = have
+        if have:
+            L.check(lib.tmdhip_set_bonded(self.ctx, C.byref(b)), "tmdhip_set_bonded")
+        self.has_nonbonded = terms != 0
+        self.ebuf = torch.zeros(nreplicas, L.NENERGY, dtype=torch.float64, device=device)
+        del keep
+
+    def close(self):
+        if self.ctx:
+            self.lib.tmdhip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Forces:
+    """
+    Parameters (as the reference, torchmd/forces.py:27-37)
+    ----------
+    cutoff : float
+        Only calculate LJ, electrostatics and bond energies for atoms closer than this threshold.
+    rfa : bool
+        Reaction-field approximation for electrostatics up to the cutoff.
+    solventDielectric : float
+        Dielectric used by `rfa`.
+    switch_dist : float
+        Start of the LJ switching function.
+
+    Extra keyword-only knobs of this implementation
+    ----------
+    skin : float          Verlet-list skin in Angstrom (default 1.0)
+    algorithm : str       "auto" | "allpairs" | "celllist"
+    switch_mode : str     "reference" (upstream's explicit switching force, extra 1/r,
+                          forces.py:410-412) | "exact" (-dE/dr)
+    """
+
+    bonded = ["bonds", "angles", "dihedrals", "impropers", "1-4"]
+    nonbonded = ["electrostatics", "lj", "repulsion", "repulsioncg"]
+    terms = bonded + nonbonded
+
+    def __init__(
+        self,
+        parameters,
+        terms=None,
+        external=None,
+        cutoff=None,
+        rfa=False,
+        solventDielectric=78.5,
+        switch_dist=None,
+        exclusions=("bonds", "angles", "1-4"),
+        *,
+        skin=None,
+        algorithm="auto",
+        switch_mode="reference",
+    ):
+        self.par = parameters
+        if terms is None:
+            raise RuntimeError(
+                'Set force terms or leave empty brackets [].\nAvailable options: "bonds", "angles", "dihedrals", '
+                '"impropers", "1-4", "electrostatics", "lj", "repulsion", "repulsioncg".'
+            )
+        if self.par.nonbonded_params is not None and "lj" in terms:
+            self.par.A, self.par.B = self.par.get_AB()
+
+        self.energies = [ene.lower() for ene in terms]
+        for et in self.energies:
+            if et not in Forces.terms:
+                raise ValueError(f"Force term {et} is not implemented.")
+        if "1-4" in self.energies and "dihedrals" not in self.energies:
+            raise RuntimeError("You cannot enable 1-4 interactions without enabling dihedrals")
+        if algorithm not in ("auto", "allpairs", "celllist"):
+            raise ValueError("algorithm must be 'auto', 'allpairs' or 'celllist'")
+        if switch_mode not in ("reference", "exact"):
+            raise ValueError("switch_mode must be 'reference' or 'exact'")
+        if rfa and cutoff is None:
+            raise RuntimeError("rfa=True needs a cutoff")
+
+        self.natoms = len(parameters.masses)
+        self.require_distances = any(f in self.nonbonded for f in self.energies)
+        self.external = external
+        self.cutoff = cutoff
+        self.rfa = rfa
+        self.solventDielectric = solventDielectric
+        self.switch_dist = switch_dist
+        self.exclusions = tuple(exclusions)
+        self.skin = skin
+        self.algorithm = algorithm
+        self.switch_mode = switch_mode
+        self._excl_csr = build_exclusion_csr(
+            self.natoms, parameters.get_exclusions(exclusions) if self.require_distances else []
+        )
+        self._engines = {}
+        self._box_cache = None
+        self._ava_idx = None
+
+    # ------------------------------------------------------------------ reference attributes
+    @property
+    def ava_idx(self):
+        """Dense [P,2] list of non-excluded i<j pairs (reference `_make_indeces`, forces.py:348-357).
+        Only materialised on request — the kernels never use it — and only for small systems."""
+        if not self.require_distances:
+            return None
+        if self._ava_idx is None:
+            if self.natoms > 20000:
+                raise MemoryError("ava_idx is O(N^2); not available for natoms > 20000")
+            i, j = np.triu_indices(self.natoms, k=1)
+            off, idx = self._excl_csr
+            rows = np.repeat(np.arange(self.natoms), np.diff(off))
+            excl_keys = rows.astype(np.int64) * self.natoms + idx
+            keep = ~np.isin(i.astype(np.int64) * self.natoms + j, excl_keys)
+            self._ava_idx = torch.tensor(np.stack([i[keep], j[keep]], axis=1)).to(self.par.device)
+        return self._ava_idx
+
+    def _lj_tables(self):
+        A, B = getattr(self.par, "A", None), getattr(self.par, "B", None)
+        if A is None or B is None:
+            if self.par.nonbonded_params is None:
+                raise RuntimeError("LJ/repulsion terms requested but the parameters hold no nonbonded table")
+            A, B = self.par.get_AB()
+        return A, B
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine(self, pos, exact=None):
+        """`exact` selects the switching-force flavour: the explicit path keeps upstream's formula,
+        the autograd path (explicit_forces=False) is -dE/dr by construction (forces.py:328-336)."""
+        if exact is None:
+            exact = self.switch_mode == "exact"
+        exact = bool(exact) and self.switch_dist is not None
+        key = (pos.device.index, pos.dtype, pos.shape[0], exact)
+        eng = self._engines.get(key)
+        if eng is None:
+            with torch.cuda.device(pos.device):
+                eng = _Engine(self, pos.device, pos.dtype, pos.shape[0], exact)
+            self._engines[key] = eng
+        return eng
+
+    def _host_box(self, box):
+        """Box diagonals on the host, [R,3] float64.  Re-read only when the tensor changed (a read is a
+        device sync; the reference syncs on `torch.all(box == 0)` every call, forces.py:361)."""
+        tag = (box.data_ptr(), box._version, tuple(box.shape))
+        if self._box_cache is None or self._box_cache[0] != tag:
+            diag = torch.diagonal(box.detach(), dim1=-2, dim2=-1).to("cpu", torch.float64).contiguous().numpy()
+            self._box_cache = (tag, np.ascontiguousarray(diag.reshape(-1, 3)))
+        return self._box_cache[1]
+
+    def _launch(self, eng, pos, box, forces, want_energy, want_forces, count_pairs=False):
+        """Enqueue bonded + nonbonded kernels of every replica on the current stream."""
+        lib = eng.lib
+        hbox = self._host_box(box)
+        stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+        flags = (L.WANT_ENERGY if want_energy else 0) | (L.WANT_FORCES if want_forces else 0)
+        R, N = pos.shape[0], pos.shape[1]
+        esz = pos.element_size()
+        if want_energy:
+            eng.ebuf.zero_()
+        for r in range(R):
+            p = C.c_void_p(pos.data_ptr() + r * N * 3 * esz)
+            f = C.c_void_p(forces.data_ptr() + r * N * 3 * esz) if want_forces else C.c_void_p()
+            e = C.c_void_p(eng.ebuf.data_ptr() + r * L.NENERGY * 8)
+            bx = (C.c_double * 3)(*[float(v) for v in hbox[min(r, len(hbox) - 1)]])
+            if eng.has_bonded:
+                L.check(lib.tmdhip_compute_bonded(eng.ctx, r, p, bx, f, e, flags, stream), "tmdhip_compute_bonded")
+            if eng.has_nonbonded:
+                nbflags = flags | (L.COUNT_PAIRS if count_pairs else 0)
+                L.check(
+                    lib.tmdhip_compute_nonbonded(eng.ctx, r, p, bx, f, e, nbflags, stream),
+                    "tmdhip_compute_nonbonded",
+                )
+
+    def _verify(self, eng, pos):
+        """Host-visible validity check (neighbour-list capacity). True = results valid."""
+        stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+        ok = True
+        for r in range(pos.shape[0]):
+            rc = L.check(eng.lib.tmdhip_check(eng.ctx, r, stream), "tmdhip_check")
+            ok = ok and rc == 0
+        return ok
+
+    def _evaluate(self, pos, box, forces, want_energy, want_forces, count_pairs=False, exact=None):
+        """Zero + fill `forces`, return the per-term energy buffer [R, NENERGY] (float64, device)."""
+        L.require_device_tensor(pos, "pos")
+        L.require_device_tensor(box, "box")
+        if pos.dim() != 3 or pos.shape[2] != 3 or pos.shape[1] != self.natoms:
+            raise RuntimeError(f"pos must have shape (nreplicas, {self.natoms}, 3), got {tuple(pos.shape)}")
+        p = pos.detach()
+        if not p.is_contiguous():
+            p = p.contiguous()
+        target = None
+        if want_forces:
+            L.require_device_tensor(forces, "forces")
+            if forces.dtype != pos.dtype or forces.shape != pos.shape:
+                raise RuntimeError("forces must have the dtype and shape of pos")
+            if not forces.is_contiguous():
+                target, forces = forces, torch.empty_like(p)
+        eng = self._engine(p, exact)
+        with torch.cuda.device(p.device):
+            for _ in range(4):
+                if want_forces:
+                    forces.zero_()
+                self._launch(eng, p, box, forces, want_energy, want_forces, count_pairs)
+                if not (want_energy or count_pairs) or self._verify(eng, p):
+                    break
+            else:
+                raise RuntimeError("neighbour list kept overflowing; increase `skin` capacity")
+        if target is not None:
+            target.copy_(forces)
+        return eng.ebuf
+
+    # ------------------------------------------------------------------ public API
+    def compute(
+        self,
+        pos,
+        box,
+        forces,
+        returnDetails=False,
+        explicit_forces=True,
+        toNumpy=True,
+        calculateForces=True,
+    ):
+        if calculateForces:
+            if not explicit_forces and not pos.requires_grad:
+                raise RuntimeError(
+                    "The positions passed don't require gradients. Please use pos.detach().requires_grad_(True) "
+                    "before passing."
+                )
+        nsystems = pos.shape[0]
+        want_forces = calculateForces and forces is not None
+        if forces is not None and not want_forces:
+            forces.zero_()  # the reference zeroes `forces` whenever it is given (forces.py:113-114)
+        scratch = None
+        if calculateForces and not explicit_forces and pos.requires_grad and forces is None:
+            scratch = torch.zeros_like(pos.detach())
+        exact = True if (calculateForces and not explicit_forces) else None
+        ebuf = self._evaluate(
+            pos, box, forces if want_forces else scratch, True, want_forces or scratch is not None, exact=exact
+        )
+
+        ext_ene = None
+        if self.external:
+            ext_ene, ext_force = self.external.calculate(pos, box)
+            if want_forces and explicit_forces:
+                forces += ext_force
+            elif want_forces and not explicit_forces:
+                forces += ext_force.detach() if ext_force is not None else 0
+
+        # per-term energies in the order of the reference dict: self.energies ..., then "external"
+        names = list(self.energies) + ["external"]
+        cols = torch.zeros(nsystems, len(names), dtype=torch.float64, device=pos.device)
+        for k, name in enumerate(self.energies):
+            slot = L.ENERGY_SLOT.get(name)
+            if slot is not None:  # "1-4" has no slot: it accumulates into lj/electrostatics (forces.py:216,232)
+                cols[:, k] = ebuf[:, slot]
+        if ext_ene is not None:
+            cols[:, -1] = torch.as_tensor(ext_ene, device=pos.device).detach().to(torch.float64).reshape(nsystems)
+
+        if not returnDetails:
+            tot = cols.sum(dim=1)
+            if toNumpy:
+                return [float(v) for v in tot.cpu().tolist()]
+            tot = tot.to(pos.dtype)
+            if not explicit_forces and calculateForces and pos.requires_grad:
+                fsrc = forces if want_forces else scratch
+                tot = _PotentialWithGrad.apply(pos, tot, fsrc.detach().clone())
+            return tot
+        if toNumpy:
+            host = cols.cpu().tolist()
+            return [{n: float(v) for n, v in zip(names, row)} for row in host]
+        cols = cols.to(pos.dtype)
+        return [{n: cols[s, k : k + 1].clone() for k, n in enumerate(names)} for s in range(nsystems)]
+
+    # used by Integrator: no host synchronisation unless energies are requested
+    def _compute_async(self, pos, box, forces, want_energy):
+        ebuf = self._evaluate(pos, box, forces, want_energy, True)
+        if self.external:
+            ext_ene, ext_force = self.external.calculate(pos, box)
+            forces += ext_force
+            if want_energy:
+                return ebuf, torch.as_tensor(ext_ene, device=pos.device).detach().to(torch.float64).reshape(-1)
+        return (ebuf, None) if want_energy else (None, None)
+
+    def total_energy_from(self, ebuf, ext):
+        cols = [L.ENERGY_SLOT[n] for n in self.energies if n in L.ENERGY_SLOT]
+        tot = ebuf[:, cols].sum(dim=1) if cols else torch.zeros(ebuf.shape[0], dtype=torch.float64, device=ebuf.device)
+        if ext is not None:
+            tot = tot + ext
+        return tot
+
+    def count_pairs(self, pos, box):
+        """Number of non-excluded i<j pairs with r <= cutoff per replica (the P_cut of the
+        pair-interactions/s metric)."""
+        self._evaluate(pos, box, None, False, False, count_pairs=True)
+        return [self.stats(pos, r)["pairs_in_cutoff"] for r in range(pos.shape[0])]
+
+    def stats(self, pos, replica=0):
+        eng = self._engine(pos.detach())
+        st = L.Stats()
+        L.check(eng.lib.tmdhip_get_stats(eng.ctx, replica, C.byref(st)), "tmdhip_get_stats")
+        return {
+            "n_compute": st.n_compute,
+            "n_rebuilds": st.n_rebuilds,
+            "list_entries": st.list_entries,
+            "pairs_in_cutoff": st.pairs_in_cutoff,
+            "algorithm": {L.ALGO_ALLPAIRS: "allpairs", L.ALGO_CELLLIST: "celllist"}.get(st.algorithm, "?"),
+            "max_neighbours": st.max_neighbours,
+            "overflow": st.overflow,
+            "ncell": tuple(st.ncell),
+        }
+
+    def enable_timing(self, pos, on=True):
+        eng = self._engine(pos.detach())
+        L.check(eng.lib.tmdhip_timing_enable(eng.ctx, 1 if on else 0))
+
+    def read_timing(self, pos, reset=True):
+        """(total ms, launches) of the list pair kernel measured with HIP events on the launch stream."""
+        eng = self._engine(pos.detach())
+        ms, n = C.c_double(), C.c_int64()
+        L.check(eng.lib.tmdhip_timing_read(eng.ctx, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+
+class _PotentialWithGrad(torch.autograd.Function):
+    """Makes the returned potential differentiable w.r.t. `pos` for `explicit_forces=False` callers
+    (reference forces.py:328-336 derives forces with autograd; here dE/dpos = -F from the kernels)."""
+
+    @staticmethod
+    def forward(ctx, pos, energy, forces):
+        ctx.save_for_backward(forces)
+        return energy.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (forces,) = ctx.saved_tensors
+        return -forces * grad_out.reshape(-1, 1, 1).to(forces.dtype), None, None
