@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""Headline benchmark: ns/day (+ pair-interactions/s) of the 100k-atom TIP3P water box (config C3 of
+BASELINE.json / SURVEY.md §8) on N MI355X, one independent replica per GPU (config C4, weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one MD time step of the whole hot path: first velocity-Verlet half step, bonded +
+nonbonded forces (incl. the amortised cell/Verlet-list rebuilds), Langevin kick + second half step.
+State is resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+TERMS = ["lj", "electrostatics", "bonds", "angles"]
+CUTOFF = 9.0
+TIMESTEP_FS = 1.0
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def ns_per_day(steps, seconds, timestep_fs=TIMESTEP_FS):
+    return steps / seconds * timestep_fs * 1e-6 * 86400.0  # reference run.py:19,279 (FS2NS)
+
+
+def build_system(nside, device, dtype, seed):
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    mol, pos, box = tip3p_box(nside, seed=0)
+    par = Parameters(water_forcefield(mol), mol, TERMS, precision=dtype)
+    system = System(mol.numAtoms, 1, dtype, device)
+    system.set_positions(pos[:, :, None])
+    system.set_box(box)
+    torch.manual_seed(seed)
+    system.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
+    forces = Forces(par, terms=TERMS, cutoff=CUTOFF, rfa=True)
+    return mol, par, system, forces, box
+
+
+def cpu_baseline(par, system, box, budget_s=20.0):
+    """Reference arithmetic on the host cores: the oracle's md_step (same torch CPU ops as the reference,
+    sparse candidate pair list as in SURVEY.md §8(d)-(ii)) on the same relaxed box.  The candidate-list
+    build is excluded from the timing (favourable to the CPU)."""
+    from oracle import torchmd_oracle as orc
+
+    pos = system.pos.detach().cpu().clone()
+    vel = system.vel.detach().cpu().clone()
+    frc = system.forces.detach().cpu().clone()
+    cbox = system.box.detach().cpu().clone()
+    masses = par.masses.to(pos.dtype).view(-1, 1)
+    pairs = orc.candidate_pairs(pos[0].double().numpy(), box, CUTOFF + 0.6, orc.exclusion_pairs(par))
+    dt, gamma, vcoeff = orc.integrator_constants(TIMESTEP_FS, 0.1, 300.0, masses)
+    kw = dict(cutoff=CUTOFF, rfa=True, pairs=pairs)
+    orc.md_step(par, pos, vel, frc, cbox, masses, dt, TERMS, gamma, vcoeff, **kw)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.md_step(par, pos, vel, frc, cbox, masses, dt, TERMS, gamma, vcoeff, **kw)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {
+        "value": ns_per_day(n, el),
+        "unit": "ns/day",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "s_per_step": el / n,
+        "sample": f"{n} MD steps of the same {pos.shape[1]}-atom box (oracle/torchmd_oracle.py md_step, "
+        f"{len(pairs)} candidate pairs, list build excluded)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--nside", type=int, default=32, help="molecules per box edge (32 -> 98 304 atoms)")
+    ap.add_argument("--relax-steps", type=int, default=1500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from torchmd_amd.integrator import Integrator
+    from torchmd_amd.replicas import ReplicaFanout, env_rank_world
+
+    rank, world, local_rank = env_rank_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    fan = ReplicaFanout(total_replicas=world, device=device)
+
+    dtype = torch.float32
+    mol, par, system, forces, box = build_system(args.nside, device, dtype, seed=1 + rank)
+    fan.check_same_topology(mol.bonds, mol.angles, mol.charge)
+    natoms = mol.numAtoms
+
+    # prime forces, relax the lattice start with strong friction, then production
+    forces.compute(system.pos, system.box, system.forces)
+    if args.relax_steps:
+        Integrator(system, forces, TIMESTEP_FS, device, gamma=10.0, T=300.0).step(args.relax_steps)
+    integ = Integrator(system, forces, TIMESTEP_FS, device, gamma=0.1, T=300.0)
+    if args.warmup:
+        integ.step(args.warmup)
+
+    st0 = forces.stats(system.pos)
+    forces.enable_timing(system.pos, True)
+    forces.read_timing(system.pos, reset=True)
+    fan.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ekin, epot, temp = integ.step(args.steps)
+    torch.cuda.synchronize()
+    fan.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = fan.max_over_ranks(elapsed)
+    pair_ms, pair_launches = forces.read_timing(system.pos, reset=True)
+    forces.enable_timing(system.pos, False)
+    st1 = forces.stats(system.pos)
+    obs = fan.gather_observables(ekin, epot, temp)
+
+    pcut = forces.count_pairs(system.pos, system.box)[0]
+    st2 = forces.stats(system.pos)
+    steps_per_s = args.steps / elapsed
+    value = ns_per_day(args.steps, elapsed) * world
+    rebuilds = st1["n_rebuilds"] - st0["n_rebuilds"]
+
+    # roofline of the dominant kernel (list pair kernel): algorithmic bytes per launch =
+    # 4 B per unique in-cutoff pair (one int32 neighbour index) + 28 B per atom (16 B xyzq read, 12 B force write)
+    alg_bytes = 4.0 * pcut + 28.0 * natoms
+    pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
+    achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
+    step_bytes = 4.0 * pcut + 132.0 * natoms  # whole step incl. integrator
+
+    out = {
+        "metric": "ns/day (aggregate over replicas), 100k-atom TIP3P water box, 9 A cutoff + reaction field",
+        "value": value,
+        "unit": "ns/day",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C3/C4 synthetic TIP3P water box: {natoms} atoms, L={box[0]:.3f} A, cutoff 9 A, "
+            "reaction field, terms lj+electrostatics+bonds+angles (flexible water), Langevin 300 K "
+            "gamma 0.1/ps, timestep 1 fs; one independent replica per GPU",
+            "natoms": natoms,
+            "replicas": world,
+            "timestep_fs": TIMESTEP_FS,
+            "relax_steps": args.relax_steps,
+        },
+        "ns_per_day_per_replica": ns_per_day(args.steps, elapsed),
+        "pair_interactions_per_s": pcut * steps_per_s * world,
+        "pairs_in_cutoff": pcut,
+        "temperature_K": [float(x) for x in obs[:, 2]],
+        "epot_kcal_mol": [float(x) for x in obs[:, 1]],
+        "list": {
+            "algorithm": st2["algorithm"],
+            "rebuilds_in_timed_region": int(rebuilds),
+            "steps_per_rebuild": (args.steps / rebuilds) if rebuilds else None,
+            "entries": int(st2["list_entries"]),
+            "capacity_per_atom": int(st2["max_neighbours"]),
+            "ncell": list(st2["ncell"]),
+        },
+        "roofline": {
+            "kernel": "list_pair_kernel<float>",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_kernel_us": pair_avg_s * 1e6,
+            "launches_timed": int(pair_launches),
+            "step_frac_of_hbm_roofline": (step_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(par, system, box)
+        out["speedup_vs_cpu_baseline"] = out["ns_per_day_per_replica"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

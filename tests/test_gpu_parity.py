@@ -205,7 +205,9 @@ def test_water_box_celllist_vs_oracle(prec):
         _, Fm, _ = orc.compute(par, pm, box_tensor(box, 1, dt), ["lj", "electrostatics"],
                                pairs=orc.candidate_pairs(pm[0].double().numpy(), box, 9.6, orc.exclusion_pairs(par)),
                                **kw)
-        assert (F.cpu() - Fm).abs().max().item() < FTOL[prec] * 5
+        # random displacements create close contacts with huge forces: compare relative to |F|
+        rel = ((F.cpu() - Fm).abs() / (1.0 + Fm.abs())).max().item()
+        assert rel < (1e-4 if prec == "f32" else 1e-10), rel
         assert (f.stats(p)["n_rebuilds"] > rebuilds0) == expect_rebuild
         rebuilds0 = f.stats(p)["n_rebuilds"]
     # atoms translated by whole box vectors keep the list valid and the forces identical
@@ -213,7 +215,7 @@ def test_water_box_celllist_vs_oracle(prec):
     F2 = torch.zeros_like(F)
     f.compute((pm[0] + shift)[None].contiguous().to(dev), b, F2)
     # (fp32 positions lose ~1e-5 A when shifted by two box lengths, hence the looser fp32 bound)
-    assert (F2 - F).abs().max().item() < (5e-2 if prec == "f32" else 1e-8)
+    assert ((F2 - F).abs() / (1.0 + F.abs())).max().item() < (1e-2 if prec == "f32" else 1e-8)
     assert f.stats(p)["n_rebuilds"] == rebuilds0
 
 
