@@ -282,75 +282,174 @@ __device__ __forceinline__ size_t list_slot(const ListGeom &lg, int a, int k) {
 }
 
 // ---- K2: Verlet list build ---------------------------------------------------------------------
+// One wave per cell.  The candidates (all atoms of the (2m+1)^3 stencil cells, which are contiguous
+// runs of the cell-sorted arrays) are streamed through the 64 lanes with coalesced loads; for every
+// chunk of 64 candidates the wave loops over the atoms i of its cell (wave-uniform data), tests
+// |d|^2 <= rlist^2 and the exclusions, and appends the hits of atom i with a ballot / prefix-popcount
+// compaction.  Entry order per atom is fixed by the stencil order -> lists are bit-reproducible.
 template <typename R>
-__global__ __launch_bounds__(256) void build_list_kernel(
+__global__ __launch_bounds__(64) void build_list_kernel(
     int n, const typename Vec<R>::T4 *__restrict__ sorted, const int *__restrict__ stype,
     const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag) {
   if (*flag == 0) return;
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  int cnt = 0;
-  if (a < n) {
-    const typename Vec<R>::T4 pi = sorted[a];
-    const int oi = order[a];
-    const int eb = excl_off[oi], ee = excl_off[oi + 1];
-    const int cx = cell_coord(pi.x, g, 0), cy = cell_coord(pi.y, g, 1), cz = cell_coord(pi.z, g, 2);
-    for (int ox = -g.m; ox <= g.m; ++ox) {
-      int x = cx + ox;
-      if (g.periodic) x = (x + g.nc[0]) % g.nc[0];
-      else if (x < 0 || x >= g.nc[0]) continue;
-      for (int oy = -g.m; oy <= g.m; ++oy) {
-        int y = cy + oy;
-        if (g.periodic) y = (y + g.nc[1]) % g.nc[1];
-        else if (y < 0 || y >= g.nc[1]) continue;
-        for (int oz = -g.m; oz <= g.m; ++oz) {
-          int z = cz + oz;
-          if (g.periodic) z = (z + g.nc[2]) % g.nc[2];
-          else if (z < 0 || z >= g.nc[2]) continue;
-          const int cidx = (x * g.nc[1] + y) * g.nc[2] + z;
-          const int s = cell_start[cidx], e = cell_start[cidx + 1];
-          for (int j = s; j < e; ++j) {
-            if (j == a) continue;
-            const typename Vec<R>::T4 pj = sorted[j];
-            const R dx = min_image(pi.x - pj.x, c.box[0], c.invbox[0]);
-            const R dy = min_image(pi.y - pj.y, c.box[1], c.invbox[1]);
-            const R dz = min_image(pi.z - pj.z, c.box[2], c.invbox[2]);
-            const R r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 <= rlist2) {
-              const int oj = order[j];
-              bool ex = false;
-              for (int q = eb; q < ee; ++q) ex |= (excl_idx[q] == oj);
-              if (!ex) {
-                if (cnt < lg.maxn) nlist[list_slot(lg, a, cnt)] = (unsigned)j | ((unsigned)stype[j] << 24);
-                ++cnt;
-              }
-            }
-          }
-        }
+  using R4 = typename Vec<R>::T4;
+  __shared__ int seg_start[128];
+  __shared__ int seg_prefix[129];
+  const int lane = threadIdx.x;
+  const int cell = blockIdx.x;
+  const int cs = cell_start[cell], ce = cell_start[cell + 1];
+  if (cell == 0 && lane == 0) status[1] += 1;  // flags[3]: number of rebuilds
+  if (cs == ce) return;
+  const int cz = cell % g.nc[2], cy = (cell / g.nc[2]) % g.nc[1], cx = cell / (g.nc[2] * g.nc[1]);
+  const int w = 2 * g.m + 1, nst = w * w * w;  // <= 125
+  // stencil segments: lane handles stencil cells `lane` and `lane + 64`
+  int cnt2[2], st2[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int sidx = lane + 64 * h;
+    int count = 0, start = 0;
+    if (sidx < nst) {
+      int x = cx + sidx / (w * w) - g.m, y = cy + (sidx / w) % w - g.m, z = cz + sidx % w - g.m;
+      bool ok = true;
+      if (g.periodic) {
+        x = (x + g.nc[0]) % g.nc[0];
+        y = (y + g.nc[1]) % g.nc[1];
+        z = (z + g.nc[2]) % g.nc[2];
+      } else {
+        ok = x >= 0 && x < g.nc[0] && y >= 0 && y < g.nc[1] && z >= 0 && z < g.nc[2];
+      }
+      if (ok) {
+        const int cidx = (x * g.nc[1] + y) * g.nc[2] + z;
+        start = cell_start[cidx];
+        count = cell_start[cidx + 1] - start;
       }
     }
-    nneigh[a] = min(cnt, lg.maxn);
-    if (a == 0) status[1] += 1;  // flags[3]: number of rebuilds
+    cnt2[h] = count;
+    st2[h] = start;
+  }
+  // exclusive prefix over the 128 slots
+  int inc0 = cnt2[0], inc1 = cnt2[1];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t0 = __shfl_up(inc0, o, 64), t1 = __shfl_up(inc1, o, 64);
+    if (lane >= o) {
+      inc0 += t0;
+      inc1 += t1;
+    }
+  }
+  const int tot0 = __shfl(inc0, 63, 64);
+  const int ncand = tot0 + __shfl(inc1, 63, 64);
+  seg_start[lane] = st2[0];
+  seg_start[lane + 64] = st2[1];
+  seg_prefix[lane] = inc0 - cnt2[0];
+  seg_prefix[lane + 64] = tot0 + inc1 - cnt2[1];
+  if (lane == 0) seg_prefix[128] = ncand;
+  __syncthreads();
+
+  // per-atom data of the i block staged in LDS: the inner loop reads it with wave-uniform
+  // (broadcast) LDS loads instead of dependent global loads
+  constexpr int EXS = 4;  // exclusions per atom held in LDS; longer rows spill to global reads
+  __shared__ R4 s_pi[64];
+  __shared__ int s_oi[64], s_ne[64], s_eb[64], s_cnt[64];
+  __shared__ int s_ex[64][EXS];
+  int wmax = 0;
+  for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
+    const int iend = min(ib + 64, ce);
+    const int ni = iend - ib;
+    __syncthreads();
+    if (lane < ni) {
+      s_pi[lane] = sorted[ib + lane];
+      const int oi = order[ib + lane];
+      const int eb = excl_off[oi], ne = excl_off[oi + 1] - eb;
+      s_oi[lane] = oi;
+      s_eb[lane] = eb;
+      s_ne[lane] = ne;
+#pragma unroll
+      for (int e = 0; e < EXS; ++e) s_ex[lane][e] = e < ne ? excl_idx[eb + e] : -1;
+    }
+    s_cnt[lane] = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < ncand; q0 += 64) {
+      const int q = q0 + lane;
+      const bool valid = q < ncand;
+      int j = cs;
+      if (valid) {  // segment of candidate q: last s with seg_prefix[s] <= q
+        int lo = 0, hi = 127;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (seg_prefix[mid] <= q) lo = mid;
+          else hi = mid - 1;
+        }
+        j = seg_start[lo] + (q - seg_prefix[lo]);
+      }
+      const R4 pj = sorted[j];
+      const int oj = order[j];
+      const unsigned entry = (unsigned)j | ((unsigned)stype[j] << 24);
+#pragma unroll 2
+      for (int t = 0; t < ni; ++t) {
+        const R4 pi = s_pi[t];  // wave-uniform LDS broadcast
+        const R dx = min_image(pi.x - pj.x, c.box[0], c.invbox[0]);
+        const R dy = min_image(pi.y - pj.y, c.box[1], c.invbox[1]);
+        const R dz = min_image(pi.z - pj.z, c.box[2], c.invbox[2]);
+        const R r2 = dx * dx + dy * dy + dz * dz;
+        bool hit = valid && (r2 <= rlist2) && (j != ib + t);
+#pragma unroll
+        for (int e = 0; e < EXS; ++e) hit = hit && (s_ex[t][e] != oj);
+        const int ne = s_ne[t];
+        if (ne > EXS) {
+          const int eb = s_eb[t];
+          for (int e = EXS; e < ne; ++e) hit = hit && (excl_idx[eb + e] != oj);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        const int base = s_cnt[t];
+        if (hit) {
+          const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
+          if (k < lg.maxn) nlist[list_slot(lg, ib + t, k)] = entry;
+        }
+        if (lane == 0) s_cnt[t] = base + __popcll(mask);
+      }
+    }
+    __syncthreads();
+    const int mycnt = s_cnt[lane];
+    if (lane < ni) nneigh[ib + lane] = min(mycnt, lg.maxn);
+    wmax = max(wmax, lane < ni ? mycnt : 0);
   }
   // flags[2] = largest neighbour count ever seen; > maxn means a list was truncated (overflow)
-  int wmax = cnt;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
-  if ((threadIdx.x & 63) == 0 && wmax > 0) atomicMax(status, wmax);
+  if (lane == 0 && wmax > 0) atomicMax(status, wmax);
 }
 
 // ---- K3: list pair kernel ------------------------------------------------------------------------
 // LPA lanes cooperate on one atom (strided over its list), APW = 64/LPA atoms per wave.
-template <typename R, bool ENERGY, int LPA>
+// The neighbour stream is read with one coalesced 256-B load per wave and iteration; UNROLL
+// iterations are issued together so that their index loads and the dependent position gathers
+// overlap (memory-level parallelism), and the pair maths is predicated instead of branched.
+// FAST = 1 is the branch-free specialisation for LJ + reaction-field electrostatics without
+// switching (the water benchmark); FAST = 0 takes every option from PairConsts at run time.
+template <typename R>
+__device__ __forceinline__ R pair_fast_lj_rf(const PairConsts<R> &c, R r2, R qq, R A, R B) {
+  const R rinv = fast_rsqrt(r2);
+  const R rinv2 = rinv * rinv;
+  const R rinv6 = rinv2 * rinv2 * rinv2;
+  // (dE_lj/dr + dE_rf/dr) / r
+  return (R(-12) * A * rinv6 + R(6) * B) * rinv6 * rinv2 + qq * (R(2) * c.krf - rinv2 * rinv);
+}
+
+template <typename R, bool ENERGY, int LPA, int FAST>
 __global__ __launch_bounds__(256) void list_pair_kernel(
     int n, const typename Vec<R>::T4 *__restrict__ sorted, const int *__restrict__ stype,
     const int *__restrict__ order, int ntypes, const typename Vec<R>::T2 *__restrict__ tab,
     const unsigned *__restrict__ nlist, const int *__restrict__ nneigh, int maxn, PairConsts<R> c,
-    R *__restrict__ forces, double *__restrict__ energies, unsigned long long *__restrict__ paircount) {
+    R *__restrict__ forces, int overwrite, double *__restrict__ energies,
+    unsigned long long *__restrict__ paircount) {
   using R4 = typename Vec<R>::T4;
   using R2 = typename Vec<R>::T2;
   constexpr int APW = 64 / LPA;
+  constexpr int UNROLL = 4;
   extern __shared__ __align__(16) unsigned char smem[];
   R2 *stab = reinterpret_cast<R2 *>(smem);
   for (int t = threadIdx.x; t < ntypes * ntypes; t += blockDim.x) stab[t] = tab[t];
@@ -361,6 +460,7 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
   const int a = wave * APW + lane / LPA;
   const int sub = lane % LPA;
   const bool active = a < n;
+  const int aself = active ? a : 0;
   R4 pi;
   pi.x = pi.y = pi.z = pi.w = 0;
   int nn = 0, trow = 0;
@@ -372,28 +472,48 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
   int nmax = nn;
 #pragma unroll
   for (int o = 32; o >= LPA; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  const int nkk = (nmax + LPA - 1) / LPA;
   const unsigned *row = nlist + (size_t)wave * maxn * APW + lane;
 
   R fx = 0, fy = 0, fz = 0;
   R en[4] = {0, 0, 0, 0};
   unsigned cnt = 0;
-  for (int k = sub, kk = 0; kk * LPA < nmax; ++kk, k += LPA) {
-    const unsigned entry = row[(size_t)kk * 64];
-    const bool valid = k < nn;
-    const int j = valid ? (int)(entry & 0xFFFFFFu) : (active ? a : 0);
-    const int tj = valid ? (int)(entry >> 24) : 0;
-    const R4 pj = sorted[j];
-    const R dx = min_image(pi.x - pj.x, c.box[0], c.invbox[0]);
-    const R dy = min_image(pi.y - pj.y, c.box[1], c.invbox[1]);
-    const R dz = min_image(pi.z - pj.z, c.box[2], c.invbox[2]);
-    const R r2 = norm2(dx, dy, dz);
-    if (valid && r2 <= c.r2max) {
-      const R2 ab = stab[trow + tj];
-      const R fs = pair_terms<R, ENERGY>(c, r2, pi.w * pj.w, ab.x, ab.y, en);
+  for (int kk0 = 0; kk0 < nkk; kk0 += UNROLL) {
+    unsigned entry[UNROLL];
+    R4 pj[UNROLL];
+    bool valid[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) entry[u] = (kk0 + u < nkk) ? row[(size_t)(kk0 + u) * 64] : 0u;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      valid[u] = (kk0 + u) * LPA + sub < nn;
+      pj[u] = sorted[valid[u] ? (int)(entry[u] & 0xFFFFFFu) : aself];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const R dx = min_image(pi.x - pj[u].x, c.box[0], c.invbox[0]);
+      const R dy = min_image(pi.y - pj[u].y, c.box[1], c.invbox[1]);
+      const R dz = min_image(pi.z - pj[u].z, c.box[2], c.invbox[2]);
+      const R r2 = norm2(dx, dy, dz);
+      const bool hit = valid[u] && (r2 <= c.r2max);
+      const R2 ab = stab[trow + (valid[u] ? (int)(entry[u] >> 24) : 0)];
+      const R r2s = hit ? r2 : R(1);
+      R fs;
+      if (FAST == 1 && !ENERGY) {
+        fs = pair_fast_lj_rf<R>(c, r2s, pi.w * pj[u].w, ab.x, ab.y);
+      } else {
+        R e4[4] = {0, 0, 0, 0};
+        fs = pair_terms<R, ENERGY>(c, r2s, pi.w * pj[u].w, ab.x, ab.y, e4);
+        if (ENERGY) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) en[t] += hit ? e4[t] : R(0);
+        }
+      }
+      fs = hit ? fs : R(0);
       fx -= dx * fs;
       fy -= dy * fs;
       fz -= dz * fs;
-      ++cnt;
+      cnt += hit ? 1u : 0u;
     }
   }
 #pragma unroll
@@ -404,9 +524,15 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
   }
   if (active && sub == 0 && forces) {
     const int oi = order[a];
-    forces[3 * oi + 0] += fx;
-    forces[3 * oi + 1] += fy;
-    forces[3 * oi + 2] += fz;
+    if (overwrite) {
+      forces[3 * oi + 0] = fx;
+      forces[3 * oi + 1] = fy;
+      forces[3 * oi + 2] = fz;
+    } else {
+      forces[3 * oi + 0] += fx;
+      forces[3 * oi + 1] += fy;
+      forces[3 * oi + 2] += fz;
+    }
   }
   if (ENERGY) {
 #pragma unroll
@@ -612,7 +738,7 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
 }
 
 template <typename R, bool ENERGY>
-int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, double *energies,
+int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, int overwrite, double *energies,
                      unsigned long long *paircount, hipStream_t st) {
   using R4 = typename Vec<R>::T4;
   using R2 = typename Vec<R>::T2;
@@ -621,11 +747,18 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const int waves = (n + apw - 1) / apw;
   const int blocks = (waves + 3) / 4;
   const size_t shmem = (size_t)ctx->d.ntypes * ctx->d.ntypes * sizeof(R2);
-#define TMD_LAUNCH_LPA(L)                                                                              \
-  hipLaunchKernelGGL((list_pair_kernel<R, ENERGY, L>), dim3(blocks), dim3(256), shmem, st, n,         \
-                     rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,        \
-                     ctx->tab.as<R2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, \
-                     energies, paircount)
+  const bool fast = !ENERGY && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS) && c.rfa && !c.switch_on;
+#define TMD_LAUNCH(L, F)                                                                                \
+  hipLaunchKernelGGL((list_pair_kernel<R, ENERGY, L, F>), dim3(blocks), dim3(256), shmem, st, n,        \
+                     rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,          \
+                     ctx->tab.as<R2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
+                     overwrite, energies, paircount)
+#define TMD_LAUNCH_LPA(L)     \
+  if (fast) {                 \
+    TMD_LAUNCH(L, 1);         \
+  } else {                    \
+    TMD_LAUNCH(L, 0);         \
+  }
   switch (rp.lg.lpa) {
     case 1: TMD_LAUNCH_LPA(1); break;
     case 2: TMD_LAUNCH_LPA(2); break;
@@ -636,6 +769,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
     default: TMD_LAUNCH_LPA(64); break;
   }
 #undef TMD_LAUNCH_LPA
+#undef TMD_LAUNCH
   TMD_HIP(hipGetLastError());
   return 0;
 }
@@ -686,7 +820,7 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
                      ctx->types.as<int>(), rp.order.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(),
                      rp.ref.as<R>(), flag);
   const R rl = (R)ctx->rlist;
-  hipLaunchKernelGGL((build_list_kernel<R>), dim3(nb), dim3(256), 0, st, n, rp.sorted.as<R4>(),
+  hipLaunchKernelGGL((build_list_kernel<R>), dim3(rp.ncell), dim3(64), 0, st, n, rp.sorted.as<R4>(),
                      rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
                      ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
                      rp.nneigh.as<int>(), flags + 2, flag);
@@ -777,10 +911,11 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     ctx->events_used++;
     TMD_HIP(hipEventRecord(e0, st));
   }
+  const int overwrite = (flags & TMDHIP_OVERWRITE_FORCES) ? 1 : 0;
   if (flags & TMDHIP_WANT_ENERGY)
-    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, energies, pc, st)));
+    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, overwrite, energies, pc, st)));
   else
-    TMD_TRY((launch_list_pair<R, false>(ctx, rp, c, f, energies, pc, st)));
+    TMD_TRY((launch_list_pair<R, false>(ctx, rp, c, f, overwrite, energies, pc, st)));
   if (ctx->timing) TMD_HIP(hipEventRecord(e1, st));
   if (pc) hipLaunchKernelGGL(halve_count_kernel, dim3(1), dim3(1), 0, st, pc);
   return 0;

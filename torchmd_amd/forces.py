@@ -14,7 +14,10 @@ There is no CPU path: tensors must live on a ROCm device, otherwise `compute()` 
 
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import sys
+import weakref
 
 import numpy as np
 import torch
@@ -44,6 +47,16 @@ def build_exclusion_csr(natoms, pairs):
     np.add.at(offsets, rows + 1, 1)
     offsets = np.cumsum(offsets).astype(np.int32)
     return offsets, cols
+
+
+_LIVE_ENGINES = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all_engines():
+    # release device contexts while the HIP runtime (and any attached profiler) is still fully alive
+    for eng in list(_LIVE_ENGINES):
+        eng.close()
 
 
 class _Engine:
@@ -154,7 +167,13 @@ class _Engine:
         if have:
             L.check(lib.tmdhip_set_bonded(self.ctx, C.byref(b)), "tmdhip_set_bonded")
         self.has_nonbonded = terms != 0
+        st = L.Stats()
+        L.check(lib.tmdhip_get_stats(self.ctx, 0, C.byref(st)), "tmdhip_get_stats")
+        # the cell-list pair kernel owns every atom exactly once and can *store* its force, which saves
+        # the zero-fill pass; the all-pairs kernel combines j-range partials with atomics and cannot
+        self.stores_forces = self.has_nonbonded and st.algorithm == L.ALGO_CELLLIST
         self.ebuf = torch.zeros(nreplicas, L.NENERGY, dtype=torch.float64, device=device)
+        _LIVE_ENGINES.add(self)
         del keep
 
     def close(self):
@@ -163,6 +182,8 @@ class _Engine:
             self.ctx = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():
+            return  # never call into the HIP runtime during interpreter teardown
         try:
             self.close()
         except Exception:
@@ -249,6 +270,12 @@ class Forces:
         self._box_cache = None
         self._ava_idx = None
 
+    def close(self):
+        """Release the device contexts (they are re-created on the next compute())."""
+        for eng in self._engines.values():
+            eng.close()
+        self._engines = {}
+
     # ------------------------------------------------------------------ reference attributes
     @property
     def ava_idx(self):
@@ -309,19 +336,24 @@ class Forces:
         esz = pos.element_size()
         if want_energy:
             eng.ebuf.zero_()
+        if want_forces and not eng.stores_forces:
+            forces.zero_()
         for r in range(R):
             p = C.c_void_p(pos.data_ptr() + r * N * 3 * esz)
             f = C.c_void_p(forces.data_ptr() + r * N * 3 * esz) if want_forces else C.c_void_p()
             e = C.c_void_p(eng.ebuf.data_ptr() + r * L.NENERGY * 8)
             bx = (C.c_double * 3)(*[float(v) for v in hbox[min(r, len(hbox) - 1)]])
-            if eng.has_bonded:
-                L.check(lib.tmdhip_compute_bonded(eng.ctx, r, p, bx, f, e, flags, stream), "tmdhip_compute_bonded")
+            # nonbonded first: on the cell-list path it overwrites `forces`, the bonded kernels then add
             if eng.has_nonbonded:
                 nbflags = flags | (L.COUNT_PAIRS if count_pairs else 0)
+                if eng.stores_forces:
+                    nbflags |= L.OVERWRITE_FORCES
                 L.check(
                     lib.tmdhip_compute_nonbonded(eng.ctx, r, p, bx, f, e, nbflags, stream),
                     "tmdhip_compute_nonbonded",
                 )
+            if eng.has_bonded:
+                L.check(lib.tmdhip_compute_bonded(eng.ctx, r, p, bx, f, e, flags, stream), "tmdhip_compute_bonded")
 
     def _verify(self, eng, pos):
         """Host-visible validity check (neighbour-list capacity). True = results valid."""
@@ -351,8 +383,6 @@ class Forces:
         eng = self._engine(p, exact)
         with torch.cuda.device(p.device):
             for _ in range(4):
-                if want_forces:
-                    forces.zero_()
                 self._launch(eng, p, box, forces, want_energy, want_forces, count_pairs)
                 if not (want_energy or count_pairs) or self._verify(eng, p):
                     break
