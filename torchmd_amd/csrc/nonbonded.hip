@@ -159,6 +159,12 @@ __device__ __forceinline__ int cell_coord(R x, const Grid &g, int d) {
   return cidx < 0 ? 0 : (cidx >= nc ? nc - 1 : cidx);
 }
 
+// position folded into [0, box) (identity for box edge 0 = open boundary)
+template <typename R>
+__device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
+  return x - floor(x * invbox) * box;
+}
+
 // flags[p] = "rebuild requested in the step with parity p".  The check kernel of parity p may only
 // SET flags[p] and CLEAR flags[p^1]; every other kernel of that step only reads flags[p].
 template <typename R>
@@ -271,14 +277,17 @@ __global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const R *
 }
 
 struct ListGeom {
-  int lpa;   // lanes per atom in the pair kernel (power of two, 1..64)
-  int apw;   // atoms per wave = 64 / lpa
-  int maxn;  // capacity per atom (multiple of lpa)
+  int lpa;        // lanes per atom in the pair kernel (power of two, 1..64)
+  int apw;        // atoms per wave = 64 / lpa
+  int maxn;       // capacity per atom (multiple of lpa)
+  int lpa_shift;  // log2(lpa)
 };
 
 __device__ __forceinline__ size_t list_slot(const ListGeom &lg, int a, int k) {
-  const int g = a / lg.apw, ain = a % lg.apw;
-  return (size_t)g * lg.maxn * lg.apw + (size_t)(k / lg.lpa) * 64 + ain * lg.lpa + (k % lg.lpa);
+  const int apw_shift = 6 - lg.lpa_shift;
+  const int g = a >> apw_shift, ain = a & (lg.apw - 1);
+  return ((size_t)g * lg.maxn << apw_shift) + ((size_t)(k >> lg.lpa_shift) << 6) + (ain << lg.lpa_shift) +
+         (k & (lg.lpa - 1));
 }
 
 // ---- K2: Verlet list build ---------------------------------------------------------------------
@@ -297,6 +306,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   using R4 = typename Vec<R>::T4;
   __shared__ int seg_start[128];
   __shared__ int seg_prefix[129];
+  __shared__ int seg_code[128];  // periodic image of the stencil cell: 2 bits per axis, 0:-L 1:0 2:+L
   const int lane = threadIdx.x;
   const int cell = blockIdx.x;
   const int cs = cell_start[cell], ce = cell_start[cell + 1];
@@ -305,15 +315,17 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   const int cz = cell % g.nc[2], cy = (cell / g.nc[2]) % g.nc[1], cx = cell / (g.nc[2] * g.nc[1]);
   const int w = 2 * g.m + 1, nst = w * w * w;  // <= 125
   // stencil segments: lane handles stencil cells `lane` and `lane + 64`
-  int cnt2[2], st2[2];
+  int cnt2[2], st2[2], code2[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int sidx = lane + 64 * h;
-    int count = 0, start = 0;
+    int count = 0, start = 0, code = 1 | (1 << 2) | (1 << 4);
     if (sidx < nst) {
       int x = cx + sidx / (w * w) - g.m, y = cy + (sidx / w) % w - g.m, z = cz + sidx % w - g.m;
       bool ok = true;
       if (g.periodic) {
+        code = (x < 0 ? 0 : (x >= g.nc[0] ? 2 : 1)) | ((y < 0 ? 0 : (y >= g.nc[1] ? 2 : 1)) << 2) |
+               ((z < 0 ? 0 : (z >= g.nc[2] ? 2 : 1)) << 4);
         x = (x + g.nc[0]) % g.nc[0];
         y = (y + g.nc[1]) % g.nc[1];
         z = (z + g.nc[2]) % g.nc[2];
@@ -328,6 +340,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     }
     cnt2[h] = count;
     st2[h] = start;
+    code2[h] = code;
   }
   // exclusive prefix over the 128 slots
   int inc0 = cnt2[0], inc1 = cnt2[1];
@@ -343,77 +356,85 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   const int ncand = tot0 + __shfl(inc1, 63, 64);
   seg_start[lane] = st2[0];
   seg_start[lane + 64] = st2[1];
+  seg_code[lane] = code2[0];
+  seg_code[lane + 64] = code2[1];
   seg_prefix[lane] = inc0 - cnt2[0];
   seg_prefix[lane + 64] = tot0 + inc1 - cnt2[1];
   if (lane == 0) seg_prefix[128] = ncand;
   __syncthreads();
 
-  // per-atom data of the i block staged in LDS: the inner loop reads it with wave-uniform
-  // (broadcast) LDS loads instead of dependent global loads
+  // per-atom data of the i block staged in LDS: the inner loop reads it with two wave-uniform
+  // (broadcast) 16-byte LDS loads per atom instead of dependent global loads, and is branch-free
   constexpr int EXS = 4;  // exclusions per atom held in LDS; longer rows spill to global reads
-  __shared__ R4 s_pi[64];
-  __shared__ int s_oi[64], s_ne[64], s_eb[64], s_cnt[64];
-  __shared__ int s_ex[64][EXS];
+  __shared__ R4 s_pi[64];     // xyz of atom i; .w carries the exclusion count (as a number)
+  __shared__ int4 s_ex[64];   // first EXS excluded partners (original indices), -1 = none
+  __shared__ int s_eb[64];
   int wmax = 0;
   for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
     const int iend = min(ib + 64, ce);
     const int ni = iend - ib;
     __syncthreads();
+    int long_rows = 0;
     if (lane < ni) {
-      s_pi[lane] = sorted[ib + lane];
+      R4 p = sorted[ib + lane];
+      p.x = wrap_into_box(p.x, c.box[0], c.invbox[0]);
+      p.y = wrap_into_box(p.y, c.box[1], c.invbox[1]);
+      p.z = wrap_into_box(p.z, c.box[2], c.invbox[2]);
       const int oi = order[ib + lane];
       const int eb = excl_off[oi], ne = excl_off[oi + 1] - eb;
-      s_oi[lane] = oi;
+      p.w = (R)ne;
+      s_pi[lane] = p;
       s_eb[lane] = eb;
-      s_ne[lane] = ne;
-#pragma unroll
-      for (int e = 0; e < EXS; ++e) s_ex[lane][e] = e < ne ? excl_idx[eb + e] : -1;
+      int4 ex;
+      ex.x = 0 < ne ? excl_idx[eb + 0] : -1;
+      ex.y = 1 < ne ? excl_idx[eb + 1] : -1;
+      ex.z = 2 < ne ? excl_idx[eb + 2] : -1;
+      ex.w = 3 < ne ? excl_idx[eb + 3] : -1;
+      s_ex[lane] = ex;
+      long_rows = ne > EXS;
     }
-    s_cnt[lane] = 0;
+    const bool any_long = __ballot(long_rows) != 0ull;
     __syncthreads();
+    int mycnt = 0;  // neighbour count of atom ib + lane
+    int seg = 0;    // segment of this lane's candidate; q grows by 64 per chunk so it only moves forward
     for (int q0 = 0; q0 < ncand; q0 += 64) {
       const int q = q0 + lane;
       const bool valid = q < ncand;
       int j = cs;
-      if (valid) {  // segment of candidate q: last s with seg_prefix[s] <= q
-        int lo = 0, hi = 127;
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (seg_prefix[mid] <= q) lo = mid;
-          else hi = mid - 1;
-        }
-        j = seg_start[lo] + (q - seg_prefix[lo]);
+      if (valid) {  // last s with seg_prefix[s] <= q
+        while (seg_prefix[seg + 1] <= q) ++seg;
+        j = seg_start[seg] + (q - seg_prefix[seg]);
       }
-      const R4 pj = sorted[j];
+      // candidate position as the periodic image that lies next to this cell: the i loop then needs
+      // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
+      // the reference's rounding; the pair kernel's cutoff test does)
+      R4 pj = sorted[j];
+      const int code = seg_code[seg];
+      pj.x = wrap_into_box(pj.x, c.box[0], c.invbox[0]) + (R)((code & 3) - 1) * c.box[0];
+      pj.y = wrap_into_box(pj.y, c.box[1], c.invbox[1]) + (R)(((code >> 2) & 3) - 1) * c.box[1];
+      pj.z = wrap_into_box(pj.z, c.box[2], c.invbox[2]) + (R)(((code >> 4) & 3) - 1) * c.box[2];
       const int oj = order[j];
       const unsigned entry = (unsigned)j | ((unsigned)stype[j] << 24);
-#pragma unroll 2
       for (int t = 0; t < ni; ++t) {
-        const R4 pi = s_pi[t];  // wave-uniform LDS broadcast
-        const R dx = min_image(pi.x - pj.x, c.box[0], c.invbox[0]);
-        const R dy = min_image(pi.y - pj.y, c.box[1], c.invbox[1]);
-        const R dz = min_image(pi.z - pj.z, c.box[2], c.invbox[2]);
+        const R4 pi = s_pi[t];
+        const int4 ex = s_ex[t];
+        const R dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         const R r2 = dx * dx + dy * dy + dz * dz;
-        bool hit = valid && (r2 <= rlist2) && (j != ib + t);
-#pragma unroll
-        for (int e = 0; e < EXS; ++e) hit = hit && (s_ex[t][e] != oj);
-        const int ne = s_ne[t];
-        if (ne > EXS) {
-          const int eb = s_eb[t];
+        // branch-free "oj is one of ex.*": the smallest xor is 0 exactly when one of them matches
+        const unsigned xm = min(min((unsigned)(ex.x ^ oj), (unsigned)(ex.y ^ oj)),
+                                min((unsigned)(ex.z ^ oj), (unsigned)(ex.w ^ oj)));
+        bool hit = valid && (r2 <= rlist2) && (j != ib + t) && (xm != 0u);
+        if (any_long) {  // wave-uniform, rare (atoms with more than EXS exclusions: proteins)
+          const int ne = (int)pi.w, eb = s_eb[t];
           for (int e = EXS; e < ne; ++e) hit = hit && (excl_idx[eb + e] != oj);
         }
         const unsigned long long mask = __ballot(hit);
-        if (mask == 0ull) continue;
-        const int base = s_cnt[t];
-        if (hit) {
-          const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
-          if (k < lg.maxn) nlist[list_slot(lg, ib + t, k)] = entry;
-        }
-        if (lane == 0) s_cnt[t] = base + __popcll(mask);
+        const int base = __builtin_amdgcn_readlane(mycnt, t);
+        const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (hit & (k < lg.maxn)) nlist[list_slot(lg, ib + t, k)] = entry;
+        mycnt += (lane == t) ? __popcll(mask) : 0;
       }
     }
-    __syncthreads();
-    const int mycnt = s_cnt[lane];
     if (lane < ni) nneigh[ib + lane] = min(mycnt, lg.maxn);
     wmax = max(wmax, lane < ni ? mycnt : 0);
   }
@@ -588,7 +609,7 @@ struct Replica {
   double box[3] = {-1, -1, -1};
   Grid grid{};
   int ncell = 0;
-  ListGeom lg{1, 64, 0};
+  ListGeom lg{1, 64, 0, 0};
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, count, cell_start, sorted, stype, ref, nlist, nneigh;
   DevBuf flags;  // int[4]: flags[0..1] rebuild parity, [2] overflow, [3] rebuild counter
@@ -788,6 +809,8 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.nneigh.ensure(sizeof(int) * n));
   rp.lg.lpa = pick_lpa(n);
   rp.lg.apw = 64 / rp.lg.lpa;
+  rp.lg.lpa_shift = 0;
+  while ((1 << rp.lg.lpa_shift) < rp.lg.lpa) rp.lg.lpa_shift++;
   maxn = (maxn + rp.lg.lpa - 1) / rp.lg.lpa * rp.lg.lpa;
   rp.lg.maxn = maxn;
   const size_t groups = (n + rp.lg.apw - 1) / rp.lg.apw;
