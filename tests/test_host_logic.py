@@ -1,0 +1,275 @@
+"""CPU tests (no GPU): C-ABI surface, host-side logic of the Forces/Integrator mirror, topology
+readers / Parameters against the reference (when /root/reference is present), replica fan-out over
+gloo with world_size 2."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import GoldenParameters, load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol():
+    """The library loads on a CPU-only box and exports exactly what include/tmdhip.h declares."""
+    from torchmd_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "tmdhip.h")).read()
+    declared = set(re.findall(r"\b(tmdhip_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.tmdhip_abi_version() == _lib.ABI_VERSION
+    # struct layouts agree with the C compiler's view of the header
+    src = '#include "tmdhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n", sizeof(tmdhip_nonbonded_desc), sizeof(tmdhip_bonded_desc), sizeof(tmdhip_stats));return 0;}'
+    exe = os.path.join(ROOT, "tests", ".sizeof_probe")
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    try:
+        sizes = [int(x) for x in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
+    finally:
+        os.remove(exe)
+    assert sizes == [C.sizeof(_lib.NonbondedDesc), C.sizeof(_lib.BondedDesc), C.sizeof(_lib.Stats)]
+
+
+def test_capi_argument_validation_without_gpu():
+    from torchmd_amd import _lib
+
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    d = _lib.NonbondedDesc()
+    d.struct_size = 4  # wrong size -> ABI error before any HIP call
+    assert lib.tmdhip_create(C.byref(ctx), C.byref(d)) < 0
+    assert "size mismatch" in _lib.last_error()
+    assert lib.tmdhip_first_vv(7, 1, 1, None, None, None, None, 0.1, None) < 0
+    assert "dtype" in _lib.last_error()
+    assert lib.tmdhip_compute_nonbonded(None, 0, None, None, None, None, 0, None) < 0
+
+
+def test_no_cpu_fallback():
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator
+    from torchmd_amd.systems import System
+
+    g = load("water291")
+    par = GoldenParameters(g, torch.float32)
+    f = Forces(par, terms=["lj", "electrostatics"], cutoff=7.3)
+    s = System(291, 1, torch.float32, "cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        f.compute(s.pos, s.box, s.forces)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Integrator(s, f, 1.0, "cpu").step(1)
+
+
+def test_forces_constructor_contract():
+    from torchmd_amd.forces import Forces, build_exclusion_csr
+
+    g = load("ala2")
+    par = GoldenParameters(g, torch.float64)
+    with pytest.raises(RuntimeError):
+        Forces(par, terms=None)
+    with pytest.raises(ValueError):
+        Forces(par, terms=["bonds", "hbonds"])
+    with pytest.raises(RuntimeError):
+        Forces(par, terms=["1-4", "lj"])
+    f = Forces(par, terms=["Bonds", "LJ", "Electrostatics"], cutoff=9, rfa=True, switch_dist=7.5)
+    assert f.energies == ["bonds", "lj", "electrostatics"] and f.require_distances and f.natoms == 688
+    assert par.A is not None and par.A.shape == (10, 10)  # T = 10 for C2
+    assert Forces.terms == Forces.bonded + Forces.nonbonded
+    off, idx = f._excl_csr
+    assert off[-1] == len(idx) == 2 * 764  # 764 exclusion entries, stored in both directions
+    assert f.ava_idx.shape == (235564, 2)  # P_all of C2
+    # CSR rows are sorted and symmetric
+    pairs = {(i, int(j)) for i in range(688) for j in idx[off[i]:off[i + 1]]}
+    assert all((j, i) in pairs for i, j in pairs)
+    assert all(np.all(np.diff(idx[off[i]:off[i + 1]]) > 0) for i in range(688))
+    off2, idx2 = build_exclusion_csr(5, [[0, 1], [1, 0], [3, 2], [0, 1]])
+    assert off2.tolist() == [0, 1, 2, 3, 4, 4] and idx2.tolist() == [1, 0, 3, 2]
+    assert Forces(par, terms=["bonds"]).ava_idx is None
+
+
+def test_system_setters():
+    from torchmd_amd.systems import System
+
+    s = System(4, 3, torch.float64, "cpu")
+    s.set_positions(np.arange(12, dtype=np.float32).reshape(4, 3))
+    assert torch.equal(s.pos[0], s.pos[2]) and s.pos.dtype == torch.float64
+    s.set_positions(np.stack([np.full((4, 3), k, dtype=np.float32) for k in range(3)], axis=2))
+    assert s.pos[1, 0, 0] == 1 and s.pos[2, 3, 2] == 2
+    s.set_box(np.array([10.0, 11.0, 12.0]))
+    assert torch.equal(s.box[2], torch.diag(torch.tensor([10.0, 11.0, 12.0], dtype=torch.float64)))
+    s.set_box(np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0], [7.0, 8.0, 9.0]]))
+    assert torch.equal(s.box[1].diagonal(), torch.tensor([2.0, 5.0, 8.0], dtype=torch.float64))
+    with pytest.raises(RuntimeError):
+        s.set_positions(np.zeros((4, 2)))
+    with pytest.raises(RuntimeError):
+        s.set_velocities(torch.zeros(1, 4, 3))
+    with pytest.raises(RuntimeError):
+        s.set_box(np.zeros(2))
+    with pytest.raises(RuntimeError):
+        s.set_masses(torch.zeros(5))
+    s.set_masses(torch.tensor([1.0, 2.0, 3.0, 4.0]))
+    assert s.masses.shape == (4, 1) and s.natoms == 4 and s.nreplicas == 3
+
+
+def test_kinetic_energy_helpers():
+    """Reference tests/test_integrator.py:7-140 (single/multi replica, batches incl. empty ones)."""
+    from torchmd_amd.integrator import BOLTZMAN, kinetic_energy, kinetic_to_temp, maxwell_boltzmann
+
+    m = torch.tensor([[1.0], [2.0], [3.0]])
+    v = torch.tensor([[[1.0, 0, 0], [0, 2.0, 0], [0, 0, 3.0]], [[0.0, 0, 0]] * 3])
+    ke = kinetic_energy(m, v)
+    assert ke.shape == (2, 1) and torch.allclose(ke[:, 0], torch.tensor([0.5 + 4.0 + 13.5, 0.0]))
+    kb = kinetic_energy(m, v, batch=torch.tensor([0, 2, 2]))
+    assert kb.shape == (2, 3) and torch.allclose(kb[0], torch.tensor([0.5, 0.0, 17.5]))
+    with pytest.raises(ValueError):
+        kinetic_energy(m, v[0])
+    assert np.isclose(kinetic_to_temp(1.0, 10), 2.0 / (30 * BOLTZMAN))
+    torch.manual_seed(0)
+    vel = maxwell_boltzmann(torch.full((20000, 1), 12.0), 300.0, replicas=2)
+    assert vel.shape == (2, 20000, 3)
+    T = kinetic_to_temp(kinetic_energy(torch.full((20000, 1), 12.0), vel)[:, 0].numpy(), 20000)
+    assert np.all(np.abs(T - 300) < 6)
+
+
+def test_builders():
+    from torchmd_amd.builders import lj_box, tip3p_box, water_forcefield
+    from torchmd_amd.parameters import Parameters
+
+    mol, pos, box = tip3p_box(4, seed=0)
+    assert mol.numAtoms == 192 and pos.shape == (192, 3) and np.allclose(box, 4 * (1 / 0.0334) ** (1 / 3))
+    d = np.linalg.norm(pos[1::3] - pos[0::3], axis=1)
+    assert np.allclose(d, 0.9572, atol=1e-10)
+    hoh = np.degrees(np.arccos(np.sum((pos[1::3] - pos[0::3]) * (pos[2::3] - pos[0::3]), axis=1) / 0.9572**2))
+    assert np.allclose(hoh, 104.52, atol=1e-8)
+    par = Parameters(water_forcefield(mol), mol, ["lj", "electrostatics", "bonds", "angles"])
+    assert len(par.bond_params["idx"]) == 192 and len(par.angle_params["idx"]) == 64
+    assert len(par.get_exclusions()) == 192 + 64
+    assert abs(float(par.charges.sum())) < 1e-4
+    mol2, pos2, box2 = tip3p_box(4, seed=0)
+    assert np.array_equal(pos, pos2)  # deterministic
+    mol3, pos3, box3 = lj_box(5)
+    assert mol3.numAtoms == 125 and np.allclose(box3, 5 * (1 / 0.0213) ** (1 / 3))
+
+
+def test_replica_slices():
+    from torchmd_amd.replicas import replica_slice
+
+    assert [list(replica_slice(8, r, 8)) for r in range(8)] == [[r] for r in range(8)]
+    got = [list(replica_slice(10, r, 4)) for r in range(4)]
+    assert got == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+    with pytest.raises(ValueError):
+        replica_slice(2, 0, 4)
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from torchmd_amd.replicas import ReplicaFanout
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+fan = ReplicaFanout(total_replicas=5)
+assert fan.rank == rank and fan.world == 2 and list(fan.local) == ([0, 1, 2] if rank == 0 else [3, 4])
+fan.check_same_topology(np.arange(10), np.ones(3))
+try:
+    fan.check_same_topology(np.arange(10) + rank)
+    raise SystemExit("mismatch not detected")
+except RuntimeError:
+    pass
+loc = list(fan.local)
+obs = fan.gather_observables([10.0 + r for r in loc], [-100.0 - r for r in loc], [300.0 + r for r in loc])
+assert obs.shape == (5, 3)
+assert np.allclose(obs[:, 0], 10 + np.arange(5)) and np.allclose(obs[:, 1], -100 - np.arange(5)) and np.allclose(obs[:, 2], 300 + np.arange(5))
+assert fan.max_over_ranks(1.0 + rank) == 2.0
+fan.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_replica_fanout_gloo_world2(tmp_path):
+    """N>1 path on CPU: two processes over gloo (the GPU run uses the same code over nccl = RCCL)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", WORLD_SIZE="2")
+    procs = [
+        subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT)
+        for r in range(2)
+    ]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
+
+
+# ------------------------------------------------------------------------------------------------
+# readers + Parameters vs the reference itself (build container only)
+# ------------------------------------------------------------------------------------------------
+def _ref_modules():
+    sys.path.insert(0, "/root/reference")
+    from torchmd.forcefields.ff_yaml import YamlForcefield
+    from torchmd.parameters import Parameters as RefParameters
+
+    return YamlForcefield, RefParameters
+
+
+def _same_table(a, b):
+    if a is None or b is None:
+        return a is None and b is None or (not torch.is_tensor((a or b).get("idx")))
+    ok = torch.equal(a["idx"], b["idx"])
+    pa, pb = a["params"][a["map"][:, 1]], b["params"][b["map"][:, 1]]
+    return ok and torch.equal(a["map"][:, 0], b["map"][:, 0]) and torch.equal(pa, pb)
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("prec", [torch.float32, torch.float64])
+def test_parameters_match_reference_water(prec):
+    from torchmd_amd import io as tio
+    from torchmd_amd.forcefields import YamlForceField
+    from torchmd_amd.parameters import Parameters
+
+    RefYaml, RefParameters = _ref_modules()
+    d = "/root/reference/tests/water"
+    mol = tio.read_psf(os.path.join(d, "structure.psf"))
+    terms = ["lj", "bonds", "angles", "electrostatics"]
+    mine = Parameters(YamlForceField(mol, os.path.join(d, "water_forcefield.yaml")), mol, terms, precision=prec)
+    ref = RefParameters(RefYaml(mol, os.path.join(d, "water_forcefield.yaml")), mol, terms, precision=prec)
+    assert torch.equal(mine.charges, ref.charges) and torch.equal(mine.masses, ref.masses)
+    assert torch.equal(mine.mapped_atom_types, ref.mapped_atom_types)
+    assert torch.equal(mine.nonbonded_params["params"], ref.nonbonded_params["params"])
+    assert _same_table(mine.bond_params, ref.bond_params) and _same_table(mine.angle_params, ref.angle_params)
+    A1, B1 = mine.get_AB()
+    A2, B2 = ref.get_AB()
+    assert torch.equal(A1, A2) and torch.equal(B1, B2)
+    assert sorted(map(tuple, mine.get_exclusions())) == sorted(map(tuple, ref.get_exclusions()))
+
+
+@pytest.mark.needs_reference
+def test_parameters_match_reference_ala2():
+    from torchmd_amd import io as tio
+    from torchmd_amd.forcefields import ForceField, PrmtopForceField
+    from torchmd_amd.parameters import Parameters
+
+    _, RefParameters = _ref_modules()
+    d = "/root/reference/tests/data/prod_alanine_dipeptide_amber"
+    mol, top = tio.read_prmtop(os.path.join(d, "structure.prmtop"))
+    ff = PrmtopForceField(mol, top)
+    assert isinstance(ForceField.create(mol, os.path.join(d, "structure.prmtop")), PrmtopForceField)
+    terms = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+    mine = Parameters(ff, mol, terms, precision=torch.float64)
+    ref = RefParameters(ff, mol, terms, precision=torch.float64)
+    for name in ("bond", "angle", "dihedral", "improper", "nonbonded_14"):
+        assert _same_table(getattr(mine, name + "_params"), getattr(ref, name + "_params")), name
+    assert torch.equal(mine.nonbonded_params["params"], ref.nonbonded_params["params"])
+    g = load("ala2")
+    assert np.array_equal(mine.charges.numpy(), g["par_charges"])
+    assert np.array_equal(tio.read_namd_coor(os.path.join(d, "input.coor")), g["pos"])
+    assert np.array_equal(tio.read_xsc(os.path.join(d, "input.xsc")), g["box"])
