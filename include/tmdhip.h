@@ -157,6 +157,10 @@ int tmdhip_compute_bonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, con
  * grown, the next compute rebuilds, and the caller must repeat the evaluation; negative = error. */
 int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream);
 
+/* Drop the neighbour list of a replica: the next tmdhip_compute_nonbonded rebuilds it (used after the
+ * caller has changed positions out of band, and by the rebuild timing tool). */
+int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica);
+
 /* Host-synchronising query (copies a few words back). */
 int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out);
 

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -363,12 +364,19 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   if (lane == 0) seg_prefix[128] = ncand;
   __syncthreads();
 
-  // per-atom data of the i block staged in LDS: the inner loop reads it with two wave-uniform
-  // (broadcast) 16-byte LDS loads per atom instead of dependent global loads, and is branch-free
-  constexpr int EXS = 4;  // exclusions per atom held in LDS; longer rows spill to global reads
-  __shared__ R4 s_pi[64];     // xyz of atom i; .w carries the exclusion count (as a number)
-  __shared__ int4 s_ex[64];   // first EXS excluded partners (original indices), -1 = none
-  __shared__ int s_eb[64];
+  // per-atom data of the i block staged in LDS as two 16-byte records that the inner loop reads with
+  // wave-uniform (broadcast) LDS loads: rec0 = {wrapped xyz, word offset of the atom's list row},
+  // rec1 = {own original index, first three excluded partners} (so "j == i" is just one more
+  // exclusion; longer exclusion rows spill to global reads).  PMC showed this loop limited by the
+  // scalar unit (one SALU per CU, shared by the 4 SIMDs) as much as by VALU, hence: LDS addresses and
+  // the row offset live in VGPRs, the per-atom hit counters move with readlane/writelane, and the
+  // rare long-exclusion path is hoisted out as a separate loop version.
+  constexpr int EXS = 4;
+  __shared__ R4 s_rec0[64];
+  __shared__ int4 s_rec1[64];
+  __shared__ int s_eb[64], s_more[64];
+  const int apw_shift = 6 - lg.lpa_shift;
+  const unsigned kmask = (unsigned)lg.lpa - 1u;
   int wmax = 0;
   for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
     const int iend = min(ib + 64, ce);
@@ -376,22 +384,27 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     __syncthreads();
     int long_rows = 0;
     if (lane < ni) {
-      R4 p = sorted[ib + lane];
+      const int a = ib + lane;
+      R4 p = sorted[a];
       p.x = wrap_into_box(p.x, c.box[0], c.invbox[0]);
       p.y = wrap_into_box(p.y, c.box[1], c.invbox[1]);
       p.z = wrap_into_box(p.z, c.box[2], c.invbox[2]);
-      const int oi = order[ib + lane];
+      const unsigned rowoff = (((unsigned)(a >> apw_shift) * (unsigned)lg.maxn) << apw_shift) +
+                              ((unsigned)(a & (lg.apw - 1)) << lg.lpa_shift);
+      if constexpr (sizeof(R) == 4) p.w = __uint_as_float(rowoff);
+      else p.w = __longlong_as_double((long long)rowoff);
+      const int oi = order[a];
       const int eb = excl_off[oi], ne = excl_off[oi + 1] - eb;
-      p.w = (R)ne;
-      s_pi[lane] = p;
-      s_eb[lane] = eb;
+      s_rec0[lane] = p;
+      s_eb[lane] = eb + (EXS - 1);
+      s_more[lane] = max(ne - (EXS - 1), 0);
       int4 ex;
-      ex.x = 0 < ne ? excl_idx[eb + 0] : -1;
-      ex.y = 1 < ne ? excl_idx[eb + 1] : -1;
-      ex.z = 2 < ne ? excl_idx[eb + 2] : -1;
-      ex.w = 3 < ne ? excl_idx[eb + 3] : -1;
-      s_ex[lane] = ex;
-      long_rows = ne > EXS;
+      ex.x = oi;
+      ex.y = 0 < ne ? excl_idx[eb + 0] : -1;
+      ex.z = 1 < ne ? excl_idx[eb + 1] : -1;
+      ex.w = 2 < ne ? excl_idx[eb + 2] : -1;
+      s_rec1[lane] = ex;
+      long_rows = ne > EXS - 1;
     }
     const bool any_long = __ballot(long_rows) != 0ull;
     __syncthreads();
@@ -407,32 +420,49 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       }
       // candidate position as the periodic image that lies next to this cell: the i loop then needs
       // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
-      // the reference's rounding; the pair kernel's cutoff test does)
+      // the reference's rounding; the pair kernel's cutoff test does).  Lanes past the end of the
+      // candidate list are parked far away so that they can never hit.
       R4 pj = sorted[j];
       const int code = seg_code[seg];
       pj.x = wrap_into_box(pj.x, c.box[0], c.invbox[0]) + (R)((code & 3) - 1) * c.box[0];
       pj.y = wrap_into_box(pj.y, c.box[1], c.invbox[1]) + (R)(((code >> 2) & 3) - 1) * c.box[1];
       pj.z = wrap_into_box(pj.z, c.box[2], c.invbox[2]) + (R)(((code >> 4) & 3) - 1) * c.box[2];
+      if (!valid) pj.x = (R)1e18;
       const int oj = order[j];
       const unsigned entry = (unsigned)j | ((unsigned)stype[j] << 24);
-      for (int t = 0; t < ni; ++t) {
-        const R4 pi = s_pi[t];
-        const int4 ex = s_ex[t];
+      // LDS byte offset of the current i record, kept in a VGPR on purpose (see above)
+      unsigned recoff;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(recoff));
+      for (int t = 0; t < ni; ++t, recoff += 16u) {
+        const R4 pi = *reinterpret_cast<const R4 *>(reinterpret_cast<const char *>(s_rec0) +
+                                                     recoff * (unsigned)(sizeof(R4) / 16));
         const R dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         const R r2 = dx * dx + dy * dy + dz * dz;
-        // branch-free "oj is one of ex.*": the smallest xor is 0 exactly when one of them matches
-        const unsigned xm = min(min((unsigned)(ex.x ^ oj), (unsigned)(ex.y ^ oj)),
-                                min((unsigned)(ex.z ^ oj), (unsigned)(ex.w ^ oj)));
-        bool hit = valid && (r2 <= rlist2) && (j != ib + t) && (xm != 0u);
-        if (any_long) {  // wave-uniform, rare (atoms with more than EXS exclusions: proteins)
-          const int ne = (int)pi.w, eb = s_eb[t];
-          for (int e = EXS; e < ne; ++e) hit = hit && (excl_idx[eb + e] != oj);
+        bool hit = r2 <= rlist2;
+        // two-level test: exclusions, compaction and the store only run for (i, chunk) combinations
+        // with at least one candidate in range (a chunk is ~one z-column of the stencil, so for a
+        // given i many chunks are entirely out of reach)
+        if (__ballot(hit) != 0ull) {
+          const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff);
+          // branch-free "oj is one of ex.*": the smallest xor is 0 exactly when one of them matches
+          const unsigned xm = min(min((unsigned)(ex.x ^ oj), (unsigned)(ex.y ^ oj)),
+                                  min((unsigned)(ex.z ^ oj), (unsigned)(ex.w ^ oj)));
+          hit = hit && (xm != 0u);
+          if (any_long) {  // wave-uniform, rare (atoms with more than EXS-1 exclusions: proteins)
+            const int more = s_more[t], eb = s_eb[t];
+            for (int e = 0; e < more; ++e) hit = hit && (excl_idx[eb + e] != oj);
+          }
+          const unsigned long long mask = __ballot(hit);
+          const int base = __builtin_amdgcn_readlane(mycnt, t);
+          const unsigned k = (unsigned)(base + __popcll(mask & ((1ull << lane) - 1ull)));
+          if (hit && (k < (unsigned)lg.maxn)) {
+            unsigned rowoff;
+            if constexpr (sizeof(R) == 4) rowoff = __float_as_uint(pi.w);
+            else rowoff = (unsigned)__double_as_longlong(pi.w);
+            nlist[rowoff + ((k >> lg.lpa_shift) << 6) + (k & kmask)] = entry;
+          }
+          mycnt += (lane == t) ? (int)__popcll(mask) : 0;
         }
-        const unsigned long long mask = __ballot(hit);
-        const int base = __builtin_amdgcn_readlane(mycnt, t);
-        const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
-        if (hit & (k < lg.maxn)) nlist[list_slot(lg, ib + t, k)] = entry;
-        mycnt += (lane == t) ? __popcll(mask) : 0;
       }
     }
     if (lane < ni) nneigh[ib + lane] = min(mycnt, lg.maxn);
@@ -565,6 +595,129 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
   if (paircount) {
     const unsigned long long s = wave_sum((unsigned long long)cnt);
     if (lane == 0 && s) atomicAdd(paircount, s);
+  }
+}
+
+// ---- K3f: packed-fp32 specialisation of the list pair kernel ------------------------------------
+// PMC (profiles/): the pair kernel is VALU-bound — 48 wave-instructions per 64 list entries at ~4
+// cycles each (SQ_ACTIVE_INST_VALU ~ 86 % of the kernel time), so the lever is instruction count.
+// On gfx950 a plain fp32 VALU op retires one result per lane, v_pk_{add,mul,fma}_f32 two.  This
+// kernel therefore evaluates list entries two at a time on float2 vectors (every add/mul/fma of the
+// minimum image, |d|^2, LJ and reaction-field maths becomes a v_pk_* instruction), gathers j through
+// 32-bit byte offsets against a scalar base (saddr addressing, no 64-bit address arithmetic), and
+// reads a pre-scaled (-12A, 6B) table from LDS.  Same decision arithmetic (bit-exact) as pair_math.h:
+// packed ops round exactly like their scalar forms.  Terms: LJ + reaction-field electrostatics, no
+// switching, forces only (the water benchmark); everything else takes list_pair_kernel.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v2f min_image2(v2f d, float box, float invbox) {
+#pragma clang fp contract(off)
+  const v2f k = __builtin_elementwise_roundeven(d * invbox);
+  const v2f p = box * k;
+  return d - p;
+}
+
+template <int LPA>
+__global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
+    int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
+    int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
+    const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite) {
+  constexpr int APW = 64 / LPA;
+  constexpr int UNROLL = 4;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float2 *stab = reinterpret_cast<float2 *>(smem);  // (-12 A, 6 B)
+  for (int t = threadIdx.x; t < ntypes * ntypes; t += blockDim.x) {
+    const float2 ab = tab[t];
+    stab[t] = make_float2(-12.0f * ab.x, 6.0f * ab.y);
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int a = wave * APW + lane / LPA;
+  const int sub = lane % LPA;
+  const bool active = a < n;
+  float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+  int nn = 0;
+  unsigned trow8 = 0;  // byte offset of this atom's row of the LDS table
+  if (active) {
+    pi = sorted[a];
+    nn = nneigh[a];
+    trow8 = (unsigned)(stype[a] * ntypes) * 8u;
+  }
+  int nmax = nn;
+#pragma unroll
+  for (int o = 32; o >= LPA; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  const int nkk = (nmax + LPA - 1) / LPA;
+  const int myiters = (nn - sub + LPA - 1) / LPA;  // entries kk < myiters are real for this lane
+  const unsigned *row = nlist + (size_t)wave * maxn * APW + lane;
+  // bounds-checked raw buffer over sorted_xyzq: lanes past the end of their list read whatever the
+  // (uninitialised) padding entry points at — out-of-range offsets return 0 instead of faulting — and
+  // are discarded by `valid`; this removes every per-entry select from the address path
+  const __amdgpu_buffer_rsrc_t srsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(sorted), 0, n * 16, 0x00020000);
+  const char *tbase = reinterpret_cast<const char *>(stab);
+  const v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, piz = {pi.z, pi.z}, piw = {pi.w, pi.w};
+  const float two_krf = 2.0f * c.krf;
+
+  v2f fx = {0.f, 0.f}, fy = {0.f, 0.f}, fz = {0.f, 0.f};
+  for (int kk0 = 0; kk0 < nkk; kk0 += UNROLL) {
+    unsigned entry[UNROLL];
+    float4 pj[UNROLL];
+    float2 ab[UNROLL];
+    bool valid[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) entry[u] = row[(size_t)(kk0 + u) * 64];  // rows are padded: always readable
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      valid[u] = kk0 + u < myiters;
+      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (entry[u] << 4) & 0x0FFFFFF0u, 0, 0);
+      pj[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
+                          __uint_as_float(raw.w));
+      ab[u] = *reinterpret_cast<const float2 *>(tbase + (trow8 + ((entry[u] >> 21) & 0x7F8u)));
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u += 2) {
+      const v2f pjx = {pj[u].x, pj[u + 1].x}, pjy = {pj[u].y, pj[u + 1].y}, pjz = {pj[u].z, pj[u + 1].z};
+      const v2f pjw = {pj[u].w, pj[u + 1].w};
+      const v2f dx = min_image2(pix - pjx, c.box[0], c.invbox[0]);
+      const v2f dy = min_image2(piy - pjy, c.box[1], c.invbox[1]);
+      const v2f dz = min_image2(piz - pjz, c.box[2], c.invbox[2]);
+      const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      const bool h0 = valid[u] && (r2.x <= c.r2max), h1 = valid[u + 1] && (r2.y <= c.r2max);
+      const v2f r2s = {h0 ? r2.x : 1.0f, h1 ? r2.y : 1.0f};
+      const v2f rinv = {__frsqrt_rn(r2s.x), __frsqrt_rn(r2s.y)};
+      const v2f rinv2 = rinv * rinv;
+      const v2f rinv6 = rinv2 * rinv2 * rinv2;
+      const v2f a12 = {ab[u].x, ab[u + 1].x}, b6 = {ab[u].y, ab[u + 1].y};
+      const v2f qq = piw * pjw;
+      // (dE_lj/dr + dE_rf/dr) / r  with a12 = -12 A, b6 = 6 B
+      v2f fs = __builtin_elementwise_fma(a12, rinv6, b6) * (rinv6 * rinv2) + qq * (two_krf - rinv2 * rinv);
+      fs = v2f{h0 ? fs.x : 0.0f, h1 ? fs.y : 0.0f};
+      fx -= dx * fs;
+      fy -= dy * fs;
+      fz -= dz * fs;
+    }
+  }
+  float sx = fx.x + fx.y, sy = fy.x + fy.y, sz = fz.x + fz.y;
+#pragma unroll
+  for (int o = LPA >> 1; o > 0; o >>= 1) {
+    sx += __shfl_xor(sx, o, 64);
+    sy += __shfl_xor(sy, o, 64);
+    sz += __shfl_xor(sz, o, 64);
+  }
+  if (active && sub == 0 && forces) {
+    const int oi = order[a];
+    if (overwrite) {
+      forces[3 * oi + 0] = sx;
+      forces[3 * oi + 1] = sy;
+      forces[3 * oi + 2] = sz;
+    } else {
+      forces[3 * oi + 0] += sx;
+      forces[3 * oi + 1] += sy;
+      forces[3 * oi + 2] += sz;
+    }
   }
 }
 
@@ -769,6 +922,28 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const int blocks = (waves + 3) / 4;
   const size_t shmem = (size_t)ctx->d.ntypes * ctx->d.ntypes * sizeof(R2);
   const bool fast = !ENERGY && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS) && c.rfa && !c.switch_on;
+  if constexpr (std::is_same<R, float>::value) {
+    // packed-fp32 kernel: needs 32-bit byte offsets into sorted_xyzq and the 7-bit type field
+    if (fast && !paircount && f && ctx->d.ntypes <= 128 && n < (1 << 24)) {
+      const size_t shfast = shmem + 2048;  // garbage type fields of padding entries stay inside the allocation
+#define TMD_LAUNCH_FAST(L)                                                                                   \
+  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L>), dim3(blocks), dim3(256), shfast, st, n, rp.sorted.as<R4>(), \
+                     rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),                 \
+                     rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite)
+      switch (rp.lg.lpa) {
+        case 1: TMD_LAUNCH_FAST(1); break;
+        case 2: TMD_LAUNCH_FAST(2); break;
+        case 4: TMD_LAUNCH_FAST(4); break;
+        case 8: TMD_LAUNCH_FAST(8); break;
+        case 16: TMD_LAUNCH_FAST(16); break;
+        case 32: TMD_LAUNCH_FAST(32); break;
+        default: TMD_LAUNCH_FAST(64); break;
+      }
+#undef TMD_LAUNCH_FAST
+      TMD_HIP(hipGetLastError());
+      return 0;
+    }
+  }
 #define TMD_LAUNCH(L, F)                                                                                \
   hipLaunchKernelGGL((list_pair_kernel<R, ENERGY, L, F>), dim3(blocks), dim3(256), shmem, st, n,        \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,          \
@@ -814,7 +989,10 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   maxn = (maxn + rp.lg.lpa - 1) / rp.lg.lpa * rp.lg.lpa;
   rp.lg.maxn = maxn;
   const size_t groups = (n + rp.lg.apw - 1) / rp.lg.apw;
-  TMD_TRY(rp.nlist.ensure(sizeof(unsigned) * groups * maxn * rp.lg.apw));
+  if (groups * maxn * rp.lg.apw + 4 * 64 >= (size_t)1 << 30)
+    return fail("neighbour list would exceed 2^30 entries per replica (32-bit row offsets)");
+  // + 4 wave-rows of padding: the unrolled pair kernels read up to 3 iterations past a group's rows
+  TMD_TRY(rp.nlist.ensure(sizeof(unsigned) * (groups * maxn * rp.lg.apw + 4 * 64)));
   return 0;
 }
 
@@ -1138,6 +1316,13 @@ int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream) {
   rp.box[0] = -1;  // forces the re-plan + rebuild path
   last_error() = "neighbour list overflowed (capacity grown, results since the last check are invalid)";
   return 1;
+}
+
+int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica) {
+  if (!ctx) return fail("tmdhip_invalidate_list: null ctx");
+  if (replica < 0 || replica >= (int)ctx->rep.size()) return fail("tmdhip_invalidate_list: bad replica index");
+  ctx->rep[replica].box[0] = -1;  // next compute re-plans the grid and rebuilds (host-synchronising)
+  return 0;
 }
 
 int tmdhip_timing_enable(tmdhip_ctx *ctx, int on) {
