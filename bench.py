@@ -30,6 +30,19 @@ TIMESTEP_FS = 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/): counters
+    cannot be collected inside the timed run, so the figure of the same kernel + workload measured with
+    `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` is reported, with its provenance."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return float(d["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
 def ns_per_day(steps, seconds, timestep_fs=TIMESTEP_FS):
     return steps / seconds * timestep_fs * 1e-6 * 86400.0  # reference run.py:19,279 (FS2NS)
 
@@ -153,6 +166,7 @@ def main():
     pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
     achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
     step_bytes = 4.0 * pcut + 132.0 * natoms  # whole step incl. integrator
+    traffic, traffic_src = pmc_traffic() if (args.nside == 32) else (None, None)
 
     out = {
         "metric": "ns/day (aggregate over replicas), 100k-atom TIP3P water box, 9 A cutoff + reaction field",
@@ -190,13 +204,14 @@ def main():
             "ncell": list(st2["ncell"]),
         },
         "roofline": {
-            "kernel": "list_pair_kernel<float>",
+            "kernel": "list_pair_fast_f32_kernel<8> (packed fp32, LJ + reaction field)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_kernel_us": pair_avg_s * 1e6,
             "launches_timed": int(pair_launches),

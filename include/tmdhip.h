@@ -185,6 +185,13 @@ int tmdhip_langevin_second_vv(int dtype, int64_t nreplicas, int64_t natoms, void
 /* kinetic_energy (integrator.py:8-31, batch=None): ke_dev[r] = sum_i 0.5*m_i*|v_ri|^2 (overwrites) */
 int tmdhip_kinetic_energy(int dtype, int64_t nreplicas, int64_t natoms, const void *vel_dev,
                           const void *mass_dev, double *ke_dev, void *stream);
+/* Wrapper.wrap (wrapper.py:8-30): translate every bonded group by -floor(com/box)*box (com = unweighted
+ * mean of its atoms).  pos_dev real [R,N,3] in place; box_dev real [R,3,3] (device, diagonal used; an
+ * all-zero box leaves the replica untouched); groups as a CSR over atoms (device int32 arrays; atoms
+ * without bonds are groups of one).  has_big_groups != 0 if any group has more than 64 atoms. */
+int tmdhip_wrap(int dtype, int64_t nreplicas, int64_t natoms, void *pos_dev, const void *box_dev, int32_t ngroups,
+                const int32_t *group_offsets_dev, const int32_t *group_members_dev, int32_t has_big_groups,
+                void *stream);
 /* Fill `out_dev` (real [n]) with the N(0,1) stream used by tmdhip_langevin_second_vv (for tests). */
 int tmdhip_normal_fill(int dtype, int64_t n, void *out_dev, uint64_t seed, uint64_t step, void *stream);
 

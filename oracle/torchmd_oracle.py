@@ -392,3 +392,19 @@ def md_step(par, pos, vel, forces, box, masses, dt, terms, gamma=None, vcoeff=No
         langevin(vel, gamma, vcoeff, dt, noise if noise is not None else torch.randn_like(vel))
     second_vv(vel, forces, masses, dt)
     return pots, npairs
+
+
+# ----------------------------------------------------------------------------- wrapper
+def wrap_molecules(pos, box, groups, nongrouped):
+    """wrapper.py:8-30 with wrapidx=None (in place): `groups` = list of index tensors, `nongrouped` =
+    index tensor of atoms without bonds; pos [R,N,3], box [R,3,3]."""
+    b = box[:, torch.eye(3).bool()]
+    if torch.all(b == 0):
+        return
+    for group in groups:
+        com = torch.sum(pos[:, group], dim=1) / len(group)
+        offset = torch.floor(com / b) * b
+        pos[:, group] -= offset.unsqueeze(1)
+    if len(nongrouped):
+        offset = torch.floor(pos[:, nongrouped] / b.unsqueeze(1)) * b.unsqueeze(1)
+        pos[:, nongrouped] -= offset

@@ -185,3 +185,49 @@ def test_energy_conservation_and_list_reuse():
     assert drift < 2e-3, (drift, e)  # kcal/mol per atom over 150 fs (reaction-field cutoff noise)
     rebuilds = f.stats(s.pos)["n_rebuilds"] - r0
     assert 1 <= rebuilds <= 60, rebuilds
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_wrapper_vs_oracle(prec):
+    """Molecule wrapping (reference wrapper.py:8-30): waters + a few free ions + one 100-atom chain (the
+    wave-per-group path), 2 replicas, against the oracle's restatement of the Python loop."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box
+    from torchmd_amd.wrapper import Wrapper
+
+    dev, dt = _dev(), PREC[prec]
+    mol, pos, box = tip3p_box(6, seed=9)  # 216 waters
+    nw = mol.numAtoms
+    nion, nchain = 5, 100
+    n = nw + nion + nchain
+    bonds = np.concatenate([mol.bonds, np.stack([nw + nion + np.arange(nchain - 1), nw + nion + np.arange(1, nchain)], 1)])
+    rng = np.random.default_rng(3)
+    extra = rng.uniform(0, box[0], size=(nion + nchain, 3))
+    allpos = np.concatenate([pos, extra])
+    # scatter molecules over several periodic images
+    shift = np.zeros_like(allpos)
+    molshift = rng.integers(-3, 4, size=(nw // 3, 3)) * box
+    shift[:nw] = np.repeat(molshift, 3, axis=0)
+    shift[nw:nw + nion] = rng.integers(-2, 3, size=(nion, 3)) * box
+    shift[nw + nion:] = np.array([2, -1, 1]) * box
+    p = torch.tensor(np.stack([allpos + shift, allpos - 0.37 * shift + 1.234]), dtype=dt)
+    b = box_tensor(box, 2, dt)
+    w = Wrapper(n, bonds, dev)
+    assert w.ngroups == nw // 3 + nion + 1 and w.has_big and len(w.nongrouped) == nion and len(w.groups) == nw // 3 + 1
+    ref = p.clone()
+    orc.wrap_molecules(ref, b, [g.cpu() for g in w.groups], w.nongrouped.cpu())
+    got = p.clone().to(dev)
+    w.wrap(got, b.to(dev))
+    diff = (got.cpu() - ref).abs()
+    tol = 1e-9 if prec == "f64" else 2e-4
+    # a group whose centre sits within rounding of a box face may legitimately land on the other image
+    bad = (diff > tol).any(dim=2).sum().item()
+    assert bad <= 3, bad
+    com_ok = got.cpu()[:, :nw].reshape(2, -1, 3, 3).mean(dim=2)
+    assert (com_ok >= -1e-3).all() and (com_ok <= box[0] + 1e-3).all()
+    # all-zero box and wrapidx are no-ops (reference behaviour)
+    z = p.clone().to(dev)
+    w.wrap(z, torch.zeros(2, 3, 3, dtype=dt, device=dev))
+    assert torch.equal(z.cpu(), p)
+    w.wrap(z, b.to(dev), wrapidx=torch.tensor([0, 1, 2]))
+    assert torch.equal(z.cpu(), p)

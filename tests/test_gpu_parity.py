@@ -274,3 +274,85 @@ def test_errors_and_api_surface():
     d1 = fe.compute(p, b, F1, returnDetails=True)
     assert d1[0]["external"] == 2.5 and abs(d1[0]["lj"] - d0[0]["lj"]) < 1e-6
     assert torch.allclose(F1 - F0, torch.ones_like(F0), atol=1e-5)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_lj_box_vs_oracle(prec):
+    """C5-shaped case at a size the oracle handles: 22^3 = 10 648 argon atoms at liquid density, LJ only,
+    one atom type, cell-list path vs oracle (forces, energy, in-cutoff pair count)."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import argon_forcefield, lj_box
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev, dt = _dev(), PREC[prec]
+    mol, pos, box = lj_box(22, seed=2)
+    par = Parameters(argon_forcefield(mol), mol, ["lj"], precision=dt)
+    p = pos_tensor(pos, 1, dt)
+    pairs = orc.candidate_pairs(pos, box, 9.6, None)
+    po, Fo, npairs = orc.compute(par, p, box_tensor(box, 1, dt), ["lj"], pairs=pairs, cutoff=9.0, switch_dist=7.5)
+    f = Forces(par, terms=["lj"], cutoff=9.0, switch_dist=7.5)
+    F = torch.zeros(1, mol.numAtoms, 3, dtype=dt, device=dev)
+    pots = f.compute(p.to(dev), box_tensor(box, 1, dt, dev), F, returnDetails=True)
+    assert f.stats(p.to(dev))["algorithm"] == "celllist"
+    assert (F.cpu() - Fo).abs().max().item() < FTOL[prec]
+    assert abs(pots[0]["lj"] - po[0]["lj"]) <= ERTOL[prec] * 50 * abs(po[0]["lj"])
+    assert f.count_pairs(p.to(dev), box_tensor(box, 1, dt, dev)) == npairs
+
+
+def test_c3_full_size_vs_oracle():
+    """Config C3 at full size (98 304 atoms, fp32): HIP cell-list path vs the oracle with a sparse
+    candidate list; bar: max |dF| <= 1e-2 kcal/mol/A, identical in-cutoff pair count, sum(F) ~ 0."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev = _dev()
+    mol, pos, box = tip3p_box(32, seed=0)
+    terms = ["lj", "electrostatics"]
+    par = Parameters(water_forcefield(mol), mol, terms + ["bonds", "angles"], precision=torch.float32)
+    p = pos_tensor(pos, 1, torch.float32)
+    f = Forces(par, terms=terms, cutoff=9.0, rfa=True)
+    F = torch.zeros(1, mol.numAtoms, 3, dtype=torch.float32, device=dev)
+    pots = f.compute(p.to(dev), box_tensor(box, 1, torch.float32, dev), F, returnDetails=True)
+    n_gpu = f.count_pairs(p.to(dev), box_tensor(box, 1, torch.float32, dev))
+    assert F.sum(dim=1).abs().max().item() < 0.5  # Newton's third law (fp32 sum over 98k atoms)
+    pairs = orc.candidate_pairs(p[0].double().numpy(), box, 9.5, orc.exclusion_pairs(par))
+    po, Fo, npairs = orc.compute(par, p, box_tensor(box, 1, torch.float32), terms, pairs=pairs, cutoff=9.0, rfa=True)
+    err = (F.cpu() - Fo).abs().max().item()
+    print(f"C3 full size: P_cut = {npairs[0]}, max|dF| = {err:.3e}, E_lj = {pots[0]['lj']:.2f}, E_el = {pots[0]['electrostatics']:.2f}")
+    assert n_gpu == npairs
+    assert err < 1e-2
+    for t in terms:
+        assert abs(pots[0][t] - po[0][t]) < 2e-5 * 50 * abs(po[0][t])
+
+
+def test_lj_million_atoms_properties():
+    """Config C5 size on one GPU (10^6 argon atoms, L = 360.8 A): size-independent checks — sum of forces
+    vanishes, the result is invariant under a rigid translation by a box vector, energy is extensive
+    w.r.t. the 10 648-atom box at the same density, and the list statistics are sane."""
+    from torchmd_amd.builders import argon_forcefield, lj_box
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev = _dev()
+    mol, pos, box = lj_box(100, seed=4)
+    par = Parameters(argon_forcefield(mol), mol, ["lj"], precision=torch.float32)
+    f = Forces(par, terms=["lj"], cutoff=9.0)
+    p = torch.tensor(pos, dtype=torch.float32, device=dev)[None].contiguous()
+    b = box_tensor(box, 1, torch.float32, dev)
+    F = torch.zeros_like(p)
+    e = f.compute(p, b, F)[0]
+    st = f.stats(p)
+    assert st["algorithm"] == "celllist" and st["overflow"] == 0
+    assert abs(st["list_entries"] / 1e6 - 0.0213 * 4.18879 * 1000) < 10  # ~89 neighbours within 10 A (lattice: 82)
+    assert F.sum(dim=1).abs().max().item() < 0.5
+    shift = torch.tensor(box, dtype=torch.float32, device=dev) * torch.tensor([1.0, -1.0, 2.0], device=dev)
+    F2 = torch.zeros_like(p)
+    e2 = f.compute((p + shift).contiguous(), b, F2)[0]
+    assert abs(e2 - e) < 2e-4 * abs(e)
+    assert ((F2 - F).abs() / (1 + F.abs())).max().item() < 2e-2
+    pcut = f.count_pairs(p, b)[0]
+    assert abs(pcut / 1e6 - 0.5 * 0.0213 * 4.18879 * 729) < 6  # ~32.5 pairs/atom within 9 A (SURVEY §8; lattice: 36.8)
+    assert -7.0 < e / 1e6 < -4.0  # cohesive LJ energy per atom at this density, kcal/mol (jittered lattice)

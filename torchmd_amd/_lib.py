@@ -153,6 +153,10 @@ SIGNATURES = {
         C.c_int,
         [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "tmdhip_wrap": (
+        C.c_int,
+        [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
+    ),
     "tmdhip_normal_fill": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
 }
 

@@ -241,3 +241,85 @@ int tmdhip_normal_fill(int dtype, int64_t n, void *out, uint64_t seed, uint64_t 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Molecule wrapping (reference torchmd/wrapper.py:8-30): every bonded group is translated by
+// -floor(com/box)*box, com = unweighted mean of its atoms.  The reference loops over the groups in
+// Python (4 torch ops per molecule: seconds per call at 32 768 waters); here one thread per group
+// computes the offset (members summed in index order -> deterministic) and shifts its atoms.
+// Groups larger than 64 atoms are handled by a whole wave.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <typename R>
+__global__ void wrap_groups_kernel(int64_t natoms, int ngroups, const int *__restrict__ goff,
+                                   const int *__restrict__ gmem, R *__restrict__ pos, const R *__restrict__ box,
+                                   int big_threshold, int big_pass) {
+  // grid.y = replica; small groups: one thread each; big groups: one wave each (second launch)
+  const int r = blockIdx.y;
+  R *p = pos + (size_t)r * natoms * 3;
+  const R bx = box[9 * r + 0], by = box[9 * r + 4], bz = box[9 * r + 8];
+  if (bx == R(0) && by == R(0) && bz == R(0)) return;
+  if (!big_pass) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const int s = goff[g], e = goff[g + 1];
+    if (e - s > big_threshold) return;
+    R sx = 0, sy = 0, sz = 0;
+    for (int k = s; k < e; ++k) {
+      const int a = gmem[k];
+      sx += p[3 * a], sy += p[3 * a + 1], sz += p[3 * a + 2];
+    }
+    const R n = (R)(e - s);
+    const R ox = floor((sx / n) / bx) * bx, oy = floor((sy / n) / by) * by, oz = floor((sz / n) / bz) * bz;
+    for (int k = s; k < e; ++k) {
+      const int a = gmem[k];
+      p[3 * a] -= ox, p[3 * a + 1] -= oy, p[3 * a + 2] -= oz;
+    }
+  } else {
+    const int g = blockIdx.x;
+    const int s = goff[g], e = goff[g + 1];
+    if (e - s <= big_threshold) return;
+    const int lane = threadIdx.x;
+    double sx = 0, sy = 0, sz = 0;
+    for (int k = s + lane; k < e; k += 64) {
+      const int a = gmem[k];
+      sx += (double)p[3 * a], sy += (double)p[3 * a + 1], sz += (double)p[3 * a + 2];
+    }
+    sx = wave_sum(sx), sy = wave_sum(sy), sz = wave_sum(sz);
+    const R n = (R)(e - s);
+    const R ox = floor(((R)sx / n) / bx) * bx, oy = floor(((R)sy / n) / by) * by, oz = floor(((R)sz / n) / bz) * bz;
+    for (int k = s + lane; k < e; k += 64) {
+      const int a = gmem[k];
+      p[3 * a] -= ox, p[3 * a + 1] -= oy, p[3 * a + 2] -= oz;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tmdhip_wrap(int dtype, int64_t nreplicas, int64_t natoms, void *pos, const void *box_dev,
+                           int32_t ngroups, const int32_t *group_offsets_dev, const int32_t *group_members_dev,
+                           int32_t has_big_groups, void *stream) {
+  TMD_TRY(check(dtype, nreplicas, natoms));
+  if (!pos || !box_dev || !group_offsets_dev || !group_members_dev || ngroups <= 0)
+    return fail("tmdhip_wrap: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int BIG = 64;
+  dim3 g1((unsigned)((ngroups + 255) / 256), (unsigned)nreplicas), g2((unsigned)ngroups, (unsigned)nreplicas);
+  if (dtype == TMDHIP_F32) {
+    hipLaunchKernelGGL((wrap_groups_kernel<float>), g1, dim3(256), 0, st, natoms, ngroups, group_offsets_dev,
+                       group_members_dev, (float *)pos, (const float *)box_dev, BIG, 0);
+    if (has_big_groups)
+      hipLaunchKernelGGL((wrap_groups_kernel<float>), g2, dim3(64), 0, st, natoms, ngroups, group_offsets_dev,
+                         group_members_dev, (float *)pos, (const float *)box_dev, BIG, 1);
+  } else {
+    hipLaunchKernelGGL((wrap_groups_kernel<double>), g1, dim3(256), 0, st, natoms, ngroups, group_offsets_dev,
+                       group_members_dev, (double *)pos, (const double *)box_dev, BIG, 0);
+    if (has_big_groups)
+      hipLaunchKernelGGL((wrap_groups_kernel<double>), g2, dim3(64), 0, st, natoms, ngroups, group_offsets_dev,
+                         group_members_dev, (double *)pos, (const double *)box_dev, BIG, 1);
+  }
+  TMD_HIP(hipGetLastError());
+  return 0;
+}

@@ -662,13 +662,16 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   const float two_krf = 2.0f * c.krf;
 
   v2f fx = {0.f, 0.f}, fy = {0.f, 0.f}, fz = {0.f, 0.f};
+  unsigned next[UNROLL];  // index words of the next group, fetched one group ahead of their use
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) next[u] = row[(size_t)u * 64];  // rows are padded: always readable
   for (int kk0 = 0; kk0 < nkk; kk0 += UNROLL) {
     unsigned entry[UNROLL];
     float4 pj[UNROLL];
     float2 ab[UNROLL];
     bool valid[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) entry[u] = row[(size_t)(kk0 + u) * 64];  // rows are padded: always readable
+    for (int u = 0; u < UNROLL; ++u) entry[u] = next[u];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       valid[u] = kk0 + u < myiters;
@@ -677,6 +680,8 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
                           __uint_as_float(raw.w));
       ab[u] = *reinterpret_cast<const float2 *>(tbase + (trow8 + ((entry[u] >> 21) & 0x7F8u)));
     }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) next[u] = row[(size_t)(kk0 + UNROLL + u) * 64];
 #pragma unroll
     for (int u = 0; u < UNROLL; u += 2) {
       const v2f pjx = {pj[u].x, pj[u + 1].x}, pjy = {pj[u].y, pj[u + 1].y}, pjz = {pj[u].z, pj[u + 1].z};
@@ -989,10 +994,10 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   maxn = (maxn + rp.lg.lpa - 1) / rp.lg.lpa * rp.lg.lpa;
   rp.lg.maxn = maxn;
   const size_t groups = (n + rp.lg.apw - 1) / rp.lg.apw;
-  if (groups * maxn * rp.lg.apw + 4 * 64 >= (size_t)1 << 30)
+  if (groups * maxn * rp.lg.apw + 8 * 64 >= (size_t)1 << 30)
     return fail("neighbour list would exceed 2^30 entries per replica (32-bit row offsets)");
-  // + 4 wave-rows of padding: the unrolled pair kernels read up to 3 iterations past a group's rows
-  TMD_TRY(rp.nlist.ensure(sizeof(unsigned) * (groups * maxn * rp.lg.apw + 4 * 64)));
+  // + 8 wave-rows of padding: the unrolled pair kernels read up to 7 iterations past a group's rows
+  TMD_TRY(rp.nlist.ensure(sizeof(unsigned) * (groups * maxn * rp.lg.apw + 8 * 64)));
   return 0;
 }
 
