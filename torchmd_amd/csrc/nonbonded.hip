@@ -160,6 +160,10 @@ __device__ __forceinline__ int cell_coord(R x, const Grid &g, int d) {
   return cidx < 0 ? 0 : (cidx >= nc ? nc - 1 : cidx);
 }
 
+// wave-wide mask of lanes with a <= b (ordered), written straight to an SGPR pair by v_cmp
+__device__ __forceinline__ unsigned long long wave_mask_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5 /* FCMP_OLE */); }
+__device__ __forceinline__ unsigned long long wave_mask_le(double a, double b) { return __builtin_amdgcn_fcmp(a, b, 5 /* FCMP_OLE */); }
+
 // position folded into [0, box) (identity for box edge 0 = open boundary)
 template <typename R>
 __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   constexpr int EXS = 4;
   __shared__ R4 s_rec0[64];
   __shared__ int4 s_rec1[64];
-  __shared__ int s_eb[64], s_more[64];
+  __shared__ int s_eb[64], s_more[64], s_cnt[64];
   const int apw_shift = 6 - lg.lpa_shift;
   const unsigned kmask = (unsigned)lg.lpa - 1u;
   int wmax = 0;
@@ -408,8 +412,10 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     }
     const bool any_long = __ballot(long_rows) != 0ull;
     __syncthreads();
-    int mycnt = 0;  // neighbour count of atom ib + lane
-    int seg = 0;    // segment of this lane's candidate; q grows by 64 per chunk so it only moves forward
+    s_cnt[lane] = 0;  // neighbour count of atom ib + lane (lives in LDS: one broadcast read + one
+                      // same-value write per iteration instead of cross-lane register traffic)
+    __syncthreads();
+    int seg = 0;      // segment of this lane's candidate; q grows by 64 per chunk so it only moves forward
     for (int q0 = 0; q0 < ncand; q0 += 64) {
       const int q = q0 + lane;
       const bool valid = q < ncand;
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       pj.y = wrap_into_box(pj.y, c.box[1], c.invbox[1]) + (R)(((code >> 2) & 3) - 1) * c.box[1];
       pj.z = wrap_into_box(pj.z, c.box[2], c.invbox[2]) + (R)(((code >> 4) & 3) - 1) * c.box[2];
       if (!valid) pj.x = (R)1e18;
-      const int oj = order[j];
+      const unsigned oj = (unsigned)order[j];
       const unsigned entry = (unsigned)j | ((unsigned)stype[j] << 24);
       // LDS byte offset of the current i record, kept in a VGPR on purpose (see above)
       unsigned recoff;
@@ -438,33 +444,37 @@ __global__ __launch_bounds__(64) void build_list_kernel(
                                                      recoff * (unsigned)(sizeof(R4) / 16));
         const R dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         const R r2 = dx * dx + dy * dy + dz * dz;
-        bool hit = r2 <= rlist2;
+        // wave-wide masks (SGPR pairs) instead of per-lane booleans: compares write the masks directly,
+        // they are combined on the scalar unit, and the prefix count is two v_mbcnt
+        unsigned long long mask = wave_mask_le(r2, rlist2);
         // two-level test: exclusions, compaction and the store only run for (i, chunk) combinations
         // with at least one candidate in range (a chunk is ~one z-column of the stencil, so for a
         // given i many chunks are entirely out of reach)
-        if (__ballot(hit) != 0ull) {
+        if (mask != 0ull) {
           const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff);
-          // branch-free "oj is one of ex.*": the smallest xor is 0 exactly when one of them matches
-          const unsigned xm = min(min((unsigned)(ex.x ^ oj), (unsigned)(ex.y ^ oj)),
-                                  min((unsigned)(ex.z ^ oj), (unsigned)(ex.w ^ oj)));
-          hit = hit && (xm != 0u);
+          const int base = s_cnt[t];
+          mask &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) |
+                    __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
+                    __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32) |
+                    __builtin_amdgcn_uicmp((unsigned)ex.w, oj, 32));
           if (any_long) {  // wave-uniform, rare (atoms with more than EXS-1 exclusions: proteins)
             const int more = s_more[t], eb = s_eb[t];
-            for (int e = 0; e < more; ++e) hit = hit && (excl_idx[eb + e] != oj);
+            for (int e = 0; e < more; ++e) mask &= ~__builtin_amdgcn_uicmp((unsigned)excl_idx[eb + e], oj, 32);
           }
-          const unsigned long long mask = __ballot(hit);
-          const int base = __builtin_amdgcn_readlane(mycnt, t);
-          const unsigned k = (unsigned)(base + __popcll(mask & ((1ull << lane) - 1ull)));
-          if (hit && (k < (unsigned)lg.maxn)) {
+          const unsigned k = (unsigned)base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
             unsigned rowoff;
             if constexpr (sizeof(R) == 4) rowoff = __float_as_uint(pi.w);
             else rowoff = (unsigned)__double_as_longlong(pi.w);
             nlist[rowoff + ((k >> lg.lpa_shift) << 6) + (k & kmask)] = entry;
           }
-          mycnt += (lane == t) ? (int)__popcll(mask) : 0;
+          s_cnt[t] = base + (int)__popcll(mask);  // every lane writes the same value
         }
       }
     }
+    __syncthreads();
+    const int mycnt = s_cnt[lane];
     if (lane < ni) nneigh[ib + lane] = min(mycnt, lg.maxn);
     wmax = max(wmax, lane < ni ? mycnt : 0);
   }
