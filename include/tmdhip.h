@@ -157,6 +157,26 @@ int tmdhip_compute_bonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, con
  * grown, the next compute rebuilds, and the caller must repeat the evaluation; negative = error. */
 int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream);
 
+/* `niter` iterations of Integrator.step's loop (integrator.py:115-120) for every replica, enqueued from
+ * C with no per-step host work:  _first_VV -> Forces.compute (bonded + nonbonded) -> langevin -> _second_VV.
+ * Between steps the second half kick of step s-1, the first half step of step s and the neighbour-list
+ * displacement test are ONE fused kernel.  Forces of the previous evaluation must be in forces_dev on
+ * entry (as the reference requires: run.py:261 primes system.forces); on return forces_dev holds the
+ * forces of the last step and velocities have received both half kicks. */
+typedef struct tmdhip_md_desc {
+  int32_t struct_size;
+  int32_t niter;
+  void *pos_dev, *vel_dev, *forces_dev; /* real [R,N,3]                                              */
+  const void *mass_dev;                 /* real [N]                                                  */
+  const void *vcoeff_dev;               /* real [N] = sqrt(2 gamma kB T dt / m), or NULL: no thermostat */
+  const double *box_host;               /* [R*3] box edge lengths                                    */
+  double dt;                            /* time step in internal units (fs / 48.88821)               */
+  double gamma;                         /* friction in internal units                                */
+  uint64_t seed, step0;                 /* noise stream key and position (step0 + iteration)         */
+  double *energies_dev;                 /* [R*TMDHIP_NENERGY]: += energies of the LAST iteration, or NULL */
+} tmdhip_md_desc;
+int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
+
 /* Drop the neighbour list of a replica: the next tmdhip_compute_nonbonded rebuilds it (used after the
  * caller has changed positions out of band, and by the rebuild timing tool). */
 int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica);

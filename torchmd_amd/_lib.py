@@ -91,6 +91,24 @@ class BondedDesc(C.Structure):
     ]
 
 
+class MdDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("niter", C.c_int32),
+        ("pos_dev", C.c_void_p),
+        ("vel_dev", C.c_void_p),
+        ("forces_dev", C.c_void_p),
+        ("mass_dev", C.c_void_p),
+        ("vcoeff_dev", C.c_void_p),
+        ("box_host", C.c_void_p),
+        ("dt", C.c_double),
+        ("gamma", C.c_double),
+        ("seed", C.c_uint64),
+        ("step0", C.c_uint64),
+        ("energies_dev", C.c_void_p),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("n_compute", C.c_int64),
@@ -120,6 +138,7 @@ SIGNATURES = {
         [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     ),
     "tmdhip_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "tmdhip_md_run": (C.c_int, [C.c_void_p, C.POINTER(MdDesc), C.c_void_p]),
     "tmdhip_invalidate_list": (C.c_int, [C.c_void_p, C.c_int]),
     "tmdhip_get_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Stats)]),
     "tmdhip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),

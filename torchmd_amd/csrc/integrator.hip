@@ -11,61 +11,11 @@
 
 #include "common.h"
 #include "pair_math.h"
+#include "rng.h"
 
 using namespace tmd;
 
 namespace {
-
-// ---- Philox4x32-10 (Salmon et al., SC'11) ----------------------------------------------------
-struct Philox {
-  uint32_t c[4];
-};
-__device__ __forceinline__ Philox philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
-  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
-  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return Philox{{c0, c1, c2, c3}};
-}
-
-// three N(0,1) draws for row `row` of step `step` (Box-Muller on 32-bit uniforms in (0,1))
-template <typename R>
-__device__ __forceinline__ void normal3(uint64_t seed, uint64_t step, uint64_t row, R &g0, R &g1, R &g2) {
-  const Philox p = philox4x32_10(row, step, seed);
-  const double inv32 = 2.3283064365386963e-10;  // 2^-32
-  const R u0 = (R)(((double)p.c[0] + 0.5) * inv32);
-  const R u1 = (R)(((double)p.c[1] + 0.5) * inv32);
-  const R u2 = (R)(((double)p.c[2] + 0.5) * inv32);
-  const R u3 = (R)(((double)p.c[3] + 0.5) * inv32);
-  R s0, c0, s1, c1;
-  if constexpr (sizeof(R) == 4) {
-    const float r0 = sqrtf(-2.0f * logf(fminf(u0, 0.99999994f)));
-    const float r1 = sqrtf(-2.0f * logf(fminf(u2, 0.99999994f)));
-    sincospif(2.0f * u1, &s0, &c0);
-    sincospif(2.0f * u3, &s1, &c1);
-    g0 = r0 * c0;
-    g1 = r0 * s0;
-    g2 = r1 * c1;
-  } else {
-    const double r0 = sqrt(-2.0 * log(u0));
-    const double r1 = sqrt(-2.0 * log(u2));
-    sincospi(2.0 * u1, &s0, &c0);
-    sincospi(2.0 * u3, &s1, &c1);
-    g0 = r0 * c0;
-    g1 = r0 * s0;
-    g2 = r1 * c1;
-  }
-}
 
 // integrator.py:61-64
 template <typename R>

@@ -29,6 +29,7 @@
 
 #include "common.h"
 #include "pair_math.h"
+#include "rng.h"
 
 namespace tmd {
 
@@ -736,6 +737,57 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   }
 }
 
+// ---- fused MD-step kernel (integrator.py:61-74 across the step boundary) -----------------------------
+// One launch per replica and step: [Langevin kick + second half kick of step s-1] + [first half step of
+// step s] + [displacement test that drives the device-side list rebuild].  Values are identical to the
+// separate kernels of integrator.hip (same operations on the same registers, no re-association).
+template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
+__global__ void md_step_kernel(int n, R *__restrict__ pos, R *__restrict__ vel, const R *__restrict__ f,
+                               const R *__restrict__ mass, const R *__restrict__ vcoeff, R dt, R half_dt, R gamma,
+                               uint64_t seed, uint64_t noise_step, uint64_t row0, const R *__restrict__ ref,
+                               PairConsts<R> c, R thresh2, int *flags, int parity) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (CHECK && i == 0) flags[parity ^ 1] = 0;
+  if (i >= n) return;
+  const R m = mass[i];
+  R v[3], a[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    v[k] = vel[3 * i + k];
+    a[k] = f[3 * i + k] / m;
+  }
+  if (SECOND) {
+    if (LANGEVIN) {
+      const R vc = vcoeff[i];
+      R g[3];
+      normal3<R>(seed, noise_step, row0 + (uint64_t)i, g[0], g[1], g[2]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] += -gamma * v[k] * dt + g[k] * vc;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] += half_dt * a[k];
+  }
+  if (FIRST) {
+    R p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p[k] = pos[3 * i + k] + (v[k] * dt + R(0.5) * a[k] * dt * dt);
+      v[k] = v[k] + half_dt * a[k];
+      pos[3 * i + k] = p[k];
+    }
+    if (CHECK) {
+      const R dx = min_image(p[0] - ref[3 * i + 0], c.box[0], c.invbox[0]);
+      const R dy = min_image(p[1] - ref[3 * i + 1], c.box[1], c.invbox[1]);
+      const R dz = min_image(p[2] - ref[3 * i + 2], c.box[2], c.invbox[2]);
+      const R d2 = dx * dx + dy * dy + dz * dz;
+      if (!(d2 <= thresh2)) flags[parity] = 1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) vel[3 * i + k] = v[k];
+}
+
 __global__ void halve_count_kernel(unsigned long long *c) { *c >>= 1; }
 
 }  // namespace tmd
@@ -1014,7 +1066,7 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
 // Enqueue: displacement check -> conditional rebuild chain -> gather.  `force` forces a rebuild.
 template <typename R>
 int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force,
-                        hipStream_t st) {
+                        hipStream_t st, bool prechecked = false) {
   using R4 = typename Vec<R>::T4;
   const int n = ctx->d.natoms;
   const int parity = (int)(rp.step & 1);
@@ -1022,8 +1074,9 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
   const int *flag = flags + parity;
   const int nb = (n + 255) / 256;
   const R half_skin = (R)(0.5 * ctx->skin);
-  hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.ref.as<R>(), c,
-                     half_skin * half_skin, flags, parity, force);
+  if (!prechecked)  // (the fused MD-step kernel already ran the displacement test for this parity)
+    hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.ref.as<R>(), c,
+                       half_skin * half_skin, flags, parity, force);
   hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, rp.cell_of.as<int>(),
                      rp.slot.as<int>(), rp.count.as<int>(), flag);
   hipLaunchKernelGGL(scan_cells_kernel, dim3(1), dim3(1024), 0, st, rp.ncell, rp.count.as<int>(),
@@ -1043,6 +1096,8 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
   TMD_HIP(hipGetLastError());
   return 0;
 }
+
+constexpr int kPrechecked = 1 << 16;  // internal compute flag: displacement test already enqueued
 
 template <typename R>
 int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces,
@@ -1090,7 +1145,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     force = 1;
   }
   for (int attempt = 0; attempt < 8; ++attempt) {
-    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st));
+    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked)));
     rp.step++;
     if (!force) break;
     // forced builds are host-visible: size the list from the observed maximum so that later
@@ -1156,6 +1211,85 @@ int upload_params(tmdhip_ctx *ctx) {
   }
   TMD_TRY(ctx->tab.ensure(sizeof(R2) * tab.size()));
   TMD_HIP(hipMemcpy(ctx->tab.p, tab.data(), sizeof(R2) * tab.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace
+
+namespace {
+
+template <typename R, bool SECOND, bool LANGEVIN, bool FIRST>
+void launch_md_step(int n, R *pos, R *vel, const R *f, const R *mass, const R *vcoeff, double dt, double gamma,
+                    uint64_t seed, uint64_t noise_step, uint64_t row0, bool check, const R *ref,
+                    const PairConsts<R> &c, R thresh2, int *flags, int parity, hipStream_t st) {
+  const dim3 grid((n + 255) / 256), block(256);
+  if (check)
+    hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, true>), grid, block, 0, st, n, pos, vel, f, mass,
+                       vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity);
+  else
+    hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, false>), grid, block, 0, st, n, pos, vel, f, mass,
+                       vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity);
+}
+
+template <typename R>
+int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
+  const int n = ctx->d.natoms;
+  const int nrep = (int)ctx->rep.size();
+  const bool langevin = d->vcoeff_dev != nullptr;
+  const bool list = ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0;
+  const R *mass = (const R *)d->mass_dev, *vc = (const R *)d->vcoeff_dev;
+  const R half_skin = (R)(0.5 * ctx->skin);
+  const size_t stride = (size_t)n * 3;
+  for (int it = 0; it <= d->niter; ++it) {
+    const bool first = it < d->niter, second = it > 0;
+    for (int r = 0; r < nrep; ++r) {
+      Replica &rp = ctx->rep[r];
+      const double *box = d->box_host + 3 * r;
+      R *pos = (R *)d->pos_dev + r * stride, *vel = (R *)d->vel_dev + r * stride, *f = (R *)d->forces_dev + r * stride;
+      const PairConsts<R> c = make_consts<R>(ctx, box);
+      // the displacement test can ride on the integrator kernel when a list exists for this box
+      const bool check = first && list && rp.have_list && box[0] == rp.box[0] && box[1] == rp.box[1] && box[2] == rp.box[2];
+      const int parity = (int)(rp.step & 1);
+      const uint64_t noise_step = d->step0 + (uint64_t)(it > 0 ? it - 1 : 0);
+      const uint64_t row0 = (uint64_t)r * (uint64_t)n;
+      const R *ref = rp.ref.as<R>();
+      int *flags = rp.flags.as<int>();
+#define TMD_MD(S, L, F) \
+  launch_md_step<R, S, L, F>(n, pos, vel, f, mass, vc, d->dt, d->gamma, d->seed, noise_step, row0, check, ref, c, \
+                             half_skin * half_skin, flags, parity, st)
+      if (second && first) {
+        if (langevin) TMD_MD(true, true, true);
+        else TMD_MD(true, false, true);
+      } else if (first) {
+        TMD_MD(false, false, true);
+      } else {
+        if (langevin) TMD_MD(true, true, false);
+        else TMD_MD(true, false, false);
+      }
+#undef TMD_MD
+      TMD_HIP(hipGetLastError());
+      if (!first) continue;
+      // forces of step `it` (forces.py:122-319): nonbonded stores (list path) or accumulates into zeros
+      int flags_c = TMDHIP_WANT_FORCES;
+      double *en = nullptr;
+      if (it == d->niter - 1 && d->energies_dev) {
+        flags_c |= TMDHIP_WANT_ENERGY;
+        en = d->energies_dev + (size_t)r * TMDHIP_NENERGY;
+      }
+      if (ctx->d.terms != 0) {
+        rp.n_compute++;
+        if (list) {
+          TMD_TRY(compute_list<R>(ctx, rp, pos, box, f, en, flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0), st));
+        } else {
+          TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride, st));
+          TMD_TRY(launch_allpairs<R>(ctx, pos, box, f, en, flags_c, nullptr, st));
+        }
+      } else {
+        TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride, st));
+      }
+      TMD_TRY(tmdhip_compute_bonded(ctx, r, pos, box, f, en, flags_c, st));
+    }
+  }
   return 0;
 }
 
@@ -1331,6 +1465,17 @@ int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream) {
   rp.box[0] = -1;  // forces the re-plan + rebuild path
   last_error() = "neighbour list overflowed (capacity grown, results since the last check are invalid)";
   return 1;
+}
+
+int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
+  if (!ctx || !desc) return fail("tmdhip_md_run: null argument");
+  if (desc->struct_size != (int32_t)sizeof(tmdhip_md_desc)) return fail("tmdhip_md_run: tmdhip_md_desc size mismatch (ABI)");
+  if (desc->niter < 0) return fail("tmdhip_md_run: niter must be >= 0");
+  if (!desc->pos_dev || !desc->vel_dev || !desc->forces_dev || !desc->mass_dev || !desc->box_host)
+    return fail("tmdhip_md_run: null buffer");
+  if (desc->niter == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  return ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
 }
 
 int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica) {

@@ -464,6 +464,32 @@ class Forces:
                 return ebuf, torch.as_tensor(ext_ene, device=pos.device).detach().to(torch.float64).reshape(-1)
         return (ebuf, None) if want_energy else (None, None)
 
+    def _md_run(self, system, masses, vcoeff, dt, gamma, seed, step0, niter):
+        """Integrator fast path: `niter` MD steps enqueued by one C call; returns the energy buffer of the
+        last step (device, [R, NENERGY])."""
+        pos = system.pos
+        L.require_device_tensor(pos, "systems.pos")
+        if pos.shape[1] != self.natoms:
+            raise RuntimeError(f"systems.pos must have {self.natoms} atoms")
+        eng = self._engine(pos)
+        hbox = self._host_box(system.box)
+        R = pos.shape[0]
+        boxes = np.ascontiguousarray(np.stack([hbox[min(r, len(hbox) - 1)] for r in range(R)]).astype(np.float64))
+        d = L.MdDesc()
+        d.struct_size = C.sizeof(L.MdDesc)
+        d.niter = int(niter)
+        d.pos_dev, d.vel_dev, d.forces_dev = pos.data_ptr(), system.vel.data_ptr(), system.forces.data_ptr()
+        d.mass_dev = masses.data_ptr()
+        d.vcoeff_dev = vcoeff.data_ptr() if vcoeff is not None else None
+        d.box_host = boxes.ctypes.data_as(C.c_void_p)
+        d.dt, d.gamma = float(dt), float(gamma)
+        d.seed, d.step0 = int(seed), int(step0)
+        eng.ebuf.zero_()
+        d.energies_dev = eng.ebuf.data_ptr()
+        stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+        L.check(eng.lib.tmdhip_md_run(eng.ctx, C.byref(d), stream), "tmdhip_md_run")
+        return eng.ebuf
+
     def total_energy_from(self, ebuf, ext):
         cols = [L.ENERGY_SLOT[n] for n in self.energies if n in L.ENERGY_SLOT]
         tot = ebuf[:, cols].sum(dim=1) if cols else torch.zeros(ebuf.shape[0], dtype=torch.float64, device=ebuf.device)

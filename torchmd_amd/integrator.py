@@ -144,8 +144,17 @@ class Integrator:
         fast = isinstance(self.forces, Forces)
         pot = None
         ebuf = ext = None
+        fused = fast and not self.forces.external and niter > 0
         with torch.cuda.device(dev):
-            for it in range(niter):
+            if fused:
+                # whole loop enqueued from C (tmdhip_md_run): fused half-kick/drift/displacement-test
+                # kernels, no Python or ctypes work per step
+                ebuf = self.forces._md_run(
+                    s, self.masses, self.vcoeff if self.T else None, self.dt,
+                    float(self.gamma) if self.T else 0.0, self._seed, self._nstep, niter,
+                )
+                self._nstep += niter
+            for it in range(0 if not fused else niter, niter):
                 st = _stream(dev)
                 L.check(
                     lib.tmdhip_first_vv(code, R, N, s.pos.data_ptr(), s.vel.data_ptr(), s.forces.data_ptr(),
