@@ -118,11 +118,13 @@ def main():
         raise SystemExit("bench.py needs a ROCm device (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torch.distributed.run / torchrun
+    if launched:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # nccl = RCCL on ROCm
     fan = ReplicaFanout(total_replicas=world, device=device)
 
     dtype = torch.float32
@@ -223,9 +225,11 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["ns_per_day_per_replica"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    forces.close()
+    if launched:
         import torch.distributed as dist
 
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

@@ -92,7 +92,7 @@ typedef struct tmdhip_nonbonded_desc {
   double solvent_dielectric;   /* reference default 78.5                                   */
   int32_t switch_mode;         /* TMDHIP_SWITCH_*                                          */
   int32_t algorithm;           /* TMDHIP_ALGO_*                                            */
-  double skin;                 /* Verlet skin in Angstrom; <= 0: library default           */
+  double skin;                 /* Verlet skin in Angstrom; <= 0: library default (1.2)     */
 } tmdhip_nonbonded_desc;
 
 /* Bonded topology (already expanded: one parameter row per instance).  Replaces the per-call

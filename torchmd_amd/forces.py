@@ -260,7 +260,7 @@ class Forces:
         self.solventDielectric = solventDielectric
         self.switch_dist = switch_dist
         self.exclusions = tuple(exclusions)
-        self.skin = skin
+        self.skin = skin  # None -> library default (1.2 A, tools/time_kernels.py sweep)
         self.algorithm = algorithm
         self.switch_mode = switch_mode
         self._excl_csr = build_exclusion_csr(
