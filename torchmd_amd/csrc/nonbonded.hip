@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <type_traits>
@@ -629,7 +630,7 @@ __device__ __forceinline__ v2f min_image2(v2f d, float box, float invbox) {
   return d - p;
 }
 
-template <int LPA>
+template <int LPA, bool LJ, bool ELEC>
 __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
       const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (entry[u] << 4) & 0x0FFFFFF0u, 0, 0);
       pj[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
                           __uint_as_float(raw.w));
-      ab[u] = *reinterpret_cast<const float2 *>(tbase + (trow8 + ((entry[u] >> 21) & 0x7F8u)));
+      if (LJ) ab[u] = *reinterpret_cast<const float2 *>(tbase + (trow8 + ((entry[u] >> 21) & 0x7F8u)));
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) next[u] = row[(size_t)(kk0 + UNROLL + u) * 64];
@@ -706,10 +707,13 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
       const v2f rinv = {__frsqrt_rn(r2s.x), __frsqrt_rn(r2s.y)};
       const v2f rinv2 = rinv * rinv;
       const v2f rinv6 = rinv2 * rinv2 * rinv2;
-      const v2f a12 = {ab[u].x, ab[u + 1].x}, b6 = {ab[u].y, ab[u + 1].y};
-      const v2f qq = piw * pjw;
-      // (dE_lj/dr + dE_rf/dr) / r  with a12 = -12 A, b6 = 6 B
-      v2f fs = __builtin_elementwise_fma(a12, rinv6, b6) * (rinv6 * rinv2) + qq * (two_krf - rinv2 * rinv);
+      // (dE_lj/dr + dE_el/dr) / r  with a12 = -12 A, b6 = 6 B; two_krf = 0 gives plain Coulomb
+      v2f fs = {0.f, 0.f};
+      if (LJ) {
+        const v2f a12 = {ab[u].x, ab[u + 1].x}, b6 = {ab[u].y, ab[u + 1].y};
+        fs = __builtin_elementwise_fma(a12, rinv6, b6) * (rinv6 * rinv2);
+      }
+      if (ELEC) fs += (piw * pjw) * (two_krf - rinv2 * rinv);
       fs = v2f{h0 ? fs.x : 0.0f, h1 ? fs.y : 0.0f};
       fx -= dx * fs;
       fy -= dy * fs;
@@ -911,11 +915,21 @@ PairConsts<R> make_consts(const tmdhip_ctx *ctx, const double *box) {
   return c;
 }
 
-int pick_lpa(int n) {
-  // aim for >= 8192 waves (32 per CU) so list/gather latency is hidden
+int pick_lpa(int n, int capacity) {
+  if (const char *e = std::getenv("TMDHIP_LPA")) {  // tuning override: lanes per atom (power of two, 1..64)
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) return v;
+  }
+  // (1) enough waves to hide list/gather latency: >= 8192 waves (32 per CU)
   int lpa = 1;
   while (lpa < 64 && (int64_t)n * lpa < 8192ll * 64) lpa <<= 1;
-  return lpa;
+  // (2) list length: measured optimum LPA = 8 for water (440 entries per atom; 4 and 16 are 10 % slower)
+  //     and 4 for liquid argon at 10^6 atoms (90 entries per atom; 1: +25 %, 2: +6 %, 8: +13 %);
+  //     capacity = ~1.25 x the expected entries + 32
+  const double per_lane = ((capacity - 32) / 1.25) / 44.0;
+  int by_len = 4;
+  while (by_len < 64 && (double)by_len * 1.4142 < per_lane) by_len <<= 1;
+  return std::max(lpa, by_len);
 }
 
 // choose grid for the current box; returns false if the cell path cannot be used
@@ -988,15 +1002,26 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const int waves = (n + apw - 1) / apw;
   const int blocks = (waves + 3) / 4;
   const size_t shmem = (size_t)ctx->d.ntypes * ctx->d.ntypes * sizeof(R2);
-  const bool fast = !ENERGY && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS) && c.rfa && !c.switch_on;
+  // packed-fp32 kernel covers LJ and/or electrostatics (reaction field or plain Coulomb) without switching
+  const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
+  const bool fast = !ENERGY && only_lj_el && !c.switch_on;
   if constexpr (std::is_same<R, float>::value) {
     // packed-fp32 kernel: needs 32-bit byte offsets into sorted_xyzq and the 7-bit type field
     if (fast && !paircount && f && ctx->d.ntypes <= 128 && n < (1 << 24)) {
       const size_t shfast = shmem + 2048;  // garbage type fields of padding entries stay inside the allocation
-#define TMD_LAUNCH_FAST(L)                                                                                   \
-  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L>), dim3(blocks), dim3(256), shfast, st, n, rp.sorted.as<R4>(), \
-                     rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),                 \
+      const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
+#define TMD_LAUNCH_FAST_T(L, A, B)                                                                                  \
+  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L, A, B>), dim3(blocks), dim3(256), shfast, st, n,                  \
+                     rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
                      rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite)
+#define TMD_LAUNCH_FAST(L)                  \
+  if (lj && el) {                           \
+    TMD_LAUNCH_FAST_T(L, true, true);       \
+  } else if (lj) {                          \
+    TMD_LAUNCH_FAST_T(L, true, false);      \
+  } else {                                  \
+    TMD_LAUNCH_FAST_T(L, false, true);      \
+  }
       switch (rp.lg.lpa) {
         case 1: TMD_LAUNCH_FAST(1); break;
         case 2: TMD_LAUNCH_FAST(2); break;
@@ -1007,6 +1032,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
         default: TMD_LAUNCH_FAST(64); break;
       }
 #undef TMD_LAUNCH_FAST
+#undef TMD_LAUNCH_FAST_T
       TMD_HIP(hipGetLastError());
       return 0;
     }
@@ -1049,7 +1075,7 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.stype.ensure(sizeof(int) * n));
   TMD_TRY(rp.ref.ensure(sizeof(R) * 3 * n));
   TMD_TRY(rp.nneigh.ensure(sizeof(int) * n));
-  rp.lg.lpa = pick_lpa(n);
+  if (rp.lg.maxn == 0 || !rp.have_list) rp.lg.lpa = pick_lpa(n, maxn);  // fixed once a list exists
   rp.lg.apw = 64 / rp.lg.lpa;
   rp.lg.lpa_shift = 0;
   while ((1 << rp.lg.lpa_shift) < rp.lg.lpa) rp.lg.lpa_shift++;
