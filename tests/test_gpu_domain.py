@@ -1,0 +1,76 @@
+"""Spatial domain decomposition (config C5) validated on ONE GPU: all ranks run inside one process
+(`LocalTransport`), forces and a short trajectory must equal the single-domain periodic engine."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(nside, dtype):
+    from torchmd_amd.builders import argon_forcefield, lj_box
+    from torchmd_amd.parameters import Parameters
+
+    mol, pos, box = lj_box(nside, seed=6)
+    par = Parameters(argon_forcefield(mol), mol, ["lj"], precision=dtype)
+    return mol, pos, box, par
+
+
+@pytest.mark.parametrize("world,grid", [(8, None), (4, (2, 1, 2)), (2, None), (1, None)])
+def test_forces_equal_single_domain(world, grid):
+    from torchmd_amd.domain import DomainSet
+    from torchmd_amd.forces import Forces
+
+    dev, dt = torch.device("cuda:0"), torch.float64
+    mol, pos, box, par = _system(22, dt)  # 10 648 atoms, L = 79.3 A
+    rng = np.random.default_rng(0)
+    pos = pos + rng.integers(-1, 2, size=pos.shape) * box  # scatter atoms over periodic images
+    n = mol.numAtoms
+    A, B = par.get_AB()
+    ds = DomainSet(box, world, dev, dt, ["lj"], 9.0, A=A, B=B, skin=1.5, grid=grid)
+    ds.scatter(pos, np.zeros_like(pos), par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
+    assert sum(d.nown for d in ds.domains.values()) == n
+    ds.compute_forces()
+    _, _, F = ds.gather(n)
+    ref = Forces(par, terms=["lj"], cutoff=9.0)
+    p = torch.tensor(pos, dtype=dt, device=dev)[None].contiguous()
+    b = torch.diag(torch.tensor(box, dtype=dt, device=dev))[None].contiguous()
+    Fr = torch.zeros_like(p)
+    ref.compute(p, b, Fr)
+    assert (F - Fr[0]).abs().max().item() < 1e-9
+    halo = [d.local_pos.shape[1] - d.nown for d in ds.domains.values()]
+    assert all(h > 0 for h in halo)
+
+
+def test_trajectory_equal_single_domain():
+    """40 NVE steps (hot start so that atoms migrate between bricks): positions/velocities agree with
+    the single-domain integrator to fp64 round-off."""
+    from torchmd_amd.domain import DomainSet
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.systems import System
+
+    dev, dt = torch.device("cuda:0"), torch.float64
+    mol, pos, box, par = _system(22, dt)
+    n = mol.numAtoms
+    torch.manual_seed(3)
+    vel = maxwell_boltzmann(par.masses, 4000.0, 1)[0].numpy()  # hot: ~0.05 A per step
+    A, B = par.get_AB()
+    ds = DomainSet(box, 8, dev, dt, ["lj"], 9.0, A=A, B=B, skin=1.0)
+    ds.scatter(pos, vel, par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
+    ds.compute_forces()
+    ds.step(40, timestep_fs=2.0)
+    P, V, F = ds.gather(n)
+
+    s = System(n, 1, dt, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    s.set_velocities(torch.tensor(vel)[None])
+    f = Forces(par, terms=["lj"], cutoff=9.0)
+    f.compute(s.pos, s.box, s.forces)
+    Integrator(s, f, 2.0, dev).step(40)
+    assert ds.migrations >= 1
+    assert (P - s.pos[0]).abs().max().item() < 1e-7
+    assert (V - s.vel[0]).abs().max().item() < 1e-7
+    assert (F - s.forces[0]).abs().max().item() < 1e-6

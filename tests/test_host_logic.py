@@ -273,3 +273,63 @@ def test_parameters_match_reference_ala2():
     assert np.array_equal(mine.charges.numpy(), g["par_charges"])
     assert np.array_equal(tio.read_namd_coor(os.path.join(d, "input.coor")), g["pos"])
     assert np.array_equal(tio.read_xsc(os.path.join(d, "input.xsc")), g["box"])
+
+
+_DD_WORKER = r"""
+import os, sys, itertools
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from torchmd_amd.domain import BrickGrid, HaloPlan, DistTransport, factor_grid
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+assert factor_grid(8) == (2, 2, 2) and sorted(factor_grid(4)) == [1, 2, 2] and sorted(factor_grid(2)) == [1, 1, 2]
+box = np.array([30.0, 24.0, 27.0])
+halo = 6.5
+rng = np.random.default_rng(11)
+n = 3000
+pos = torch.tensor(rng.uniform(-40, 70, size=(n, 3)))          # any periodic image
+grid = BrickGrid(box, world)
+owner, w = grid.owner(pos)
+mine = torch.nonzero(owner == rank).flatten()
+plan = HaloPlan(grid, rank, w[mine], halo)
+tr = DistTransport().bind(torch.device("cpu"))
+payload = torch.cat([plan.pack_positions(w[mine]), plan.pack(mine.double()[:, None])], dim=1)
+recv_counts = tr.exchange_counts(plan.send_counts)
+got = tr.all_to_all(payload, plan.send_counts, recv_counts)
+# brute force: every periodic image of every atom inside my brick grown by the halo, minus the brick itself
+lo, hi = grid.bounds(rank)
+exp = []
+for s in itertools.product((-1, 0, 1), repeat=3):
+    img = w + torch.tensor(s, dtype=torch.float64) * torch.tensor(box)
+    inside_ext = ((img >= lo - halo) & (img < hi + halo)).all(dim=1)
+    inside = ((img >= lo) & (img < hi)).all(dim=1)
+    sel = torch.nonzero(inside_ext & ~inside).flatten()
+    exp.append(torch.cat([img[sel], sel.double()[:, None]], dim=1))
+exp = torch.cat(exp)
+key = lambda t: t[np.lexsort((t[:, 2].numpy(), t[:, 1].numpy(), t[:, 0].numpy(), t[:, 3].numpy()))]
+assert got.shape == exp.shape, (got.shape, exp.shape)
+assert torch.allclose(key(got), key(exp), atol=1e-12)
+assert tr.any_true(torch.tensor(rank == world - 1)) and not tr.any_true(torch.tensor(False))
+assert float(tr.sum(torch.tensor([1.0 + rank]))) == world * (world + 1) / 2
+dist.barrier()
+dist.destroy_process_group()
+print("ok", rank, got.shape[0])
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_halo_exchange_gloo(tmp_path, world):
+    """Exchange layer of the domain decomposition over gloo: the halo every rank receives equals the
+    brute-force set of periodic images within `halo` of its brick (26 directed messages, incl. messages
+    to itself across the periodic boundary when a dimension has one brick)."""
+    script = tmp_path / "dd_worker.py"
+    script.write_text(_DD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29580 + world), WORLD_SIZE=str(world))
+    procs = [
+        subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT)
+        for r in range(world)
+    ]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
