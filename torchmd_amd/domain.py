@@ -228,17 +228,23 @@ class Domain:
 
     # -- state ------------------------------------------------------------------------------
     def adopt(self, ids, pos, vel, charges, types, masses):
-        self.ids, self.pos, self.vel = ids, pos.contiguous(), vel.contiguous()
+        """Take ownership of a set of atoms.  Own positions are kept in the WRAPPED frame (the frame the
+        halo images live in) and are integrated in place inside the engine's local position buffer, so
+        a step moves no own-atom data around; `unwrap` restores the caller's periodic image on gather."""
+        self.ids, self.vel = ids, vel.contiguous()
         self.charges, self.types, self.masses = charges.contiguous(), types.contiguous(), masses.contiguous()
         self.nown = len(ids)
-        self.ref = self.pos.clone()
-        _, w = self.grid.owner(self.pos)
+        _, w = self.grid.owner(pos)
+        self.unwrap = (pos - w).contiguous()
+        self._own_init = w.contiguous()
+        self.pos = self._own_init  # re-pointed into local_pos once the halo size is known
+        self.ref = w.clone()
         self.plan = HaloPlan(self.grid, self.rank, w, self.halo)
-        self._unwrap = self.pos - w  # own atoms keep their unwrapped coordinates; halos use wrapped ones
+        self.vcoeff_unit = torch.sqrt(1.0 / self.masses).contiguous()  # x sqrt(2 gamma kB T dt) at run time
 
     def state_rows(self):
         """[n_own, 10] float64 rows for migration: id, pos(3), vel(3), charge, type, mass."""
-        return torch.cat([self.ids.double()[:, None], self.pos.double(), self.vel.double(),
+        return torch.cat([self.ids.double()[:, None], (self.pos + self.unwrap).double(), self.vel.double(),
                           self.charges.double()[:, None], self.types.double()[:, None],
                           self.masses.double()[:, None]], dim=1)
 
@@ -247,15 +253,14 @@ class Domain:
         self.adopt(rows[:, 0].long(), rows[:, 1:4].to(dt), rows[:, 4:7].to(dt), rows[:, 7].to(dt),
                    rows[:, 8].long(), rows[:, 9].to(dt))
 
-    def moved_too_far(self):
+    def max_displacement(self):
         d2 = ((self.pos - self.ref) ** 2).sum(dim=1)
-        return (d2.max() if len(d2) else torch.zeros((), device=self.device)) > (0.5 * self.skin) ** 2
+        return torch.sqrt(d2.max()) if len(d2) else torch.zeros((), dtype=self.dtype, device=self.device)
 
     # -- halo -------------------------------------------------------------------------------
     def halo_payload(self, static: bool):
         """Rows to send: positions (wrapped frame + image shift), plus charge/type on (re)builds."""
-        w = self.pos - self._unwrap
-        p = self.plan.pack_positions(w)
+        p = self.plan.pack_positions(self.pos)
         if not static:
             return p
         extra = torch.stack([self.charges, self.types.to(self.dtype)], dim=1)
@@ -266,8 +271,10 @@ class Domain:
             self.halo_charges = rows[:, 3].contiguous()
             self.halo_types = rows[:, 4].long()
             self._build_engine(rows.shape[0])
-        w = self.pos - self._unwrap
-        self.local_pos = torch.cat([w, rows[:, :3]], dim=0)[None].contiguous()
+            self.local_pos = torch.empty(1, self.nown + rows.shape[0], 3, dtype=self.dtype, device=self.device)
+            self.local_pos[0, : self.nown] = self._own_init
+            self.pos = self.local_pos[0, : self.nown]  # the integrator now updates the engine's buffer in place
+        self.local_pos[0, self.nown:] = rows[:, :3]
 
     def _build_engine(self, nhalo):
         from .forces import Forces
@@ -308,6 +315,8 @@ class DomainSet:
         self.migrations = 0
         self._recv_counts = {}
         self._nstep = 0
+        self._since_migration = 0
+        self.check_every = 4  # steps between migration-trigger collectives
 
     # -- setup: every rank holds the same global arrays and keeps its brick ---------------------
     def scatter(self, pos, vel, charges, types, masses):
@@ -351,6 +360,16 @@ class DomainSet:
             return any(bool(f) for f in flags.values())
         return self.transport.any_true(next(iter(flags.values())))
 
+    def _migration_due(self):
+        """Checked every `check_every` steps (one 4-byte all-reduce + one host read).  A migration is
+        requested early enough that the halo stays complete until the next check: displacement so far
+        plus twice the average growth over `check_every` more steps must stay below skin/2."""
+        self._since_migration += 1
+        if self._since_migration % self.check_every:
+            return False
+        ahead = 1.0 + 2.0 * self.check_every / self._since_migration
+        return self._any({r: d.max_displacement() * ahead > 0.5 * d.skin for r, d in self.domains.items()})
+
     def migrate(self):
         """Re-assign atoms to bricks, rebuild halo plans and engines."""
         payloads, counts = {}, {}
@@ -366,6 +385,7 @@ class DomainSet:
             rows = rows[torch.argsort(rows[:, 0], stable=True)]  # deterministic local order: by global id
             d.from_rows(rows)
         self.migrations += 1
+        self._since_migration = 0
         self._exchange(static=True)
 
     # -- dynamics -------------------------------------------------------------------------------
@@ -387,7 +407,7 @@ class DomainSet:
             for d in self.domains.values():
                 L.check(lib.tmdhip_first_vv(code, 1, d.nown, d.pos.data_ptr(), d.vel.data_ptr(),
                                             d.forces.contiguous().data_ptr(), d.masses.data_ptr(), dt, stream()))
-            if self._any({r: d.moved_too_far() for r, d in self.domains.items()}):
+            if self._migration_due():
                 self.migrate()
             else:
                 self._exchange(static=False)
@@ -395,7 +415,10 @@ class DomainSet:
             for d in self.domains.values():
                 f = d.forces.contiguous()
                 if T:
-                    vc = torch.sqrt(2.0 * gamma / d.masses * BOLTZMAN * T * dt).contiguous()
+                    if getattr(d, "_vc_key", None) != (gamma, T, dt, d.nown, id(d.vcoeff_unit)):
+                        d._vc = (d.vcoeff_unit * float(np.sqrt(2.0 * gamma * BOLTZMAN * T * dt))).contiguous()
+                        d._vc_key = (gamma, T, dt, d.nown, id(d.vcoeff_unit))
+                    vc = d._vc
                     L.check(lib.tmdhip_langevin_second_vv(code, 1, d.nown, d.vel.data_ptr(), f.data_ptr(),
                                                           d.masses.data_ptr(), vc.data_ptr(), dt, gamma,
                                                           seed + 7919 * d.rank, self._nstep, stream()))
@@ -410,5 +433,5 @@ class DomainSet:
         pos = torch.zeros(natoms, 3, dtype=self.dtype, device=self.device)
         vel, frc = torch.zeros_like(pos), torch.zeros_like(pos)
         for d in self.domains.values():
-            pos[d.ids], vel[d.ids], frc[d.ids] = d.pos, d.vel, d.forces
+            pos[d.ids], vel[d.ids], frc[d.ids] = d.pos + d.unwrap, d.vel, d.forces
         return pos, vel, frc
