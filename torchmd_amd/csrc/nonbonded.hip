@@ -623,9 +623,17 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
+// k = round-half-even(d / box) by the magic-number trick: fma(d, 1/box, 1.5*2^23) - 1.5*2^23 is exact
+// round-to-nearest-even for |d/box| < 2^22 and is two packed instructions for two list entries, where
+// v_rndne_f32 has no packed form.  It differs from rndne(fl(d*invbox)) only when d/box lies within one
+// rounding error of a half-integer, i.e. |d| ~ box/2 >= cutoff, where the pair is rejected either way
+// (same argument as for d*invbox vs d/box in pair_math.h).  box*k and d - box*k are rounded separately
+// like the reference's `d - box*round(d/box)`.
 __device__ __forceinline__ v2f min_image2(v2f d, float box, float invbox) {
 #pragma clang fp contract(off)
-  const v2f k = __builtin_elementwise_roundeven(d * invbox);
+  const v2f magic = {12582912.0f, 12582912.0f};
+  const v2f t = __builtin_elementwise_fma(d, v2f{invbox, invbox}, magic);
+  const v2f k = t - magic;
   const v2f p = box * k;
   return d - p;
 }
