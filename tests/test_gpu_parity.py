@@ -356,3 +356,37 @@ def test_lj_million_atoms_properties():
     pcut = f.count_pairs(p, b)[0]
     assert abs(pcut / 1e6 - 0.5 * 0.0213 * 4.18879 * 729) < 6  # ~32.5 pairs/atom within 9 A (lattice: 36.8)
     assert -1.6 < e / 1e6 < -0.6  # cohesive LJ energy per atom (eps = 0.238 kcal/mol, jittered lattice: -1.01)
+
+
+def test_auto_falls_back_to_allpairs_in_small_boxes():
+    """N >= 2048 with a cutoff selects the cell-list path, but with cutoff 10.5 A a 27.9 A box holds fewer than 5 cells of
+    (cutoff + skin)/2 per edge: algorithm='auto' must switch to the all-pairs kernel by itself (also inside
+    the fused Integrator loop) and still match the oracle."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev = _dev()
+    mol, pos, box = tip3p_box(9, seed=8)  # 2 187 atoms, L = 27.95 A
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=torch.float64)
+    f = Forces(par, terms=terms, cutoff=10.5, rfa=True)
+    s = System(mol.numAtoms, 1, torch.float64, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    pots = f.compute(s.pos, s.box, s.forces, returnDetails=True)
+    assert f.stats(s.pos)["algorithm"] == "allpairs"
+    po, Fo, npairs = orc.compute(par, s.pos.cpu(), s.box.cpu(), terms, cutoff=10.5, rfa=True,
+                                 pairs=orc.candidate_pairs(pos, box, 11.0, orc.exclusion_pairs(par)))
+    assert (s.forces.cpu() - Fo).abs().max().item() < 1e-8
+    assert f.count_pairs(s.pos, s.box) == npairs
+    with pytest.raises(RuntimeError):
+        Forces(par, terms=terms, cutoff=10.5, rfa=True, algorithm="celllist").compute(s.pos, s.box, s.forces)
+    # fresh object, first use from inside the fused loop
+    f2 = Forces(par, terms=terms, cutoff=10.5, rfa=True)
+    s.forces.copy_(Fo.to(dev))
+    ek, ep, T = Integrator(s, f2, 0.5, dev).step(3)
+    assert f2.stats(s.pos)["algorithm"] == "allpairs" and np.isfinite(ep).all()

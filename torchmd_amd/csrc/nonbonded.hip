@@ -438,41 +438,56 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       if (!valid) pj.x = (R)1e18;
       const unsigned oj = (unsigned)order[j];
       const unsigned entry = (unsigned)j | ((unsigned)stype[j] << 24);
-      // LDS byte offset of the current i record, kept in a VGPR on purpose (see above)
+      // exclusions, compaction and store of the hits of atom t (mask = lanes whose candidate is in range)
+      auto handle = [&](int t, unsigned roff, const R4 &pi, unsigned long long mask) {
+        const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + roff);
+        const int base = s_cnt[t];
+        // wave-wide masks (SGPR pairs) instead of per-lane booleans: the compares write the masks
+        // directly, they are combined on the scalar unit, and the prefix count is two v_mbcnt
+        mask &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) |
+                  __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
+                  __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32) |
+                  __builtin_amdgcn_uicmp((unsigned)ex.w, oj, 32));
+        if (any_long) {  // wave-uniform, rare (atoms with more than EXS-1 exclusions: proteins)
+          const int more = s_more[t], eb = s_eb[t];
+          for (int e = 0; e < more; ++e) mask &= ~__builtin_amdgcn_uicmp((unsigned)excl_idx[eb + e], oj, 32);
+        }
+        const unsigned k = (unsigned)base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
+          unsigned rowoff;
+          if constexpr (sizeof(R) == 4) rowoff = __float_as_uint(pi.w);
+          else rowoff = (unsigned)__double_as_longlong(pi.w);
+          nlist[rowoff + ((k >> lg.lpa_shift) << 6) + (k & kmask)] = entry;
+        }
+        s_cnt[t] = base + (int)__popcll(mask);  // every lane writes the same value
+      };
+      auto rec0 = [&](unsigned roff) -> R4 {
+        return *reinterpret_cast<const R4 *>(reinterpret_cast<const char *>(s_rec0) + roff * (unsigned)(sizeof(R4) / 16));
+      };
+      auto in_range = [&](const R4 &pi) -> unsigned long long {
+        const R dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        return wave_mask_le(dx * dx + dy * dy + dz * dz, rlist2);
+      };
+      // LDS byte offset of the current i record, kept in a VGPR on purpose (see above).  Two-level test:
+      // the distance masks of four atoms are computed together (independent LDS reads and arithmetic
+      // chains), the expensive part only runs for (atom, chunk) combinations with at least one hit
+      // (a chunk is ~one z-column of the stencil, so for a given atom many chunks are out of reach).
       unsigned recoff;
       asm volatile("v_mov_b32 %0, 0" : "=v"(recoff));
-      for (int t = 0; t < ni; ++t, recoff += 16u) {
-        const R4 pi = *reinterpret_cast<const R4 *>(reinterpret_cast<const char *>(s_rec0) +
-                                                     recoff * (unsigned)(sizeof(R4) / 16));
-        const R dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        const R r2 = dx * dx + dy * dy + dz * dz;
-        // wave-wide masks (SGPR pairs) instead of per-lane booleans: compares write the masks directly,
-        // they are combined on the scalar unit, and the prefix count is two v_mbcnt
-        unsigned long long mask = wave_mask_le(r2, rlist2);
-        // two-level test: exclusions, compaction and the store only run for (i, chunk) combinations
-        // with at least one candidate in range (a chunk is ~one z-column of the stencil, so for a
-        // given i many chunks are entirely out of reach)
-        if (mask != 0ull) {
-          const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff);
-          const int base = s_cnt[t];
-          mask &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) |
-                    __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
-                    __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32) |
-                    __builtin_amdgcn_uicmp((unsigned)ex.w, oj, 32));
-          if (any_long) {  // wave-uniform, rare (atoms with more than EXS-1 exclusions: proteins)
-            const int more = s_more[t], eb = s_eb[t];
-            for (int e = 0; e < more; ++e) mask &= ~__builtin_amdgcn_uicmp((unsigned)excl_idx[eb + e], oj, 32);
-          }
-          const unsigned k = (unsigned)base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-          if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
-            unsigned rowoff;
-            if constexpr (sizeof(R) == 4) rowoff = __float_as_uint(pi.w);
-            else rowoff = (unsigned)__double_as_longlong(pi.w);
-            nlist[rowoff + ((k >> lg.lpa_shift) << 6) + (k & kmask)] = entry;
-          }
-          s_cnt[t] = base + (int)__popcll(mask);  // every lane writes the same value
-        }
+      int t = 0;
+      for (; t + 4 <= ni; t += 4, recoff += 64u) {
+        const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
+        const unsigned long long m0 = in_range(p0), m1 = in_range(p1), m2 = in_range(p2), m3 = in_range(p3);
+        if (m0) handle(t, recoff, p0, m0);
+        if (m1) handle(t + 1, recoff + 16u, p1, m1);
+        if (m2) handle(t + 2, recoff + 32u, p2, m2);
+        if (m3) handle(t + 3, recoff + 48u, p3, m3);
+      }
+      for (; t < ni; ++t, recoff += 16u) {
+        const R4 p0 = rec0(recoff);
+        const unsigned long long m0 = in_range(p0);
+        if (m0) handle(t, recoff, p0, m0);
       }
     }
     __syncthreads();
@@ -981,6 +996,8 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
                     int flags, unsigned long long *paircount, hipStream_t st) {
   const int n = ctx->d.natoms;
   const PairConsts<R> c = make_consts<R>(ctx, box);
+  if ((flags & TMDHIP_OVERWRITE_FORCES) && (flags & TMDHIP_WANT_FORCES))
+    TMD_HIP(hipMemsetAsync(forces, 0, sizeof(R) * 3 * (size_t)n, st));  // partial sums are combined with atomics
   const int nb = (n + 63) / 64;
   int nsplit = std::max(1, std::min(nb, 2048 / std::max(nb, 1)));
   int jchunk = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
@@ -1132,6 +1149,7 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
 }
 
 constexpr int kPrechecked = 1 << 16;  // internal compute flag: displacement test already enqueued
+constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
 
 template <typename R>
 int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces,
@@ -1162,9 +1180,11 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     } else {
       volume = box[0] * box[1] * box[2];
     }
-    if (!plan_grid(ctx, box, lo, hi, rp.grid))
+    if (!plan_grid(ctx, box, lo, hi, rp.grid)) {
+      if (ctx->d.algorithm == TMDHIP_ALGO_AUTO) return kFallbackAllPairs;  // caller switches the context over
       return fail("cell list cannot be used for this box (fewer than 3 cells of cutoff+skin per edge); use "
                   "TMDHIP_ALGO_ALLPAIRS");
+    }
     rp.ncell = rp.grid.nc[0] * rp.grid.nc[1] * rp.grid.nc[2];
     TMD_TRY(rp.count.ensure(sizeof(int) * (size_t)rp.ncell));
     TMD_TRY(rp.cell_start.ensure(sizeof(int) * ((size_t)rp.ncell + 1)));
@@ -1270,7 +1290,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   const int n = ctx->d.natoms;
   const int nrep = (int)ctx->rep.size();
   const bool langevin = d->vcoeff_dev != nullptr;
-  const bool list = ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0;
   const R *mass = (const R *)d->mass_dev, *vc = (const R *)d->vcoeff_dev;
   const R half_skin = (R)(0.5 * ctx->skin);
   const size_t stride = (size_t)n * 3;
@@ -1281,6 +1300,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       const double *box = d->box_host + 3 * r;
       R *pos = (R *)d->pos_dev + r * stride, *vel = (R *)d->vel_dev + r * stride, *f = (R *)d->forces_dev + r * stride;
       const PairConsts<R> c = make_consts<R>(ctx, box);
+      bool list = ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0;
       // the displacement test can ride on the integrator kernel when a list exists for this box
       const bool check = first && list && rp.have_list && box[0] == rp.box[0] && box[1] == rp.box[1] && box[2] == rp.box[2];
       const int parity = (int)(rp.step & 1);
@@ -1313,11 +1333,16 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       if (ctx->d.terms != 0) {
         rp.n_compute++;
         if (list) {
-          TMD_TRY(compute_list<R>(ctx, rp, pos, box, f, en, flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0), st));
-        } else {
-          TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride, st));
-          TMD_TRY(launch_allpairs<R>(ctx, pos, box, f, en, flags_c, nullptr, st));
+          const int rc = compute_list<R>(ctx, rp, pos, box, f, en,
+                                         flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0), st);
+          if (rc == kFallbackAllPairs) {
+            ctx->algorithm = TMDHIP_ALGO_ALLPAIRS;
+            list = false;
+          } else if (rc != 0) {
+            return rc;
+          }
         }
+        if (!list) TMD_TRY(launch_allpairs<R>(ctx, pos, box, f, en, flags_c | TMDHIP_OVERWRITE_FORCES, nullptr, st));
       } else {
         TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride, st));
       }
@@ -1443,8 +1468,10 @@ int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, 
   rp.n_compute++;
   const bool f32 = ctx->d.dtype == TMDHIP_F32;
   if (ctx->algorithm == TMDHIP_ALGO_CELLLIST) {
-    return f32 ? compute_list<float>(ctx, rp, pos_dev, box_host, forces_dev, energies_dev, flags, st)
-               : compute_list<double>(ctx, rp, pos_dev, box_host, forces_dev, energies_dev, flags, st);
+    const int rc = f32 ? compute_list<float>(ctx, rp, pos_dev, box_host, forces_dev, energies_dev, flags, st)
+                       : compute_list<double>(ctx, rp, pos_dev, box_host, forces_dev, energies_dev, flags, st);
+    if (rc != kFallbackAllPairs) return rc;
+    ctx->algorithm = TMDHIP_ALGO_ALLPAIRS;  // AUTO and the box holds fewer than 3 cells per edge
   }
   unsigned long long *pc = nullptr;
   if (flags & TMDHIP_COUNT_PAIRS) {

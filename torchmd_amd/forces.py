@@ -169,9 +169,9 @@ class _Engine:
         self.has_nonbonded = terms != 0
         st = L.Stats()
         L.check(lib.tmdhip_get_stats(self.ctx, 0, C.byref(st)), "tmdhip_get_stats")
-        # the cell-list pair kernel owns every atom exactly once and can *store* its force, which saves
-        # the zero-fill pass; the all-pairs kernel combines j-range partials with atomics and cannot
-        self.stores_forces = self.has_nonbonded and st.algorithm == L.ALGO_CELLLIST
+        # the nonbonded kernels *store* forces when asked to (the cell-list pair kernel owns every atom
+        # exactly once; the all-pairs path zero-fills internally), which saves a zero-fill pass here
+        self.stores_forces = self.has_nonbonded
         self.ebuf = torch.zeros(nreplicas, L.NENERGY, dtype=torch.float64, device=device)
         _LIVE_ENGINES.add(self)
         del keep
