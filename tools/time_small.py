@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Small-system throughput (needs a GPU): the reference's only published number is the tutorial's MD loop
+on alanine dipeptide (688 atoms, fp32, cutoff 9 + switch 7.5 + reaction field, all 7 terms, Langevin 1 fs):
+2.7 ns/day on a CUDA GPU (examples/tutorial.ipynb:737).  Same system and settings here, from
+tests/golden/ala2.npz; also tests/water (291 atoms x 2 replicas, water_conf.yaml settings)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+from _golden import GoldenParameters, load  # noqa: E402
+from torchmd_amd.forces import Forces  # noqa: E402
+from torchmd_amd.integrator import Integrator, maxwell_boltzmann  # noqa: E402
+from torchmd_amd.systems import System  # noqa: E402
+
+
+def run(name, terms, R, steps=4000, **kw):
+    g = load(name)
+    dev = torch.device("cuda:0")
+    par = GoldenParameters(g, torch.float32)
+    n = len(g["pos"])
+    s = System(n, R, torch.float32, dev)
+    s.set_positions(g["pos"][:, :, None])
+    s.set_box(g["box"])
+    torch.manual_seed(1)
+    s.set_velocities(maxwell_boltzmann(par.masses, 300.0, R))
+    f = Forces(par, terms=terms, **kw)
+    f.compute(s.pos, s.box, s.forces)
+    integ = Integrator(s, f, 1.0, dev, gamma=0.1, T=300.0)
+    integ.step(500)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps // 10):
+        ek, ep, T = integ.step(10)  # energies read back every 10 steps like the tutorial's output period
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(f"{name}: {n} atoms x {R} replicas, {el / steps * 1e6:.1f} us/step = {steps / el * 1e-6 * 86400:.0f} ns/day per replica, "
+          f"T={T[0]:.0f} K, Epot={ep[0]:.1f}, algorithm={f.stats(s.pos)['algorithm']}")
+
+
+if __name__ == "__main__":
+    all7 = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+    run("ala2", all7, 1, cutoff=9.0, switch_dist=7.5, rfa=True)
+    run("water291", ["lj", "bonds", "angles", "electrostatics"], 2, cutoff=7.3)

@@ -194,6 +194,18 @@ def load():
         return _lib
     import torch  # noqa: F401  (maps torch's libamdhip64 before ours is resolved)
 
+    if not os.path.exists(LIBPATH) and os.environ.get("TMDHIP_NO_AUTOBUILD") != "1":
+        # a source checkout without the built library: compile it in-tree (hipcc, ~25 s).  This builds
+        # the product; it is not a fallback — without hipcc the error below is raised.
+        try:
+            from . import _build
+
+            _build.build_library()
+        except Exception as exc:  # noqa: BLE001
+            raise RuntimeError(
+                f"{LIBPATH} is missing and could not be built ({exc}). Run `python -m torchmd_amd._build` "
+                "(needs hipcc, cross-compiles for gfx950 without a GPU). torchmd_amd has no CPU or PyTorch fallback."
+            ) from exc
     if not os.path.exists(LIBPATH):
         raise RuntimeError(
             f"{LIBPATH} is missing: the HIP extension has not been built. Run "
