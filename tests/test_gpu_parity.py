@@ -390,3 +390,46 @@ def test_auto_falls_back_to_allpairs_in_small_boxes():
     s.forces.copy_(Fo.to(dev))
     ek, ep, T = Integrator(s, f2, 0.5, dev).step(3)
     assert f2.stats(s.pos)["algorithm"] == "allpairs" and np.isfinite(ep).all()
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize(
+    "terms,kw",
+    [
+        (["lj"], dict(cutoff=9.0)),  # packed kernel, LJ only
+        (["electrostatics"], dict(cutoff=9.0)),  # packed kernel, plain Coulomb
+        (["electrostatics"], dict(cutoff=9.0, rfa=True)),  # packed kernel, reaction field only
+        (["lj", "electrostatics"], dict(cutoff=9.0)),  # packed kernel, LJ + plain Coulomb
+        (["lj", "electrostatics"], dict(cutoff=9.0, rfa=True, switch_dist=7.5)),  # generic kernel (switch)
+        (["repulsion"], dict(cutoff=9.0)),
+        (["repulsioncg", "electrostatics"], dict(cutoff=8.0, rfa=True, solventDielectric=60.0)),
+    ],
+)
+def test_celllist_term_variants_vs_oracle(prec, terms, kw):
+    """Every term combination on the cell-list path (packed fp32 kernel variants and the generic kernel)
+    against the oracle on the 5 184-atom water box: forces, per-term energies, in-cutoff pair count."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev, dt = _dev(), PREC[prec]
+    mol, pos, box = tip3p_box(12, seed=13)
+    par = Parameters(water_forcefield(mol), mol, ["lj", "electrostatics", "bonds", "angles"], precision=dt)
+    p = pos_tensor(pos, 1, dt)
+    okw = dict(kw)
+    pairs = orc.candidate_pairs(pos, box, kw["cutoff"] + 0.6, orc.exclusion_pairs(par))
+    po, Fo, npairs = orc.compute(par, p, box_tensor(box, 1, dt), terms, pairs=pairs, **okw)
+    f = Forces(par, terms=terms, algorithm="celllist", **kw)
+    pd, bd = p.to(dev), box_tensor(box, 1, dt, dev)
+    F = torch.zeros_like(pd)
+    f.compute(pd, bd, F)  # forces-only path first (this is what the packed kernel serves) ...
+    F_noenergy = torch.zeros_like(pd)
+    f._evaluate(pd, bd, F_noenergy, False, True)
+    pots = f.compute(pd, bd, F, returnDetails=True)  # ... then with energies (generic kernel)
+    scale = 1.0 + Fo.abs()
+    assert ((F.cpu() - Fo).abs() / scale).max().item() < (1e-10 if prec == "f64" else 3e-5)
+    assert ((F_noenergy.cpu() - Fo).abs() / scale).max().item() < (1e-10 if prec == "f64" else 3e-5)
+    for t in terms:
+        assert abs(pots[0][t] - po[0][t]) <= ERTOL[prec] * 50 * max(1, abs(po[0][t])), t
+    assert f.count_pairs(pd, bd) == npairs

@@ -1067,8 +1067,10 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,          \
                      ctx->tab.as<R2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
                      overwrite, energies, paircount)
+  // the generic kernel's branch-free FAST=1 body hard-codes LJ + electrostatics (krf = 0: plain Coulomb)
+  const bool fast_generic = fast && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS);
 #define TMD_LAUNCH_LPA(L)     \
-  if (fast) {                 \
+  if (fast_generic) {         \
     TMD_LAUNCH(L, 1);         \
   } else {                    \
     TMD_LAUNCH(L, 0);         \
