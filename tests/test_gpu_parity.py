@@ -433,3 +433,91 @@ def test_celllist_term_variants_vs_oracle(prec, terms, kw):
     for t in terms:
         assert abs(pots[0][t] - po[0][t]) <= ERTOL[prec] * 50 * max(1, abs(po[0][t])), t
     assert f.count_pairs(pd, bd) == npairs
+
+
+@pytest.mark.parametrize("lpa", [1, 2, 4, 16, 32, 64])
+def test_every_lanes_per_atom_variant(lpa, monkeypatch):
+    """The list layout / pair kernels are templated on LPA (lanes per atom); the heuristic picks 4-64
+    depending on N.  Force every instantiation on the same box (fp32 packed kernel and fp64 generic)."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    monkeypatch.setenv("TMDHIP_LPA", str(lpa))
+    dev = _dev()
+    mol, pos, box = tip3p_box(12, seed=17)
+    terms = ["lj", "electrostatics"]
+    for prec in ("f32", "f64"):
+        dt = PREC[prec]
+        par = Parameters(water_forcefield(mol), mol, terms + ["bonds", "angles"], precision=dt)
+        p = pos_tensor(pos, 1, dt)
+        pairs = orc.candidate_pairs(pos, box, 9.6, orc.exclusion_pairs(par))
+        po, Fo, npairs = orc.compute(par, p, box_tensor(box, 1, dt), terms, pairs=pairs, cutoff=9.0, rfa=True)
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        pd, bd = p.to(dev), box_tensor(box, 1, dt, dev)
+        F = torch.zeros_like(pd)
+        f._evaluate(pd, bd, F, False, True)
+        # (one lane summing ~440 fp32 terms sequentially at LPA=1 rounds a little more than 8 lanes x 55)
+        assert ((F.cpu() - Fo).abs() / (1 + Fo.abs())).max().item() < (1e-10 if prec == "f64" else 1e-4), (lpa, prec)
+        e = f.compute(pd, bd, F, returnDetails=True)
+        assert abs(e[0]["lj"] - po[0]["lj"]) <= ERTOL[prec] * 50 * abs(po[0]["lj"])
+        assert f.count_pairs(pd, bd) == npairs
+
+
+def test_box_change_and_capacity_growth():
+    """(a) changing the box between calls re-plans the cell grid; (b) a denser configuration makes a
+    device-side rebuild overflow the list capacity: tmdhip_check reports it, the capacity grows and the
+    evaluation is repeated transparently."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev, dt = _dev(), torch.float64
+    mol, pos, box = tip3p_box(12, seed=19)
+    terms = ["lj", "electrostatics"]
+    par = Parameters(water_forcefield(mol), mol, terms + ["bonds", "angles"], precision=dt)
+
+    def fresh(p, b):
+        F = torch.zeros_like(p)
+        e = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist").compute(p, b, F)
+        return e[0], F
+
+    f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+    p = pos_tensor(pos, 1, dt, dev)
+    b = box_tensor(box, 1, dt, dev)
+    F = torch.zeros_like(p)
+    f.compute(p, b, F)
+    ncell0 = f.stats(p)["ncell"]
+    # (a) isotropic expansion by 30 %: new box tensor values -> new grid, same object
+    p2, b2 = (p * 1.3).contiguous(), box_tensor(box * 1.3, 1, dt, dev)
+    e2 = f.compute(p2, b2, F)[0]
+    er, Fr = fresh(p2, b2)
+    assert f.stats(p)["ncell"] != ncell0
+    assert abs(e2 - er) < 1e-9 * abs(er) and (F - Fr).abs().max().item() < 1e-9
+    # (b) open boundaries: compress the cluster so that neighbour counts exceed the capacity
+    zero = box_tensor(np.zeros(3), 1, dt, dev)
+    g = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+    g.compute(p, zero, F)
+    cap0 = g.stats(p)["max_neighbours"]
+    p3 = (p * 0.7).contiguous()  # density x 2.9 (atoms overlap: forces are huge but well defined)
+    e3 = g.compute(p3, zero, F)[0]
+    assert g.stats(p)["max_neighbours"] > cap0 and g.stats(p)["overflow"] == 0
+    er, Fr = fresh(p3, zero)
+    assert abs(e3 - er) < 1e-9 * abs(er)
+    assert ((F - Fr).abs() / (1 + Fr.abs())).max().item() < 1e-9
+
+
+def test_thrombin_fp32_open_boundaries_packed_kernel():
+    """fp32 packed kernel on a non-periodic system with 15 atom types (LDS table, clamp-to-grid cells)."""
+    g = load("thrombin")
+    par = GoldenParameters(g, torch.float32)
+    zero = np.zeros(3)
+    terms = ["electrostatics", "lj"]
+    kw = dict(cutoff=9.0, rfa=True)
+    _, F_c, fc, p, b = _run(par, g["pos"], zero, terms, prec="f32", algorithm="celllist", **kw)
+    _, F_a, fa, _, _ = _run(par, g["pos"], zero, terms, prec="f32", algorithm="allpairs", **kw)
+    Fn = torch.zeros_like(p)
+    fc._evaluate(p, b, Fn, False, True)  # forces only -> packed kernel
+    assert np.abs(F_c - F_a).max() < 2e-3 and np.abs(Fn.cpu().numpy() - F_a).max() < 2e-3
+    assert fc.count_pairs(p, b) == fa.count_pairs(p, b)
