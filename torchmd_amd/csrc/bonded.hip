@@ -12,6 +12,7 @@
 // Energies are taken from the role-0 evaluation of each term only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -43,6 +44,9 @@ struct DevArr {
   }
 };
 
+// topologies where no atom takes part in more terms than this use the single atom-centric kernel
+constexpr int kAtomCentricLimit = 8;
+
 enum Kind : unsigned { KBOND = 0, KANGLE = 1, KDIHEDRAL = 2, KIMPROPER = 3, KPAIR14 = 4 };
 // entry = kind << 28 | role << 26 | term index (26 bits)
 constexpr unsigned kIdxBits = 26;
@@ -50,6 +54,8 @@ constexpr unsigned kIdxBits = 26;
 struct Bonded {
   int natoms = 0;
   int nentries = 0;
+  int max_entries_per_atom = 0;
+  DevArr entry_f;  // per-entry forces of the two-kernel path (real [3*nentries])
   int dih_amber = 1, imp_amber = 1;
   uint32_t terms14 = 0;
   int bonds_use_cutoff = 0;
@@ -58,7 +64,7 @@ struct Bonded {
   DevArr dih_idx, dih_start, dih_prm, imp_idx, imp_start, imp_prm;
   DevArr p14_idx, p14_prm;
   void release() {
-    for (DevArr *a : {&atom_off, &atom_ent, &bond_idx, &bond_prm, &angle_idx, &angle_prm, &dih_idx, &dih_start,
+    for (DevArr *a : {&entry_f, &atom_off, &atom_ent, &bond_idx, &bond_prm, &angle_idx, &angle_prm, &dih_idx, &dih_start,
                       &dih_prm, &imp_idx, &imp_start, &imp_prm, &p14_idx, &p14_prm})
       a->release();
   }
@@ -256,6 +262,38 @@ __device__ __forceinline__ void wave_energy(double e, double *dst) {
   if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(dst, s);
 }
 
+// force on the atom that entry `ent` stands for (and the term's energy if that atom has role 0)
+template <typename R>
+__device__ __forceinline__ void eval_entry(const BondedArgs<R> &A, const R *__restrict__ pos, unsigned ent, R &fx,
+                                           R &fy, R &fz, double *e) {
+  const unsigned kind = ent >> 28;
+  const int role = (int)((ent >> kIdxBits) & 3u);
+  const int t = (int)(ent & ((1u << kIdxBits) - 1u));
+  if (kind == KBOND) {
+    bond_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_BONDS]);
+  } else if (kind == KANGLE) {
+    angle_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_ANGLES]);
+  } else if (kind == KDIHEDRAL) {
+    torsion_term<R>(A.dih_idx, A.dih_start, A.dih_prm, A.dih_amber, A.b, pos, t, role, fx, fy, fz,
+                    e[TMDHIP_E_DIHEDRALS]);
+  } else if (kind == KIMPROPER) {
+    torsion_term<R>(A.imp_idx, A.imp_start, A.imp_prm, A.imp_amber, A.b, pos, t, role, fx, fy, fz,
+                    e[TMDHIP_E_IMPROPERS]);
+  } else {
+    pair14_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_LJ], e[TMDHIP_E_ELECTROSTATICS]);
+  }
+}
+
+__device__ __forceinline__ void flush_energies(const double *e, double *energies) {
+  wave_energy(e[TMDHIP_E_BONDS], energies + TMDHIP_E_BONDS);
+  wave_energy(e[TMDHIP_E_ANGLES], energies + TMDHIP_E_ANGLES);
+  wave_energy(e[TMDHIP_E_DIHEDRALS], energies + TMDHIP_E_DIHEDRALS);
+  wave_energy(e[TMDHIP_E_IMPROPERS], energies + TMDHIP_E_IMPROPERS);
+  wave_energy(e[TMDHIP_E_LJ], energies + TMDHIP_E_LJ);
+  wave_energy(e[TMDHIP_E_ELECTROSTATICS], energies + TMDHIP_E_ELECTROSTATICS);
+}
+
+// (1) light topologies (every atom in a handful of terms: water, ions): thread = atom, one launch
 template <typename R>
 __global__ __launch_bounds__(256) void bonded_atom_kernel(int natoms, BondedArgs<R> A, const R *__restrict__ pos,
                                                           R *__restrict__ forces, double *__restrict__ energies,
@@ -264,39 +302,51 @@ __global__ __launch_bounds__(256) void bonded_atom_kernel(int natoms, BondedArgs
   R fx = 0, fy = 0, fz = 0;
   double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (a < natoms) {
-    for (int q = A.atom_off[a], qe = A.atom_off[a + 1]; q < qe; ++q) {
-      const unsigned ent = (unsigned)A.atom_ent[q];
-      const unsigned kind = ent >> 28;
-      const int role = (int)((ent >> kIdxBits) & 3u);
-      const int t = (int)(ent & ((1u << kIdxBits) - 1u));
-      if (kind == KBOND) {
-        bond_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_BONDS]);
-      } else if (kind == KANGLE) {
-        angle_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_ANGLES]);
-      } else if (kind == KDIHEDRAL) {
-        torsion_term<R>(A.dih_idx, A.dih_start, A.dih_prm, A.dih_amber, A.b, pos, t, role, fx, fy, fz,
-                        e[TMDHIP_E_DIHEDRALS]);
-      } else if (kind == KIMPROPER) {
-        torsion_term<R>(A.imp_idx, A.imp_start, A.imp_prm, A.imp_amber, A.b, pos, t, role, fx, fy, fz,
-                        e[TMDHIP_E_IMPROPERS]);
-      } else {
-        pair14_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_LJ], e[TMDHIP_E_ELECTROSTATICS]);
-      }
-    }
+    for (int q = A.atom_off[a], qe = A.atom_off[a + 1]; q < qe; ++q)
+      eval_entry<R>(A, pos, (unsigned)A.atom_ent[q], fx, fy, fz, e);
     if (forces) {
       forces[3 * a + 0] += fx;
       forces[3 * a + 1] += fy;
       forces[3 * a + 2] += fz;
     }
   }
-  if (want_e) {
-    wave_energy(e[TMDHIP_E_BONDS], energies + TMDHIP_E_BONDS);
-    wave_energy(e[TMDHIP_E_ANGLES], energies + TMDHIP_E_ANGLES);
-    wave_energy(e[TMDHIP_E_DIHEDRALS], energies + TMDHIP_E_DIHEDRALS);
-    wave_energy(e[TMDHIP_E_IMPROPERS], energies + TMDHIP_E_IMPROPERS);
-    wave_energy(e[TMDHIP_E_LJ], energies + TMDHIP_E_LJ);
-    wave_energy(e[TMDHIP_E_ELECTROSTATICS], energies + TMDHIP_E_ELECTROSTATICS);
+  if (want_e) flush_energies(e, energies);
+}
+
+// (2) heavy topologies (proteins: an atom sits in dozens of torsions; one thread walking them is a chain
+// of dependent global loads, measured 102 us for alanine dipeptide's 688 atoms): thread = (atom, term)
+// entry writes its force to a per-entry buffer, then thread = atom sums its contiguous entries.
+// Still no atomics and a fixed summation order.
+template <typename R>
+__global__ __launch_bounds__(256) void bonded_entry_kernel(int nentries, BondedArgs<R> A, const R *__restrict__ pos,
+                                                           R *__restrict__ entry_f, double *__restrict__ energies,
+                                                           int want_e) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (q < nentries) {
+    R fx = 0, fy = 0, fz = 0;
+    eval_entry<R>(A, pos, (unsigned)A.atom_ent[q], fx, fy, fz, e);
+    entry_f[3 * q + 0] = fx;
+    entry_f[3 * q + 1] = fy;
+    entry_f[3 * q + 2] = fz;
   }
+  if (want_e) flush_energies(e, energies);
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void bonded_sum_kernel(int natoms, const int *__restrict__ atom_off,
+                                                         const R *__restrict__ entry_f, R *__restrict__ forces) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= natoms) return;
+  R fx = 0, fy = 0, fz = 0;
+  for (int q = atom_off[a], qe = atom_off[a + 1]; q < qe; ++q) {
+    fx += entry_f[3 * q + 0];
+    fy += entry_f[3 * q + 1];
+    fz += entry_f[3 * q + 2];
+  }
+  forces[3 * a + 0] += fx;
+  forces[3 * a + 1] += fy;
+  forces[3 * a + 2] += fz;
 }
 
 template <typename R>
@@ -402,6 +452,11 @@ int set_bonded(tmdhip_ctx *ctx, Bonded *b, const tmdhip_bonded_desc *d) {
   std::vector<int> ent((size_t)off[n] + 1);
   for (int a = 0; a < n; ++a) std::copy(per_atom[a].begin(), per_atom[a].end(), ent.begin() + off[a]);
   b->nentries = off[n];
+  for (int a = 0; a < n; ++a) b->max_entries_per_atom = std::max(b->max_entries_per_atom, off[a + 1] - off[a]);
+  if (b->max_entries_per_atom > kAtomCentricLimit) {
+    std::vector<R> zeros((size_t)3 * off[n], R(0));
+    TMD_TRY(b->entry_f.upload(zeros.data(), zeros.size()));
+  }
   TMD_TRY(b->atom_off.upload(off.data(), off.size()));
   TMD_TRY(b->atom_ent.upload(ent.data(), ent.size()));
   b->terms14 = d->terms14;
@@ -451,8 +506,17 @@ int run_bonded(tmdhip_ctx *ctx, const Bonded *b, const void *pos_v, const double
   R *forces = (flags & TMDHIP_WANT_FORCES) ? (R *)forces_v : nullptr;
   const int we = (flags & TMDHIP_WANT_ENERGY) ? 1 : 0;
   const int n = b->natoms;
-  hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, A, (const R *)pos_v, forces,
-                     en, we);
+  if (b->max_entries_per_atom <= kAtomCentricLimit) {
+    hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, A, (const R *)pos_v,
+                       forces, en, we);
+  } else {
+    const int ne = b->nentries;
+    hipLaunchKernelGGL((bonded_entry_kernel<R>), dim3((ne + 255) / 256), dim3(256), 0, st, ne, A, (const R *)pos_v,
+                       b->entry_f.as<R>(), en, we);
+    if (forces)
+      hipLaunchKernelGGL((bonded_sum_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, b->atom_off.as<int>(),
+                         b->entry_f.as<R>(), forces);
+  }
   TMD_HIP(hipGetLastError());
   return 0;
 }

@@ -999,8 +999,10 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
   if ((flags & TMDHIP_OVERWRITE_FORCES) && (flags & TMDHIP_WANT_FORCES))
     TMD_HIP(hipMemsetAsync(forces, 0, sizeof(R) * 3 * (size_t)n, st));  // partial sums are combined with atomics
   const int nb = (n + 63) / 64;
-  int nsplit = std::max(1, std::min(nb, 2048 / std::max(nb, 1)));
-  int jchunk = ((n + nsplit - 1) / nsplit + 63) / 64 * 64;
+  // split the j range so that ~1024 waves are in flight even for a few hundred atoms (each block then
+  // walks a short j range; the partial forces are combined with one atomic per atom and split)
+  int nsplit = std::max(1, std::min((n + 15) / 16, 1024 / std::max(nb, 1)));
+  int jchunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
   nsplit = (n + jchunk - 1) / jchunk;
   dim3 grid(nb, nsplit);
   R *f = (flags & TMDHIP_WANT_FORCES) ? (R *)forces : nullptr;
