@@ -259,7 +259,7 @@ __device__ __forceinline__ void pair14_term(const BondedArgs<R> &A, const R *__r
 
 __device__ __forceinline__ void wave_energy(double e, double *dst) {
   const double s = wave_sum(e);
-  if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(dst, s);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(dst, s);  // dst: this wave's scratch row
 }
 
 // force on the atom that entry `ent` stands for (and the term's energy if that atom has role 0)
@@ -284,7 +284,8 @@ __device__ __forceinline__ void eval_entry(const BondedArgs<R> &A, const R *__re
   }
 }
 
-__device__ __forceinline__ void flush_energies(const double *e, double *energies) {
+__device__ __forceinline__ void flush_energies(const double *e, double *scratch) {
+  double *energies = energy_row(scratch);
   wave_energy(e[TMDHIP_E_BONDS], energies + TMDHIP_E_BONDS);
   wave_energy(e[TMDHIP_E_ANGLES], energies + TMDHIP_E_ANGLES);
   wave_energy(e[TMDHIP_E_DIHEDRALS], energies + TMDHIP_E_DIHEDRALS);
@@ -377,6 +378,8 @@ void *&ctx_bonded_slot(tmdhip_ctx *ctx);
 const tmdhip_nonbonded_desc &ctx_desc(const tmdhip_ctx *ctx);
 const void *ctx_scaled_charges(const tmdhip_ctx *ctx);
 int ctx_nreplicas(const tmdhip_ctx *ctx);
+double *ctx_energy_scratch(const tmdhip_ctx *ctx);
+int fold_energies(tmdhip_ctx *ctx, double *energies, hipStream_t st);
 
 void bonded_release(tmdhip_ctx *ctx) {
   Bonded *b = (Bonded *)ctx_bonded_slot(ctx);
@@ -508,16 +511,17 @@ int run_bonded(tmdhip_ctx *ctx, const Bonded *b, const void *pos_v, const double
   const int n = b->natoms;
   if (b->max_entries_per_atom <= kAtomCentricLimit) {
     hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, A, (const R *)pos_v,
-                       forces, en, we);
+                       forces, ctx_energy_scratch(ctx), we);
   } else {
     const int ne = b->nentries;
     hipLaunchKernelGGL((bonded_entry_kernel<R>), dim3((ne + 255) / 256), dim3(256), 0, st, ne, A, (const R *)pos_v,
-                       b->entry_f.as<R>(), en, we);
+                       b->entry_f.as<R>(), ctx_energy_scratch(ctx), we);
     if (forces)
       hipLaunchKernelGGL((bonded_sum_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, b->atom_off.as<int>(),
                          b->entry_f.as<R>(), forces);
   }
   TMD_HIP(hipGetLastError());
+  if (we) TMD_TRY(fold_energies(ctx, en, st));
   return 0;
 }
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void allpairs_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const double s = wave_sum((double)en[t]);
-      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energies[t], 0.5 * s);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[t], 0.5 * s);
     }
   }
   if (paircount) {
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const double s = wave_sum((double)en[t]);
-      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energies[t], 0.5 * s);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[t], 0.5 * s);
     }
   }
   if (paircount) {
@@ -653,11 +653,12 @@ __device__ __forceinline__ v2f min_image2(v2f d, float box, float invbox) {
   return d - p;
 }
 
-template <int LPA, bool LJ, bool ELEC>
+template <int LPA, bool LJ, bool ELEC, bool ENERGY>
 __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
-    const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite) {
+    const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
+    double *__restrict__ energies) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -697,6 +698,7 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   const float two_krf = 2.0f * c.krf;
 
   v2f fx = {0.f, 0.f}, fy = {0.f, 0.f}, fz = {0.f, 0.f};
+  v2f e_lj = {0.f, 0.f}, e_el = {0.f, 0.f};  // per-lane fp32 partial sums (~55 pairs), reduced in fp64
   unsigned next[UNROLL];  // index words of the next group, fetched one group ahead of their use
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) next[u] = row[(size_t)u * 64];  // rows are padded: always readable
@@ -737,6 +739,14 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
         fs = __builtin_elementwise_fma(a12, rinv6, b6) * (rinv6 * rinv2);
       }
       if (ELEC) fs += (piw * pjw) * (two_krf - rinv2 * rinv);
+      if (ENERGY) {
+        const v2f hm = {h0 ? 1.0f : 0.0f, h1 ? 1.0f : 0.0f};
+        if (LJ) {  // E = (A r^-6 - B) r^-6 with the table holding (-12 A, 6 B)
+          const v2f a12 = {ab[u].x, ab[u + 1].x}, b6 = {ab[u].y, ab[u + 1].y};
+          e_lj += hm * ((a12 * (-1.0f / 12.0f)) * rinv6 - b6 * (1.0f / 6.0f)) * rinv6;
+        }
+        if (ELEC) e_el += hm * (piw * pjw) * (rinv + c.krf * r2s - c.crf);  // krf = crf = 0: plain Coulomb
+      }
       fs = v2f{h0 ? fs.x : 0.0f, h1 ? fs.y : 0.0f};
       fx -= dx * fs;
       fy -= dy * fs;
@@ -760,6 +770,16 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
       forces[3 * oi + 0] += sx;
       forces[3 * oi + 1] += sy;
       forces[3 * oi + 2] += sz;
+    }
+  }
+  if (ENERGY) {  // every pair is listed from both atoms: half of the sum
+    if (LJ) {
+      const double s = wave_sum((double)e_lj.x + (double)e_lj.y);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_LJ], 0.5 * s);
+    }
+    if (ELEC) {
+      const double s = wave_sum((double)e_el.x + (double)e_el.y);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_ELECTROSTATICS], 0.5 * s);
     }
   }
 }
@@ -877,6 +897,7 @@ struct tmdhip_ctx {
   double skin = 1.0;
   double rlist = 0;
   DevBuf types, qs, tab, excl_off, excl_idx;
+  DevBuf escratch;  // kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
   int max_excl = 0;
   std::vector<Replica> rep;
   // bonded part lives in bonded.hip
@@ -895,6 +916,12 @@ void *&ctx_bonded_slot(tmdhip_ctx *ctx) { return ctx->bonded; }
 const tmdhip_nonbonded_desc &ctx_desc(const tmdhip_ctx *ctx) { return ctx->d; }
 const void *ctx_scaled_charges(const tmdhip_ctx *ctx) { return ctx->qs.p; }
 int ctx_nreplicas(const tmdhip_ctx *ctx) { return (int)ctx->rep.size(); }
+double *ctx_energy_scratch(const tmdhip_ctx *ctx) { return ctx->escratch.as<double>(); }
+int fold_energies(tmdhip_ctx *ctx, double *energies, hipStream_t st) {
+  hipLaunchKernelGGL(energy_fold_kernel, dim3(1), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), energies);
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
 }  // namespace tmd
 
 namespace {
@@ -1010,12 +1037,14 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
   if (flags & TMDHIP_WANT_ENERGY)
     hipLaunchKernelGGL((allpairs_kernel<R, true>), grid, dim3(64), 0, st, n, (const R *)pos,
                        ctx->qs.as<R>(), ctx->types.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),
-                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, energies, paircount);
+                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, ctx->escratch.as<double>(),
+                       paircount);
   else
     hipLaunchKernelGGL((allpairs_kernel<R, false>), grid, dim3(64), 0, st, n, (const R *)pos,
                        ctx->qs.as<R>(), ctx->types.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),
-                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, energies, paircount);
+                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, nullptr, paircount);
   TMD_HIP(hipGetLastError());
+  if (flags & TMDHIP_WANT_ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st));
   return 0;
 }
 
@@ -1031,16 +1060,17 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const size_t shmem = (size_t)ctx->d.ntypes * ctx->d.ntypes * sizeof(R2);
   // packed-fp32 kernel covers LJ and/or electrostatics (reaction field or plain Coulomb) without switching
   const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
-  const bool fast = !ENERGY && only_lj_el && !c.switch_on;
+  const bool fast = only_lj_el && !c.switch_on;
   if constexpr (std::is_same<R, float>::value) {
     // packed-fp32 kernel: needs 32-bit byte offsets into sorted_xyzq and the 7-bit type field
-    if (fast && !paircount && f && ctx->d.ntypes <= 128 && n < (1 << 24)) {
+    if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= 128 && n < (1 << 24)) {
       const size_t shfast = shmem + 2048;  // garbage type fields of padding entries stay inside the allocation
       const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
 #define TMD_LAUNCH_FAST_T(L, A, B)                                                                                  \
-  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L, A, B>), dim3(blocks), dim3(256), shfast, st, n,                  \
+  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L, A, B, ENERGY>), dim3(blocks), dim3(256), shfast, st, n,          \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
-                     rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite)
+                     rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,                   \
+                     ctx->escratch.as<double>())
 #define TMD_LAUNCH_FAST(L)                  \
   if (lj && el) {                           \
     TMD_LAUNCH_FAST_T(L, true, true);       \
@@ -1061,6 +1091,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
 #undef TMD_LAUNCH_FAST
 #undef TMD_LAUNCH_FAST_T
       TMD_HIP(hipGetLastError());
+      if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st));
       return 0;
     }
   }
@@ -1068,9 +1099,9 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   hipLaunchKernelGGL((list_pair_kernel<R, ENERGY, L, F>), dim3(blocks), dim3(256), shmem, st, n,        \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,          \
                      ctx->tab.as<R2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
-                     overwrite, energies, paircount)
+                     overwrite, ctx->escratch.as<double>(), paircount)
   // the generic kernel's branch-free FAST=1 body hard-codes LJ + electrostatics (krf = 0: plain Coulomb)
-  const bool fast_generic = fast && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS);
+  const bool fast_generic = fast && !ENERGY && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS);
 #define TMD_LAUNCH_LPA(L)     \
   if (fast_generic) {         \
     TMD_LAUNCH(L, 1);         \
@@ -1089,6 +1120,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
 #undef TMD_LAUNCH_LPA
 #undef TMD_LAUNCH
   TMD_HIP(hipGetLastError());
+  if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st));
   return 0;
 }
 
@@ -1433,6 +1465,8 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
     if (tabbytes > 64 * 1024) return cleanup(fail("tmdhip_create: LJ table does not fit in LDS (too many atom types)"));
   }
   ctx->algorithm = algo;
+  if (ctx->escratch.ensure(sizeof(double) * kEnergySlots * kEnergyStride)) return cleanup(-1);
+  (void)hipMemset(ctx->escratch.p, 0, sizeof(double) * kEnergySlots * kEnergyStride);
   ctx->rep.resize(desc->nreplicas);
   for (auto &rp : ctx->rep) {
     if (rp.flags.ensure(sizeof(int) * 4)) return cleanup(-1);
@@ -1451,7 +1485,7 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
 void tmdhip_destroy(tmdhip_ctx *ctx) {
   if (!ctx) return;
   for (auto &rp : ctx->rep) rp.release();
-  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx}) b->release();
+  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->escratch}) b->release();
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
