@@ -244,10 +244,16 @@ __global__ void fill_cells_kernel(int n, const int *__restrict__ cell_of, const 
   order_tmp[cell_start[cell_of[i]] + slot[i]] = i;
 }
 
-// deterministic order inside a cell: rank by original index
-__global__ void sort_in_cell_kernel(int n, const int *__restrict__ cell_of, const int *__restrict__ cell_start,
-                                    const int *__restrict__ order_tmp, int *__restrict__ order,
-                                    const int *flag) {
+// deterministic order inside a cell (rank by original index) and, with the final position known, the
+// cell-sorted copies the pair kernel reads: {x, y, z, q*sqrt(k)}, type, inverse permutation, and the
+// reference positions of the displacement test
+template <typename R>
+__global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, const int *__restrict__ cell_start,
+                                    const int *__restrict__ order_tmp, const R *__restrict__ pos,
+                                    const R *__restrict__ qs, const int *__restrict__ types,
+                                    int *__restrict__ order, int *__restrict__ inv,
+                                    typename Vec<R>::T4 *__restrict__ sorted, int *__restrict__ stype,
+                                    R *__restrict__ ref, const int *flag) {
   if (*flag == 0) return;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
@@ -256,31 +262,33 @@ __global__ void sort_in_cell_kernel(int n, const int *__restrict__ cell_of, cons
   const int s = cell_start[cidx], e = cell_start[cidx + 1];
   int rank = 0;
   for (int k = s; k < e; ++k) rank += order_tmp[k] < me;
-  order[s + rank] = me;
+  const int dst = s + rank;
+  order[dst] = me;
+  inv[me] = dst;
+  typename Vec<R>::T4 v;
+  v.x = pos[3 * me + 0];
+  v.y = pos[3 * me + 1];
+  v.z = pos[3 * me + 2];
+  v.w = qs[me];
+  sorted[dst] = v;
+  stype[dst] = types[me];
+  ref[3 * me + 0] = v.x;
+  ref[3 * me + 1] = v.y;
+  ref[3 * me + 2] = v.z;
 }
 
-// every step: refresh the cell-sorted coordinate copy; on rebuild steps also types and the
-// reference positions of the displacement test
+// refresh of the cell-sorted coordinate copy for callers that hand in arbitrary new positions
+// (tmdhip_compute_nonbonded); the MD loop's integrator kernel writes the copy itself
 template <typename R>
-__global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const R *__restrict__ qs,
-                                     const int *__restrict__ types, const int *__restrict__ order,
-                                     typename Vec<R>::T4 *__restrict__ sorted, int *__restrict__ stype,
-                                     R *__restrict__ ref, const int *flag) {
+__global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const int *__restrict__ order,
+                                     typename Vec<R>::T4 *__restrict__ sorted, const int *flag) {
+  if (*flag) return;  // place_sorted_kernel has just written everything
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
   const int i = order[a];
-  typename Vec<R>::T4 v;
-  v.x = pos[3 * i + 0];
-  v.y = pos[3 * i + 1];
-  v.z = pos[3 * i + 2];
-  v.w = qs[i];
-  sorted[a] = v;
-  if (*flag) {
-    stype[a] = types[i];
-    ref[3 * i + 0] = v.x;
-    ref[3 * i + 1] = v.y;
-    ref[3 * i + 2] = v.z;
-  }
+  sorted[a].x = pos[3 * i + 0];
+  sorted[a].y = pos[3 * i + 1];
+  sorted[a].z = pos[3 * i + 2];
 }
 
 struct ListGeom {
@@ -642,15 +650,14 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // round-to-nearest-even for |d/box| < 2^22 and is two packed instructions for two list entries, where
 // v_rndne_f32 has no packed form.  It differs from rndne(fl(d*invbox)) only when d/box lies within one
 // rounding error of a half-integer, i.e. |d| ~ box/2 >= cutoff, where the pair is rejected either way
-// (same argument as for d*invbox vs d/box in pair_math.h).  box*k and d - box*k are rounded separately
-// like the reference's `d - box*round(d/box)`.
+// (same argument as for d*invbox vs d/box in pair_math.h).  k is -1, 0 or 1 for every listed pair, so
+// box*k is exact and the fused d - box*k equals the reference's separately rounded `d - box*round(d/box)`.
 __device__ __forceinline__ v2f min_image2(v2f d, float box, float invbox) {
 #pragma clang fp contract(off)
   const v2f magic = {12582912.0f, 12582912.0f};
   const v2f t = __builtin_elementwise_fma(d, v2f{invbox, invbox}, magic);
   const v2f k = t - magic;
-  const v2f p = box * k;
-  return d - p;
+  return __builtin_elementwise_fma(-k, v2f{box, box}, d);
 }
 
 template <int LPA, bool LJ, bool ELEC, bool ENERGY>
@@ -728,7 +735,8 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
       const v2f dz = min_image2(piz - pjz, c.box[2], c.invbox[2]);
       const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
       const bool h0 = valid[u] && (r2.x <= c.r2max), h1 = valid[u + 1] && (r2.y <= c.r2max);
-      const v2f r2s = {h0 ? r2.x : 1.0f, h1 ? r2.y : 1.0f};
+      // forces only: rejected entries may produce inf/NaN below, the final select discards them
+      const v2f r2s = ENERGY ? v2f{h0 ? r2.x : 1.0f, h1 ? r2.y : 1.0f} : r2;
       const v2f rinv = {__frsqrt_rn(r2s.x), __frsqrt_rn(r2s.y)};
       const v2f rinv2 = rinv * rinv;
       const v2f rinv6 = rinv2 * rinv2 * rinv2;
@@ -792,7 +800,9 @@ template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
 __global__ void md_step_kernel(int n, R *__restrict__ pos, R *__restrict__ vel, const R *__restrict__ f,
                                const R *__restrict__ mass, const R *__restrict__ vcoeff, R dt, R half_dt, R gamma,
                                uint64_t seed, uint64_t noise_step, uint64_t row0, const R *__restrict__ ref,
-                               PairConsts<R> c, R thresh2, int *flags, int parity) {
+                               PairConsts<R> c, R thresh2, int *flags, int parity,
+                               typename Vec<R>::T4 *__restrict__ sorted, const int *__restrict__ inv,
+                               const R *__restrict__ qs) {
 #pragma clang fp contract(off)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (CHECK && i == 0) flags[parity ^ 1] = 0;
@@ -824,6 +834,14 @@ __global__ void md_step_kernel(int n, R *__restrict__ pos, R *__restrict__ vel, 
       pos[3 * i + k] = p[k];
     }
     if (CHECK) {
+      // keep the cell-sorted copy the pair kernel reads current (on rebuild steps place_sorted_kernel
+      // rewrites it in the new order)
+      typename Vec<R>::T4 sv;  // one full 16/32-byte store (partial writes of a record are slower)
+      sv.x = p[0];
+      sv.y = p[1];
+      sv.z = p[2];
+      sv.w = qs[i];
+      sorted[inv[i]] = sv;
       const R dx = min_image(p[0] - ref[3 * i + 0], c.box[0], c.invbox[0]);
       const R dy = min_image(p[1] - ref[3 * i + 1], c.box[1], c.invbox[1]);
       const R dz = min_image(p[2] - ref[3 * i + 2], c.box[2], c.invbox[2]);
@@ -878,11 +896,11 @@ struct Replica {
   int ncell = 0;
   ListGeom lg{1, 64, 0, 0};
   int64_t host_rebuilds = 0;
-  DevBuf cell_of, slot, order_tmp, order, count, cell_start, sorted, stype, ref, nlist, nneigh;
+  DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
   DevBuf flags;  // int[4]: flags[0..1] rebuild parity, [2] overflow, [3] rebuild counter
   DevBuf paircount;  // unsigned long long
   void release() {
-    for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &count, &cell_start, &sorted, &stype, &ref,
+    for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref,
                       &nlist, &nneigh, &flags, &paircount})
       b->release();
   }
@@ -1132,6 +1150,7 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.slot.ensure(sizeof(int) * n));
   TMD_TRY(rp.order_tmp.ensure(sizeof(int) * n));
   TMD_TRY(rp.order.ensure(sizeof(int) * n));
+  TMD_TRY(rp.inv.ensure(sizeof(int) * n));
   TMD_TRY(rp.sorted.ensure(sizeof(R4) * n));
   TMD_TRY(rp.stype.ensure(sizeof(int) * n));
   TMD_TRY(rp.ref.ensure(sizeof(R) * 3 * n));
@@ -1170,11 +1189,13 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
                      rp.cell_start.as<int>(), flag);
   hipLaunchKernelGGL(fill_cells_kernel, dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(), rp.slot.as<int>(),
                      rp.cell_start.as<int>(), rp.order_tmp.as<int>(), flag);
-  hipLaunchKernelGGL(sort_in_cell_kernel, dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(),
-                     rp.cell_start.as<int>(), rp.order_tmp.as<int>(), rp.order.as<int>(), flag);
-  hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, ctx->qs.as<R>(),
-                     ctx->types.as<int>(), rp.order.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(),
-                     rp.ref.as<R>(), flag);
+  hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(),
+                     rp.cell_start.as<int>(), rp.order_tmp.as<int>(), pos, ctx->qs.as<R>(), ctx->types.as<int>(),
+                     rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(),
+                     flag);
+  if (!prechecked)
+    hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.order.as<int>(),
+                       rp.sorted.as<R4>(), flag);
   const R rl = (R)ctx->rlist;
   hipLaunchKernelGGL((build_list_kernel<R>), dim3(rp.ncell), dim3(64), 0, st, n, rp.sorted.as<R4>(),
                      rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
@@ -1311,14 +1332,17 @@ namespace {
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST>
 void launch_md_step(int n, R *pos, R *vel, const R *f, const R *mass, const R *vcoeff, double dt, double gamma,
                     uint64_t seed, uint64_t noise_step, uint64_t row0, bool check, const R *ref,
-                    const PairConsts<R> &c, R thresh2, int *flags, int parity, hipStream_t st) {
+                    const PairConsts<R> &c, R thresh2, int *flags, int parity, typename Vec<R>::T4 *sorted,
+                    const int *inv, const R *qs, hipStream_t st) {
   const dim3 grid((n + 255) / 256), block(256);
   if (check)
     hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, true>), grid, block, 0, st, n, pos, vel, f, mass,
-                       vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity);
+                       vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity,
+                       sorted, inv, qs);
   else
     hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, false>), grid, block, 0, st, n, pos, vel, f, mass,
-                       vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity);
+                       vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity,
+                       sorted, inv, qs);
 }
 
 template <typename R>
@@ -1346,7 +1370,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       int *flags = rp.flags.as<int>();
 #define TMD_MD(S, L, F) \
   launch_md_step<R, S, L, F>(n, pos, vel, f, mass, vc, d->dt, d->gamma, d->seed, noise_step, row0, check, ref, c, \
-                             half_skin * half_skin, flags, parity, st)
+                             half_skin * half_skin, flags, parity, rp.sorted.as<typename Vec<R>::T4>(),          \
+                             rp.inv.as<int>(), ctx->qs.as<R>(), st)
       if (second && first) {
         if (langevin) TMD_MD(true, true, true);
         else TMD_MD(true, false, true);
