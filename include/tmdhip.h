@@ -144,7 +144,12 @@ void tmdhip_destroy(tmdhip_ctx *ctx);
 /* Nonbonded block of Forces.compute (forces.py:260-319) for one replica: minimum-image distances
  * (360-372), `dist <= cutoff` filter (76-81), LJ (+switch) / Coulomb / reaction field / repulsion
  * (381-491), force scatter and per-term energy sums (316-319).
- * box_host = the three box edge lengths (diagonal of box[r], forces.py:118); all zero = no wrapping. */
+ * box_host = the three box edge lengths (diagonal of box[r], forces.py:118); all zero = no wrapping.
+ * replica = TMDHIP_ALL_REPLICAS: the body of the reference's `for i in range(nsystems)` loop
+ * (forces.py:116) for every replica in one call — pos_dev/forces_dev are the full [R][N][3] arrays,
+ * energies_dev is [R][TMDHIP_NENERGY], box_host is [R][3]; all-pairs contexts serve all replicas with
+ * one launch per kernel (small systems are launch-bound). */
+#define TMDHIP_ALL_REPLICAS (-1)
 int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, const double *box_host,
                              void *forces_dev, double *energies_dev, int flags, void *stream);
 

@@ -270,3 +270,46 @@ def test_fused_md_run_equals_stepwise_loop(prec):
     assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(f0, f1)
     for a, b in zip(r0, r1):
         assert np.allclose(a[0], b[0], rtol=1e-12) and np.allclose(a[1], b[1], rtol=1e-12)
+
+
+def test_replica_batched_md_matches_single_replica_runs():
+    """tmdhip_md_run batches the replicas of all-pairs systems into single launches: 25 NVE steps of
+    R = 3 water replicas (different start coordinates) == three separate R = 1 runs."""
+    import numpy as np
+
+    from _golden import GoldenParameters, load
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator
+    from torchmd_amd.systems import System
+
+    g = load("water291")
+    dev = torch.device("cuda:0")
+    par = GoldenParameters(g, torch.float64)
+    pos0 = np.asarray(g["pos"], dtype=np.float64).reshape(-1, 3)
+    box0 = np.asarray(g["box"], dtype=np.float64).reshape(-1)[:3]
+    n = pos0.shape[0]
+    rng = np.random.default_rng(11)
+    R = 3
+    starts = [pos0 + 0.02 * r * rng.standard_normal(pos0.shape) for r in range(R)]
+    vels = [0.01 * rng.standard_normal(pos0.shape) for r in range(R)]
+    terms = ["bonds", "angles", "electrostatics", "lj"]
+
+    def run(idx):
+        k = len(idx)
+        s = System(n, k, torch.float64, dev)
+        s.set_positions(np.stack([starts[i] for i in idx], axis=2))
+        s.set_box(np.stack([box0 for _ in idx], axis=1))
+        s.set_velocities(torch.tensor(np.stack([vels[i] for i in idx])))
+        f = Forces(par, terms=terms, cutoff=7.3, rfa=True)
+        f.compute(s.pos, s.box, s.forces)
+        integ = Integrator(s, f, 1.0, dev)
+        ek, ep, T = integ.step(25)
+        return s.pos.cpu().numpy(), np.asarray(ek), np.asarray(ep)
+
+    pb, ekb, epb = run([0, 1, 2])
+    for r in range(R):
+        p1, ek1, ep1 = run([r])
+        assert np.abs(pb[r] - p1[0]).max() < 1e-9, r
+        assert abs(ekb[r] - ek1[0]) < 1e-9 * max(1.0, abs(ek1[0]))
+        assert abs(epb[r] - ep1[0]) < 1e-9 * max(1.0, abs(ep1[0]))
+    assert np.abs(pb[0] - pb[2]).max() > 1e-3

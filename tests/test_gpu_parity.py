@@ -521,3 +521,41 @@ def test_thrombin_fp32_open_boundaries_packed_kernel():
     fc._evaluate(p, b, Fn, False, True)  # forces only -> packed kernel
     assert np.abs(F_c - F_a).max() < 2e-3 and np.abs(Fn.cpu().numpy() - F_a).max() < 2e-3
     assert fc.count_pairs(p, b) == fa.count_pairs(p, b)
+
+
+@pytest.mark.parametrize("which", ["water291", "ala2"])
+def test_replica_batch_matches_single_replica_calls(which):
+    """All-pairs systems serve every replica with one launch per kernel (grid.z / grid.y = replica):
+    R = 3 replicas with different coordinates AND different boxes must reproduce three independent
+    single-replica evaluations (energies per term and forces), for the atom-centric (water) and the
+    entry-parallel (alanine dipeptide) bonded paths."""
+    from torchmd_amd.forces import Forces
+
+    g = load(which)
+    dev = _dev()
+    par = GoldenParameters(g, torch.float64)
+    terms = ["bonds", "angles", "electrostatics", "lj"] if which == "water291" else ALL_TERMS
+    kw = dict(cutoff=7.3, rfa=True) if which == "water291" else dict(cutoff=9.0, rfa=True, switch_dist=7.5)
+    rng = np.random.default_rng(5)
+    pos0 = np.asarray(g["pos"], dtype=np.float64).reshape(-1, 3)
+    box0 = np.asarray(g["box"], dtype=np.float64).reshape(-1)[:3]
+    R = 3
+    pos = np.stack([pos0 + 0.05 * r * rng.standard_normal(pos0.shape) for r in range(R)])
+    boxes = np.stack([box0 * (1.0 + 0.01 * r) for r in range(R)])
+    p = torch.tensor(pos, dtype=torch.float64, device=dev)
+    b = torch.zeros(R, 3, 3, dtype=torch.float64, device=dev)
+    for r in range(R):
+        b[r] = torch.diag(torch.tensor(boxes[r], dtype=torch.float64))
+    fb = Forces(par, terms=terms, **kw)
+    Fb = torch.zeros_like(p)
+    pots_b = fb.compute(p, b, Fb, returnDetails=True)
+    assert fb.stats(p)["algorithm"] == "allpairs"
+    for r in range(R):
+        f1 = Forces(par, terms=terms, **kw)
+        F1 = torch.zeros(1, p.shape[1], 3, dtype=torch.float64, device=dev)
+        pots_1 = f1.compute(p[r : r + 1].contiguous(), b[r : r + 1].contiguous(), F1, returnDetails=True)
+        for t in pots_1[0]:
+            assert abs(pots_b[r][t] - pots_1[0][t]) <= 1e-9 * max(1.0, abs(pots_1[0][t])), (r, t)
+        assert (Fb[r] - F1[0]).abs().max().item() <= 1e-9 * max(1.0, F1.abs().max().item()), r
+    # the three replicas really differ
+    assert abs(pots_b[0]["lj"] - pots_b[2]["lj"]) > 1e-3

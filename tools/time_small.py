@@ -45,4 +45,6 @@ def run(name, terms, R, steps=4000, **kw):
 if __name__ == "__main__":
     all7 = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
     run("ala2", all7, 1, cutoff=9.0, switch_dist=7.5, rfa=True)
-    run("water291", ["lj", "bonds", "angles", "electrostatics"], 2, cutoff=7.3)
+    for R in (2, 16, 64):  # replicas share every launch (batched all-pairs / bonded / integrator kernels)
+        run("water291", ["lj", "bonds", "angles", "electrostatics"], R, steps=2000, cutoff=7.3)
+    run("ala2", all7, 16, steps=2000, cutoff=9.0, switch_dist=7.5, rfa=True)

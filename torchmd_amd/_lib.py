@@ -18,6 +18,7 @@ TERM_LJ, TERM_ELECTROSTATICS, TERM_REPULSION, TERM_REPULSIONCG = 1, 2, 4, 8
 E_LJ, E_ELECTROSTATICS, E_REPULSION, E_REPULSIONCG, E_BONDS, E_ANGLES, E_DIHEDRALS, E_IMPROPERS = range(8)
 NENERGY = 8
 WANT_ENERGY, WANT_FORCES, COUNT_PAIRS, OVERWRITE_FORCES = 1, 2, 4, 8
+ALL_REPLICAS = -1  # TMDHIP_ALL_REPLICAS
 ALGO_AUTO, ALGO_ALLPAIRS, ALGO_CELLLIST = 0, 1, 2
 SWITCH_REFERENCE, SWITCH_EXACT = 0, 1
 

@@ -55,7 +55,7 @@ struct Bonded {
   int natoms = 0;
   int nentries = 0;
   int max_entries_per_atom = 0;
-  DevArr entry_f;  // per-entry forces of the two-kernel path (real [3*nentries])
+  DevArr entry_f;  // per-entry forces of the two-kernel path (real [nreplicas][3*nentries])
   int dih_amber = 1, imp_amber = 1;
   uint32_t terms14 = 0;
   int bonds_use_cutoff = 0;
@@ -294,11 +294,29 @@ __device__ __forceinline__ void flush_energies(const double *e, double *scratch)
   wave_energy(e[TMDHIP_E_ELECTROSTATICS], energies + TMDHIP_E_ELECTROSTATICS);
 }
 
+// replica batch: blockIdx.y = replica; boxes[y] = {box[3], 1/box[3]} (null: single replica, box in A.b)
+template <typename R>
+__device__ __forceinline__ void replica_view(BondedArgs<R> &A, const R *__restrict__ &pos, R *__restrict__ &forces,
+                                             double *__restrict__ &energies, const R *__restrict__ boxes,
+                                             int natoms) {
+  if (!boxes) return;
+  const int rep = blockIdx.y;
+  pos += (size_t)rep * 3 * natoms;
+  if (forces) forces += (size_t)rep * 3 * natoms;
+  if (energies) energies += (size_t)rep * kEnergySlots * kEnergyStride;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    A.b.box[k] = boxes[6 * rep + k];
+    A.b.invbox[k] = boxes[6 * rep + 3 + k];
+  }
+}
+
 // (1) light topologies (every atom in a handful of terms: water, ions): thread = atom, one launch
 template <typename R>
 __global__ __launch_bounds__(256) void bonded_atom_kernel(int natoms, BondedArgs<R> A, const R *__restrict__ pos,
                                                           R *__restrict__ forces, double *__restrict__ energies,
-                                                          int want_e) {
+                                                          int want_e, const R *__restrict__ boxes) {
+  replica_view(A, pos, forces, energies, boxes, natoms);
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   R fx = 0, fy = 0, fz = 0;
   double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -321,7 +339,10 @@ __global__ __launch_bounds__(256) void bonded_atom_kernel(int natoms, BondedArgs
 template <typename R>
 __global__ __launch_bounds__(256) void bonded_entry_kernel(int nentries, BondedArgs<R> A, const R *__restrict__ pos,
                                                            R *__restrict__ entry_f, double *__restrict__ energies,
-                                                           int want_e) {
+                                                           int want_e, const R *__restrict__ boxes, int natoms) {
+  R *none = nullptr;
+  replica_view(A, pos, none, energies, boxes, natoms);
+  entry_f += (size_t)blockIdx.y * 3 * nentries;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (q < nentries) {
@@ -336,9 +357,12 @@ __global__ __launch_bounds__(256) void bonded_entry_kernel(int nentries, BondedA
 
 template <typename R>
 __global__ __launch_bounds__(256) void bonded_sum_kernel(int natoms, const int *__restrict__ atom_off,
-                                                         const R *__restrict__ entry_f, R *__restrict__ forces) {
+                                                         const R *__restrict__ entry_f, R *__restrict__ forces,
+                                                         int nentries) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= natoms) return;
+  entry_f += (size_t)blockIdx.y * 3 * nentries;  // blockIdx.y = replica
+  forces += (size_t)blockIdx.y * 3 * natoms;
   R fx = 0, fy = 0, fz = 0;
   for (int q = atom_off[a], qe = atom_off[a + 1]; q < qe; ++q) {
     fx += entry_f[3 * q + 0];
@@ -379,7 +403,8 @@ const tmdhip_nonbonded_desc &ctx_desc(const tmdhip_ctx *ctx);
 const void *ctx_scaled_charges(const tmdhip_ctx *ctx);
 int ctx_nreplicas(const tmdhip_ctx *ctx);
 double *ctx_energy_scratch(const tmdhip_ctx *ctx);
-int fold_energies(tmdhip_ctx *ctx, double *energies, hipStream_t st);
+int fold_energies(tmdhip_ctx *ctx, double *energies, hipStream_t st, int nrep);
+const void *set_boxes(tmdhip_ctx *ctx, const double *box_host, hipStream_t st);
 
 void bonded_release(tmdhip_ctx *ctx) {
   Bonded *b = (Bonded *)ctx_bonded_slot(ctx);
@@ -457,7 +482,7 @@ int set_bonded(tmdhip_ctx *ctx, Bonded *b, const tmdhip_bonded_desc *d) {
   b->nentries = off[n];
   for (int a = 0; a < n; ++a) b->max_entries_per_atom = std::max(b->max_entries_per_atom, off[a + 1] - off[a]);
   if (b->max_entries_per_atom > kAtomCentricLimit) {
-    std::vector<R> zeros((size_t)3 * off[n], R(0));
+    std::vector<R> zeros((size_t)3 * off[n] * ctx_nreplicas(ctx), R(0));  // one slab per replica (batched launches)
     TMD_TRY(b->entry_f.upload(zeros.data(), zeros.size()));
   }
   TMD_TRY(b->atom_off.upload(off.data(), off.size()));
@@ -478,9 +503,14 @@ R host_r2max(double cutoff) {
 }
 
 template <typename R>
-int run_bonded(tmdhip_ctx *ctx, const Bonded *b, const void *pos_v, const double *box, void *forces_v, double *en,
-               int flags, hipStream_t st) {
+int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box, void *forces_v, double *en,
+               int flags, hipStream_t st, int nrep) {
   if (b->nentries == 0) return 0;
+  const R *boxes = nullptr;
+  if (nrep > 1) {
+    boxes = (const R *)set_boxes(ctx, box, st);
+    if (!boxes) return fail("could not upload the replica boxes");
+  }
   BondedArgs<R> A;
   A.atom_off = b->atom_off.as<int>();
   A.atom_ent = b->atom_ent.as<int>();
@@ -510,18 +540,18 @@ int run_bonded(tmdhip_ctx *ctx, const Bonded *b, const void *pos_v, const double
   const int we = (flags & TMDHIP_WANT_ENERGY) ? 1 : 0;
   const int n = b->natoms;
   if (b->max_entries_per_atom <= kAtomCentricLimit) {
-    hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, A, (const R *)pos_v,
-                       forces, ctx_energy_scratch(ctx), we);
+    hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((n + 255) / 256, nrep), dim3(256), 0, st, n, A,
+                       (const R *)pos_v, forces, ctx_energy_scratch(ctx), we, boxes);
   } else {
     const int ne = b->nentries;
-    hipLaunchKernelGGL((bonded_entry_kernel<R>), dim3((ne + 255) / 256), dim3(256), 0, st, ne, A, (const R *)pos_v,
-                       b->entry_f.as<R>(), ctx_energy_scratch(ctx), we);
+    hipLaunchKernelGGL((bonded_entry_kernel<R>), dim3((ne + 255) / 256, nrep), dim3(256), 0, st, ne, A,
+                       (const R *)pos_v, b->entry_f.as<R>(), ctx_energy_scratch(ctx), we, boxes, n);
     if (forces)
-      hipLaunchKernelGGL((bonded_sum_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, b->atom_off.as<int>(),
-                         b->entry_f.as<R>(), forces);
+      hipLaunchKernelGGL((bonded_sum_kernel<R>), dim3((n + 255) / 256, nrep), dim3(256), 0, st, n,
+                         b->atom_off.as<int>(), b->entry_f.as<R>(), forces, ne);
   }
   TMD_HIP(hipGetLastError());
-  if (we) TMD_TRY(fold_energies(ctx, en, st));
+  if (we) TMD_TRY(fold_energies(ctx, en, st, nrep));
   return 0;
 }
 
@@ -548,17 +578,20 @@ int tmdhip_set_bonded(tmdhip_ctx *ctx, const tmdhip_bonded_desc *desc) {
 int tmdhip_compute_bonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, const double *box_host,
                           void *forces_dev, double *energies_dev, int flags, void *stream) {
   if (!ctx || !pos_dev || !box_host) return fail("tmdhip_compute_bonded: null argument");
-  if (replica < 0 || replica >= ctx_nreplicas(ctx)) return fail("tmdhip_compute_bonded: bad replica index");
+  if (replica != TMDHIP_ALL_REPLICAS && (replica < 0 || replica >= ctx_nreplicas(ctx)))
+    return fail("tmdhip_compute_bonded: bad replica index");
   if ((flags & TMDHIP_WANT_FORCES) && !forces_dev)
     return fail("tmdhip_compute_bonded: forces requested without a buffer");
   if ((flags & TMDHIP_WANT_ENERGY) && !energies_dev)
     return fail("tmdhip_compute_bonded: energies requested without a buffer");
-  const Bonded *b = (const Bonded *)ctx_bonded_slot(ctx);
+  Bonded *b = (Bonded *)ctx_bonded_slot(ctx);
   if (!b) return 0;
   hipStream_t st = (hipStream_t)stream;
+  // all replicas ([R][N][3] positions/forces, [R][8] energies, [R][3] boxes): one launch with grid.y = R
+  const int nrep = replica == TMDHIP_ALL_REPLICAS ? ctx_nreplicas(ctx) : 1;
   return ctx_desc(ctx).dtype == TMDHIP_F32
-             ? run_bonded<float>(ctx, b, pos_dev, box_host, forces_dev, energies_dev, flags, st)
-             : run_bonded<double>(ctx, b, pos_dev, box_host, forces_dev, energies_dev, flags, st);
+             ? run_bonded<float>(ctx, b, pos_dev, box_host, forces_dev, energies_dev, flags, st, nrep)
+             : run_bonded<double>(ctx, b, pos_dev, box_host, forces_dev, energies_dev, flags, st, nrep);
 }
 
 }  // extern "C"

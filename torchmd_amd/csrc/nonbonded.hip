@@ -57,10 +57,21 @@ __global__ __launch_bounds__(64) void allpairs_kernel(
     int n, const R *__restrict__ pos, const R *__restrict__ qs, const int *__restrict__ types, int ntypes,
     const typename Vec<R>::T2 *__restrict__ tab, const int *__restrict__ excl_off,
     const int *__restrict__ excl_idx, PairConsts<R> c, int jchunk, R *__restrict__ forces,
-    double *__restrict__ energies, unsigned long long *__restrict__ paircount) {
+    double *__restrict__ energies, unsigned long long *__restrict__ paircount, const R *__restrict__ boxes) {
   using R4 = typename Vec<R>::T4;
   __shared__ R4 sj[64];
   __shared__ int st[64];
+  if (boxes) {  // replica batch: blockIdx.z = replica, boxes[z] = {box[3], 1/box[3]} (see set_boxes)
+    const int rep = blockIdx.z;
+    pos += (size_t)rep * 3 * n;
+    if (forces) forces += (size_t)rep * 3 * n;
+    if (ENERGY) energies += (size_t)rep * kEnergySlots * kEnergyStride;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      c.box[k] = boxes[6 * rep + k];
+      c.invbox[k] = boxes[6 * rep + 3 + k];
+    }
+  }
   const int lane = threadIdx.x;
   const int i = blockIdx.x * 64 + lane;
   const bool active = i < n;
@@ -807,6 +818,13 @@ __global__ void md_step_kernel(int n, R *__restrict__ pos, R *__restrict__ vel, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (CHECK && i == 0) flags[parity ^ 1] = 0;
   if (i >= n) return;
+  if (!CHECK) {  // replica batch (all-pairs systems): blockIdx.y = replica
+    const size_t off = (size_t)blockIdx.y * 3 * n;
+    pos += off;
+    vel += off;
+    f += off;
+    row0 += (uint64_t)blockIdx.y * (uint64_t)n;
+  }
   const R m = mass[i];
   R v[3], a[3];
 #pragma unroll
@@ -915,7 +933,9 @@ struct tmdhip_ctx {
   double skin = 1.0;
   double rlist = 0;
   DevBuf types, qs, tab, excl_off, excl_idx;
-  DevBuf escratch;  // kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
+  DevBuf escratch;  // nreplicas x kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
+  DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
+  std::vector<double> boxes_host;  // what `boxes` currently holds
   int max_excl = 0;
   std::vector<Replica> rep;
   // bonded part lives in bonded.hip
@@ -935,10 +955,40 @@ const tmdhip_nonbonded_desc &ctx_desc(const tmdhip_ctx *ctx) { return ctx->d; }
 const void *ctx_scaled_charges(const tmdhip_ctx *ctx) { return ctx->qs.p; }
 int ctx_nreplicas(const tmdhip_ctx *ctx) { return (int)ctx->rep.size(); }
 double *ctx_energy_scratch(const tmdhip_ctx *ctx) { return ctx->escratch.as<double>(); }
-int fold_energies(tmdhip_ctx *ctx, double *energies, hipStream_t st) {
-  hipLaunchKernelGGL(energy_fold_kernel, dim3(1), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), energies);
+int fold_energies(tmdhip_ctx *ctx, double *energies, hipStream_t st, int nrep) {
+  hipLaunchKernelGGL(energy_fold_kernel, dim3(nrep), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), energies);
   TMD_HIP(hipGetLastError());
   return 0;
+}
+// device copy of the replicas' boxes ({box[3], 1/box[3]} each, in the context's real type) for the
+// replica-batched kernels; uploaded only when a box changes
+const void *set_boxes(tmdhip_ctx *ctx, const double *box_host, hipStream_t st) {
+  const size_t nrep = ctx->rep.size();
+  bool same = ctx->boxes_host.size() == 3 * nrep;
+  for (size_t k = 0; same && k < 3 * nrep; ++k) same = ctx->boxes_host[k] == box_host[k];
+  if (same) return ctx->boxes.p;
+  const bool f32 = ctx->d.dtype == TMDHIP_F32;
+  std::vector<float> hf(6 * nrep);
+  std::vector<double> hd(6 * nrep);
+  for (size_t r = 0; r < nrep; ++r) {
+    const double *b = box_host + 3 * r;
+    const bool allzero = b[0] == 0 && b[1] == 0 && b[2] == 0;
+    for (int k = 0; k < 3; ++k) {
+      hf[6 * r + k] = (float)b[k];
+      hd[6 * r + k] = b[k];
+      hf[6 * r + 3 + k] = (!allzero && hf[6 * r + k] != 0.f) ? 1.0f / hf[6 * r + k] : 0.f;
+      hd[6 * r + 3 + k] = (!allzero && b[k] != 0.0) ? 1.0 / b[k] : 0.0;
+    }
+  }
+  const size_t bytes = 6 * nrep * (f32 ? sizeof(float) : sizeof(double));
+  if (ctx->boxes.ensure(bytes)) return nullptr;
+  // pageable source: the runtime stages it before returning, the vectors may die afterwards
+  if (hipMemcpyAsync(ctx->boxes.p, f32 ? (const void *)hf.data() : (const void *)hd.data(), bytes,
+                     hipMemcpyHostToDevice, st) != hipSuccess)
+    return nullptr;
+  if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+  ctx->boxes_host.assign(box_host, box_host + 3 * nrep);
+  return ctx->boxes.p;
 }
 }  // namespace tmd
 
@@ -1038,31 +1088,38 @@ bool plan_grid(const tmdhip_ctx *ctx, const double *box, const double *lo, const
 
 template <typename R>
 int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *forces, double *energies,
-                    int flags, unsigned long long *paircount, hipStream_t st) {
+                    int flags, unsigned long long *paircount, hipStream_t st, int nrep = 1) {
+  // nrep > 1: pos/forces/energies/box are the arrays of all replicas ([nrep][n][3], [nrep][8], [nrep][3])
+  // and one launch (grid.z = replica) serves them all — small systems are launch-bound
   const int n = ctx->d.natoms;
   const PairConsts<R> c = make_consts<R>(ctx, box);
+  const R *boxes = nullptr;
+  if (nrep > 1) {
+    boxes = (const R *)tmd::set_boxes(ctx, box, st);
+    if (!boxes) return fail("could not upload the replica boxes");
+  }
   if ((flags & TMDHIP_OVERWRITE_FORCES) && (flags & TMDHIP_WANT_FORCES))
-    TMD_HIP(hipMemsetAsync(forces, 0, sizeof(R) * 3 * (size_t)n, st));  // partial sums are combined with atomics
+    TMD_HIP(hipMemsetAsync(forces, 0, sizeof(R) * 3 * (size_t)n * nrep, st));  // partial sums are combined with atomics
   const int nb = (n + 63) / 64;
   // split the j range so that ~1024 waves are in flight even for a few hundred atoms (each block then
   // walks a short j range; the partial forces are combined with one atomic per atom and split)
-  int nsplit = std::max(1, std::min((n + 15) / 16, 1024 / std::max(nb, 1)));
+  int nsplit = std::max(1, std::min((n + 15) / 16, 1024 / std::max(nb * nrep, 1)));
   int jchunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
   nsplit = (n + jchunk - 1) / jchunk;
-  dim3 grid(nb, nsplit);
+  dim3 grid(nb, nsplit, nrep);
   R *f = (flags & TMDHIP_WANT_FORCES) ? (R *)forces : nullptr;
   using R2 = typename Vec<R>::T2;
   if (flags & TMDHIP_WANT_ENERGY)
     hipLaunchKernelGGL((allpairs_kernel<R, true>), grid, dim3(64), 0, st, n, (const R *)pos,
                        ctx->qs.as<R>(), ctx->types.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),
                        ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, ctx->escratch.as<double>(),
-                       paircount);
+                       paircount, boxes);
   else
     hipLaunchKernelGGL((allpairs_kernel<R, false>), grid, dim3(64), 0, st, n, (const R *)pos,
                        ctx->qs.as<R>(), ctx->types.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),
-                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, nullptr, paircount);
+                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, nullptr, paircount, boxes);
   TMD_HIP(hipGetLastError());
-  if (flags & TMDHIP_WANT_ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st));
+  if (flags & TMDHIP_WANT_ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st, nrep));
   return 0;
 }
 
@@ -1109,7 +1166,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
 #undef TMD_LAUNCH_FAST
 #undef TMD_LAUNCH_FAST_T
       TMD_HIP(hipGetLastError());
-      if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st));
+      if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
       return 0;
     }
   }
@@ -1138,7 +1195,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
 #undef TMD_LAUNCH_LPA
 #undef TMD_LAUNCH
   TMD_HIP(hipGetLastError());
-  if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st));
+  if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
   return 0;
 }
 
@@ -1333,8 +1390,8 @@ template <typename R, bool SECOND, bool LANGEVIN, bool FIRST>
 void launch_md_step(int n, R *pos, R *vel, const R *f, const R *mass, const R *vcoeff, double dt, double gamma,
                     uint64_t seed, uint64_t noise_step, uint64_t row0, bool check, const R *ref,
                     const PairConsts<R> &c, R thresh2, int *flags, int parity, typename Vec<R>::T4 *sorted,
-                    const int *inv, const R *qs, hipStream_t st) {
-  const dim3 grid((n + 255) / 256), block(256);
+                    const int *inv, const R *qs, hipStream_t st, int nrep = 1) {
+  const dim3 grid((n + 255) / 256, check ? 1 : nrep), block(256);
   if (check)
     hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, true>), grid, block, 0, st, n, pos, vel, f, mass,
                        vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity,
@@ -1355,6 +1412,41 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   const size_t stride = (size_t)n * 3;
   for (int it = 0; it <= d->niter; ++it) {
     const bool first = it < d->niter, second = it > 0;
+    if (nrep > 1 && (ctx->algorithm == TMDHIP_ALGO_ALLPAIRS || ctx->d.terms == 0)) {
+      // small systems are launch-bound: one launch of every kernel serves all replicas
+      R *pos = (R *)d->pos_dev, *vel = (R *)d->vel_dev, *f = (R *)d->forces_dev;
+      const PairConsts<R> c = make_consts<R>(ctx, d->box_host);
+      const uint64_t noise_step = d->step0 + (uint64_t)(it > 0 ? it - 1 : 0);
+#define TMD_MD(S, L, F)                                                                                       \
+  launch_md_step<R, S, L, F>(n, pos, vel, f, mass, vc, d->dt, d->gamma, d->seed, noise_step, 0, false, nullptr, \
+                             c, R(0), nullptr, 0, nullptr, nullptr, nullptr, st, nrep)
+      if (second && first) {
+        if (langevin) TMD_MD(true, true, true);
+        else TMD_MD(true, false, true);
+      } else if (first) {
+        TMD_MD(false, false, true);
+      } else {
+        if (langevin) TMD_MD(true, true, false);
+        else TMD_MD(true, false, false);
+      }
+#undef TMD_MD
+      TMD_HIP(hipGetLastError());
+      if (!first) continue;
+      int flags_c = TMDHIP_WANT_FORCES;
+      double *en = nullptr;
+      if (it == d->niter - 1 && d->energies_dev) {
+        flags_c |= TMDHIP_WANT_ENERGY;
+        en = d->energies_dev;
+      }
+      if (ctx->d.terms != 0) {
+        for (auto &rp : ctx->rep) rp.n_compute++;
+        TMD_TRY(launch_allpairs<R>(ctx, pos, d->box_host, f, en, flags_c | TMDHIP_OVERWRITE_FORCES, nullptr, st, nrep));
+      } else {
+        TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride * nrep, st));
+      }
+      TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos, d->box_host, f, en, flags_c, st));
+      continue;
+    }
     for (int r = 0; r < nrep; ++r) {
       Replica &rp = ctx->rep[r];
       const double *box = d->box_host + 3 * r;
@@ -1490,8 +1582,9 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
     if (tabbytes > 64 * 1024) return cleanup(fail("tmdhip_create: LJ table does not fit in LDS (too many atom types)"));
   }
   ctx->algorithm = algo;
-  if (ctx->escratch.ensure(sizeof(double) * kEnergySlots * kEnergyStride)) return cleanup(-1);
-  (void)hipMemset(ctx->escratch.p, 0, sizeof(double) * kEnergySlots * kEnergyStride);
+  const size_t esbytes = sizeof(double) * kEnergySlots * kEnergyStride * (size_t)desc->nreplicas;
+  if (ctx->escratch.ensure(esbytes)) return cleanup(-1);
+  (void)hipMemset(ctx->escratch.p, 0, esbytes);
   ctx->rep.resize(desc->nreplicas);
   for (auto &rp : ctx->rep) {
     if (rp.flags.ensure(sizeof(int) * 4)) return cleanup(-1);
@@ -1510,7 +1603,8 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
 void tmdhip_destroy(tmdhip_ctx *ctx) {
   if (!ctx) return;
   for (auto &rp : ctx->rep) rp.release();
-  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->escratch}) b->release();
+  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->escratch, &ctx->boxes})
+    b->release();
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -1522,11 +1616,28 @@ void tmdhip_destroy(tmdhip_ctx *ctx) {
 int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, const double *box_host,
                              void *forces_dev, double *energies_dev, int flags, void *stream) {
   if (!ctx || !pos_dev || !box_host) return fail("tmdhip_compute_nonbonded: null argument");
-  if (replica < 0 || replica >= (int)ctx->rep.size()) return fail("tmdhip_compute_nonbonded: bad replica index");
+  if (replica != TMDHIP_ALL_REPLICAS && (replica < 0 || replica >= (int)ctx->rep.size()))
+    return fail("tmdhip_compute_nonbonded: bad replica index");
   if ((flags & TMDHIP_WANT_FORCES) && !forces_dev) return fail("tmdhip_compute_nonbonded: forces requested without a buffer");
   if ((flags & TMDHIP_WANT_ENERGY) && !energies_dev) return fail("tmdhip_compute_nonbonded: energies requested without a buffer");
   if (ctx->d.terms == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (replica == TMDHIP_ALL_REPLICAS) {
+    const int nrep = (int)ctx->rep.size();
+    const size_t esz = ctx->real_size, stride = (size_t)ctx->d.natoms * 3 * esz;
+    if (nrep > 1 && ctx->algorithm == TMDHIP_ALGO_ALLPAIRS && !(flags & TMDHIP_COUNT_PAIRS)) {
+      for (auto &rp : ctx->rep) rp.n_compute++;
+      return ctx->d.dtype == TMDHIP_F32
+                 ? launch_allpairs<float>(ctx, pos_dev, box_host, forces_dev, energies_dev, flags, nullptr, st, nrep)
+                 : launch_allpairs<double>(ctx, pos_dev, box_host, forces_dev, energies_dev, flags, nullptr, st, nrep);
+    }
+    for (int r = 0; r < nrep; ++r)  // (a cell-list context may fall back to all pairs on the way: still correct)
+      TMD_TRY(tmdhip_compute_nonbonded(ctx, r, (const char *)pos_dev + r * stride, box_host + 3 * r,
+                                       forces_dev ? (char *)forces_dev + r * stride : nullptr,
+                                       energies_dev ? energies_dev + (size_t)r * TMDHIP_NENERGY : nullptr, flags,
+                                       stream));
+    return 0;
+  }
   Replica &rp = ctx->rep[replica];
   rp.n_compute++;
   const bool f32 = ctx->d.dtype == TMDHIP_F32;

@@ -130,10 +130,12 @@ __device__ __forceinline__ double *energy_row(double *scratch) {
   return scratch + (size_t)(w & (kEnergySlots - 1)) * kEnergyStride;
 }
 
-// one block of kEnergySlots threads
+// one block of kEnergySlots threads per replica
 static __global__ __launch_bounds__(kEnergySlots) void energy_fold_kernel(double *__restrict__ scratch,
                                                                    double *__restrict__ out) {
   __shared__ double part[kEnergySlots / 64][8];
+  scratch += (size_t)blockIdx.x * kEnergySlots * kEnergyStride;
+  out += (size_t)blockIdx.x * 8;
   double *row = scratch + (size_t)threadIdx.x * kEnergyStride;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {

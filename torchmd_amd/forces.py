@@ -333,27 +333,33 @@ class Forces:
         stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
         flags = (L.WANT_ENERGY if want_energy else 0) | (L.WANT_FORCES if want_forces else 0)
         R, N = pos.shape[0], pos.shape[1]
-        esz = pos.element_size()
         if want_energy:
             eng.ebuf.zero_()
         if want_forces and not eng.stores_forces:
             forces.zero_()
-        for r in range(R):
-            p = C.c_void_p(pos.data_ptr() + r * N * 3 * esz)
-            f = C.c_void_p(forces.data_ptr() + r * N * 3 * esz) if want_forces else C.c_void_p()
-            e = C.c_void_p(eng.ebuf.data_ptr() + r * L.NENERGY * 8)
-            bx = (C.c_double * 3)(*[float(v) for v in hbox[min(r, len(hbox) - 1)]])
-            # nonbonded first: on the cell-list path it overwrites `forces`, the bonded kernels then add
-            if eng.has_nonbonded:
-                nbflags = flags | (L.COUNT_PAIRS if count_pairs else 0)
-                if eng.stores_forces:
-                    nbflags |= L.OVERWRITE_FORCES
-                L.check(
-                    lib.tmdhip_compute_nonbonded(eng.ctx, r, p, bx, f, e, nbflags, stream),
-                    "tmdhip_compute_nonbonded",
-                )
-            if eng.has_bonded:
-                L.check(lib.tmdhip_compute_bonded(eng.ctx, r, p, bx, f, e, flags, stream), "tmdhip_compute_bonded")
+        # one call for all replicas (the reference's `for i in range(nsystems)` loop, forces.py:116, runs
+        # inside the library: batched launches for all-pairs systems, per-replica lists otherwise)
+        boxes = np.ascontiguousarray(
+            np.stack([hbox[min(r, len(hbox) - 1)] for r in range(R)]).astype(np.float64)
+        )
+        bx = boxes.ctypes.data_as(C.POINTER(C.c_double))
+        p = C.c_void_p(pos.data_ptr())
+        f = C.c_void_p(forces.data_ptr()) if want_forces else C.c_void_p()
+        e = C.c_void_p(eng.ebuf.data_ptr())
+        # nonbonded first: on the cell-list path it overwrites `forces`, the bonded kernels then add
+        if eng.has_nonbonded:
+            nbflags = flags | (L.COUNT_PAIRS if count_pairs else 0)
+            if eng.stores_forces:
+                nbflags |= L.OVERWRITE_FORCES
+            L.check(
+                lib.tmdhip_compute_nonbonded(eng.ctx, L.ALL_REPLICAS, p, bx, f, e, nbflags, stream),
+                "tmdhip_compute_nonbonded",
+            )
+        if eng.has_bonded:
+            L.check(
+                lib.tmdhip_compute_bonded(eng.ctx, L.ALL_REPLICAS, p, bx, f, e, flags, stream),
+                "tmdhip_compute_bonded",
+            )
 
     def _verify(self, eng, pos):
         """Host-visible validity check (neighbour-list capacity). True = results valid."""
