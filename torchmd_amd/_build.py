@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libtmdhip.so")
 SOURCES = ["nonbonded.hip", "bonded.hip", "integrator.hip"]
-HEADERS = ["common.h", "pair_math.h", "rng.h", os.path.join("..", "..", "include", "tmdhip.h")]
+HEADERS = ["common.h", "pair_math.h", "rng.h", "bonded_math.h", os.path.join("..", "..", "include", "tmdhip.h")]
 ARCH = "gfx950"
 
 

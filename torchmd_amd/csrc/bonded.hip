@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "pair_math.h"
+#include "bonded_math.h"
 
 using namespace tmd;
 
@@ -47,9 +48,6 @@ struct DevArr {
 // topologies where no atom takes part in more terms than this use the single atom-centric kernel
 constexpr int kAtomCentricLimit = 8;
 
-enum Kind : unsigned { KBOND = 0, KANGLE = 1, KDIHEDRAL = 2, KIMPROPER = 3, KPAIR14 = 4 };
-// entry = kind << 28 | role << 26 | term index (26 bits)
-constexpr unsigned kIdxBits = 26;
 
 struct Bonded {
   int natoms = 0;
@@ -70,219 +68,11 @@ struct Bonded {
   }
 };
 
-template <typename R>
-struct Box3 {
-  R box[3], invbox[3];
-};
-
-template <typename R>
-struct BondedArgs {
-  const int *atom_off, *atom_ent;
-  const int *bond_idx;
-  const R *bond_prm;
-  const int *angle_idx;
-  const R *angle_prm;
-  const int *dih_idx, *dih_start;
-  const R *dih_prm;
-  const int *imp_idx, *imp_start;
-  const R *imp_prm;
-  const int *p14_idx;
-  const R *p14_prm;
-  const R *qs;
-  int dih_amber, imp_amber;
-  uint32_t terms14;
-  R bond_r2max;
-  Box3<R> b;
-};
-
-template <typename R>
-struct V3 {
-  R x, y, z;
-};
-
-template <typename R>
-__device__ __forceinline__ V3<R> wrapped_delta(const R *__restrict__ pos, int i, int j, const Box3<R> &b) {
-  V3<R> d;
-  d.x = min_image(pos[3 * i + 0] - pos[3 * j + 0], b.box[0], b.invbox[0]);
-  d.y = min_image(pos[3 * i + 1] - pos[3 * j + 1], b.box[1], b.invbox[1]);
-  d.z = min_image(pos[3 * i + 2] - pos[3 * j + 2], b.box[2], b.invbox[2]);
-  return d;
-}
-
-__device__ __forceinline__ float dsqrt(float x) { return sqrtf(x); }
-__device__ __forceinline__ double dsqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ float dacos(float x) { return acosf(x); }
-__device__ __forceinline__ double dacos(double x) { return acos(x); }
-__device__ __forceinline__ float datan2(float y, float x) { return atan2f(y, x); }
-__device__ __forceinline__ double datan2(double y, double x) { return atan2(y, x); }
-__device__ __forceinline__ void dsincos(float a, float *s, float *c) { sincosf(a, s, c); }
-__device__ __forceinline__ void dsincos(double a, double *s, double *c) { sincos(a, s, c); }
-
-// forces.py:122-143 + evaluate_bonds 494-503.  The reference drops bonds with dist > cutoff when a
-// cutoff is set (same decision arithmetic as the nonbonded filter).  role 0 = first atom.
-template <typename R>
-__device__ __forceinline__ void bond_term(const BondedArgs<R> &A, const R *__restrict__ pos, int t, int role,
-                                          R &fx, R &fy, R &fz, double &e) {
-  const int i = A.bond_idx[2 * t], j = A.bond_idx[2 * t + 1];
-  const V3<R> d = wrapped_delta(pos, i, j, A.b);
-  const R r2 = norm2(d.x, d.y, d.z);
-  if (!(r2 <= A.bond_r2max)) return;
-  const R r = dsqrt(r2);
-  const R k0 = A.bond_prm[2 * t], d0 = A.bond_prm[2 * t + 1];
-  const R x = r - d0;
-  if (role == 0) e += (double)(k0 * x * x);
-  const R fs = R(2) * k0 * x / r;  // unitvec * force_coeff ; F_i -= , F_j +=
-  const R sgn = role == 0 ? R(-1) : R(1);
-  fx += sgn * d.x * fs;
-  fy += sgn * d.y * fs;
-  fz += sgn * d.z * fs;
-}
-
-// forces.py:145-161 + evaluate_angles 506-539.  roles 0,1,2 = idx columns (1 = vertex)
-template <typename R>
-__device__ __forceinline__ void angle_term(const BondedArgs<R> &A, const R *__restrict__ pos, int t, int role,
-                                           R &fx, R &fy, R &fz, double &e) {
-  const int a0 = A.angle_idx[3 * t], a1 = A.angle_idx[3 * t + 1], a2 = A.angle_idx[3 * t + 2];
-  const V3<R> r21 = wrapped_delta(pos, a0, a1, A.b);
-  const V3<R> r23 = wrapped_delta(pos, a2, a1, A.b);
-  const R k0 = A.angle_prm[2 * t], th0 = A.angle_prm[2 * t + 1];
-  const R dot = r23.x * r21.x + r23.y * r21.y + r23.z * r21.z;
-  const R n21 = R(1) / dsqrt(r21.x * r21.x + r21.y * r21.y + r21.z * r21.z);
-  const R n23 = R(1) / dsqrt(r23.x * r23.x + r23.y * r23.y + r23.z * r23.z);
-  R cs = dot * n21 * n23;
-  cs = cs < R(-1) ? R(-1) : (cs > R(1) ? R(1) : cs);
-  const R dth = dacos(cs) - th0;
-  if (role == 0) e += (double)(k0 * dth * dth);
-  const R sn = dsqrt(R(1) - cs * cs);
-  const R coef = sn != R(0) ? R(-2) * k0 * dth / sn : R(0);
-  const R f0x = coef * (cs * r21.x * n21 - r23.x * n23) * n21;
-  const R f0y = coef * (cs * r21.y * n21 - r23.y * n23) * n21;
-  const R f0z = coef * (cs * r21.z * n21 - r23.z * n23) * n21;
-  const R f2x = coef * (cs * r23.x * n23 - r21.x * n21) * n23;
-  const R f2y = coef * (cs * r23.y * n23 - r21.y * n21) * n23;
-  const R f2z = coef * (cs * r23.z * n23 - r21.z * n21) * n23;
-  if (role == 0) {
-    fx += f0x, fy += f0y, fz += f0z;
-  } else if (role == 2) {
-    fx += f2x, fy += f2y, fz += f2z;
-  } else {
-    fx -= f0x + f2x, fy -= f0y + f2y, fz -= f0z + f2z;
-  }
-}
-
-// forces.py:163-183 / 238-258 + evaluate_torsion 542-605.  The terms of torsion t are rows
-// [start[t], start[t+1]) of prm = (k0, phi0, per); `amber` mirrors `torch.all(per > 0)`.
-template <typename R>
-__device__ __forceinline__ void torsion_term(const int *__restrict__ idx, const int *__restrict__ start,
-                                             const R *__restrict__ prm, int amber, const Box3<R> &b,
-                                             const R *__restrict__ pos, int t, int role, R &fx, R &fy, R &fz,
-                                             double &e) {
-  const int i0 = idx[4 * t], i1 = idx[4 * t + 1], i2 = idx[4 * t + 2], i3 = idx[4 * t + 3];
-  const V3<R> a = wrapped_delta(pos, i0, i1, b);  // r12
-  const V3<R> m = wrapped_delta(pos, i1, i2, b);  // r23
-  const V3<R> c = wrapped_delta(pos, i2, i3, b);  // r34
-  // crossA = r12 x r23, crossB = r23 x r34, crossC = r23 x crossA
-  const R Ax = a.y * m.z - a.z * m.y, Ay = a.z * m.x - a.x * m.z, Az = a.x * m.y - a.y * m.x;
-  const R Bx = m.y * c.z - m.z * c.y, By = m.z * c.x - m.x * c.z, Bz = m.x * c.y - m.y * c.x;
-  const R Cx = m.y * Az - m.z * Ay, Cy = m.z * Ax - m.x * Az, Cz = m.x * Ay - m.y * Ax;
-  const R nA2 = Ax * Ax + Ay * Ay + Az * Az, nB2 = Bx * Bx + By * By + Bz * Bz;
-  const R nA = dsqrt(nA2), nB = dsqrt(nB2), nC = dsqrt(Cx * Cx + Cy * Cy + Cz * Cz);
-  const R ux = Bx / nB, uy = By / nB, uz = Bz / nB;
-  const R cosphi = (Ax * ux + Ay * uy + Az * uz) / nA;
-  const R sinphi = (Cx * ux + Cy * uy + Cz * uz) / nC;
-  const R phi = -datan2(sinphi, cosphi);
-  R pot = 0, coeff = 0;
-  const R PI = R(3.14159265358979323846);
-  for (int q = start[t]; q < start[t + 1]; ++q) {
-    const R k0 = prm[3 * q], phi0 = prm[3 * q + 1], per = prm[3 * q + 2];
-    if (amber) {
-      R s, cc;
-      dsincos(per * phi - phi0, &s, &cc);
-      pot += k0 * (R(1) + cc);
-      coeff += -per * k0 * s;
-    } else {
-      R ad = phi - phi0;
-      if (ad < -PI) ad += R(2) * PI;
-      else if (ad > PI) ad -= R(2) * PI;
-      pot += k0 * ad * ad;
-      coeff += R(2) * k0 * ad;
-    }
-  }
-  if (role == 0) e += (double)pot;
-  const R n23sq = m.x * m.x + m.y * m.y + m.z * m.z;
-  const R n23 = dsqrt(n23sq);
-  const R ff0 = (-coeff * n23) / nA2;
-  const R ff1 = (a.x * m.x + a.y * m.y + a.z * m.z) / n23sq;
-  const R ff2 = (c.x * m.x + c.y * m.y + c.z * m.z) / n23sq;
-  const R ff3 = (coeff * n23) / nB2;
-  const R f0x = ff0 * Ax, f0y = ff0 * Ay, f0z = ff0 * Az;
-  const R f3x = ff3 * Bx, f3y = ff3 * By, f3z = ff3 * Bz;
-  const R sx = ff1 * f0x - ff2 * f3x, sy = ff1 * f0y - ff2 * f3y, sz = ff1 * f0z - ff2 * f3z;
-  if (role == 0) {
-    fx -= f0x, fy -= f0y, fz -= f0z;
-  } else if (role == 1) {
-    fx += f0x + sx, fy += f0y + sy, fz += f0z + sz;
-  } else if (role == 2) {
-    fx += f3x - sx, fy += f3y - sy, fz += f3z - sz;
-  } else {
-    fx -= f3x, fy -= f3y, fz -= f3z;
-  }
-}
-
-// forces.py:185-236: scaled 1-4 LJ (evaluate_LJ_internal with scale=scnb, no switch) and plain Coulomb
-// with scale=scee, no cutoff.  prm = (A, B, scnb, scee); qs = q*sqrt(k_e).
-template <typename R>
-__device__ __forceinline__ void pair14_term(const BondedArgs<R> &A, const R *__restrict__ pos, int t, int role,
-                                            R &fx, R &fy, R &fz, double &elj, double &eel) {
-  const int i = A.p14_idx[2 * t], j = A.p14_idx[2 * t + 1];
-  const V3<R> d = wrapped_delta(pos, i, j, A.b);
-  const R r2 = norm2(d.x, d.y, d.z);
-  const R rinv = R(1) / dsqrt(r2);
-  const R rinv2 = rinv * rinv, rinv6 = rinv2 * rinv2 * rinv2;
-  const R a = A.p14_prm[4 * t], bb = A.p14_prm[4 * t + 1], scnb = A.p14_prm[4 * t + 2], scee = A.p14_prm[4 * t + 3];
-  R dEdr = 0;
-  if (A.terms14 & TMDHIP_TERM_LJ) {
-    if (role == 0) elj += (double)((a * rinv6 - bb) * rinv6 / scnb);
-    dEdr += (R(-12) * a * rinv6 + R(6) * bb) * rinv6 * rinv / scnb;
-  }
-  if (A.terms14 & TMDHIP_TERM_ELECTROSTATICS) {
-    const R ee = A.qs[i] * A.qs[j] * rinv / scee;
-    if (role == 0) eel += (double)ee;
-    dEdr -= ee * rinv;
-  }
-  const R fs = dEdr * rinv;
-  const R sgn = role == 0 ? R(-1) : R(1);
-  fx += sgn * d.x * fs;
-  fy += sgn * d.y * fs;
-  fz += sgn * d.z * fs;
-}
-
 __device__ __forceinline__ void wave_energy(double e, double *dst) {
   const double s = wave_sum(e);
   if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(dst, s);  // dst: this wave's scratch row
 }
 
-// force on the atom that entry `ent` stands for (and the term's energy if that atom has role 0)
-template <typename R>
-__device__ __forceinline__ void eval_entry(const BondedArgs<R> &A, const R *__restrict__ pos, unsigned ent, R &fx,
-                                           R &fy, R &fz, double *e) {
-  const unsigned kind = ent >> 28;
-  const int role = (int)((ent >> kIdxBits) & 3u);
-  const int t = (int)(ent & ((1u << kIdxBits) - 1u));
-  if (kind == KBOND) {
-    bond_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_BONDS]);
-  } else if (kind == KANGLE) {
-    angle_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_ANGLES]);
-  } else if (kind == KDIHEDRAL) {
-    torsion_term<R>(A.dih_idx, A.dih_start, A.dih_prm, A.dih_amber, A.b, pos, t, role, fx, fy, fz,
-                    e[TMDHIP_E_DIHEDRALS]);
-  } else if (kind == KIMPROPER) {
-    torsion_term<R>(A.imp_idx, A.imp_start, A.imp_prm, A.imp_amber, A.b, pos, t, role, fx, fy, fz,
-                    e[TMDHIP_E_IMPROPERS]);
-  } else {
-    pair14_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_LJ], e[TMDHIP_E_ELECTROSTATICS]);
-  }
-}
 
 __device__ __forceinline__ void flush_energies(const double *e, double *scratch) {
   double *energies = energy_row(scratch);
@@ -503,15 +293,7 @@ R host_r2max(double cutoff) {
 }
 
 template <typename R>
-int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box, void *forces_v, double *en,
-               int flags, hipStream_t st, int nrep) {
-  if (b->nentries == 0) return 0;
-  const R *boxes = nullptr;
-  if (nrep > 1) {
-    boxes = (const R *)set_boxes(ctx, box, st);
-    if (!boxes) return fail("could not upload the replica boxes");
-  }
-  BondedArgs<R> A;
+void fill_args(tmdhip_ctx *ctx, const Bonded *b, const double *box, BondedArgs<R> &A) {
   A.atom_off = b->atom_off.as<int>();
   A.atom_ent = b->atom_ent.as<int>();
   A.bond_idx = b->bond_idx.as<int>();
@@ -536,6 +318,19 @@ int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box,
     A.b.box[k] = (R)box[k];
     A.b.invbox[k] = (!allzero && A.b.box[k] != R(0)) ? R(1) / A.b.box[k] : R(0);
   }
+}
+
+template <typename R>
+int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box, void *forces_v, double *en,
+               int flags, hipStream_t st, int nrep) {
+  if (b->nentries == 0) return 0;
+  const R *boxes = nullptr;
+  if (nrep > 1) {
+    boxes = (const R *)set_boxes(ctx, box, st);
+    if (!boxes) return fail("could not upload the replica boxes");
+  }
+  BondedArgs<R> A;
+  fill_args<R>(ctx, b, box, A);
   R *forces = (flags & TMDHIP_WANT_FORCES) ? (R *)forces_v : nullptr;
   const int we = (flags & TMDHIP_WANT_ENERGY) ? 1 : 0;
   const int n = b->natoms;
@@ -556,6 +351,23 @@ int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box,
 }
 
 }  // namespace
+
+namespace tmd {
+// Arguments for evaluating the bonded force of an atom inline in the MD-step kernel (nonbonded.hip).
+// False when there are no bonded terms or the topology is too heavy for the atom-centric scheme.
+bool bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A) {
+  const Bonded *b = (const Bonded *)ctx_bonded_slot(ctx);
+  if (!b || b->nentries == 0 || b->max_entries_per_atom > kAtomCentricLimit) return false;
+  fill_args<float>(ctx, b, box, A);
+  return true;
+}
+bool bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A) {
+  const Bonded *b = (const Bonded *)ctx_bonded_slot(ctx);
+  if (!b || b->nentries == 0 || b->max_entries_per_atom > kAtomCentricLimit) return false;
+  fill_args<double>(ctx, b, box, A);
+  return true;
+}
+}  // namespace tmd
 
 extern "C" {
 

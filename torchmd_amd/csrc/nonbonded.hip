@@ -30,6 +30,7 @@
 
 #include "common.h"
 #include "pair_math.h"
+#include "bonded_math.h"
 #include "rng.h"
 
 namespace tmd {
@@ -688,7 +689,13 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // XCD-aware block order: consecutive block ids go to the 8 XCDs round-robin, so block b works on
+  // chunk (b % 8) * gridDim.x/8 + b / 8 — every XCD (own L2) gets a contiguous eighth of the cell-sorted
+  // atoms and gathers neighbours from that region only.  gridDim.x is a multiple of 8; the surplus
+  // blocks of the last eighths have nothing to do.
+  const int blk = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  if (blk * 4 * APW >= n) return;
+  const int wave = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int a = wave * APW + lane / LPA;
   const int sub = lane % LPA;
   const bool active = a < n;
@@ -807,49 +814,61 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
 // One launch per replica and step: [Langevin kick + second half kick of step s-1] + [first half step of
 // step s] + [displacement test that drives the device-side list rebuild].  Values are identical to the
 // separate kernels of integrator.hip (same operations on the same registers, no re-association).
+template <typename R>
+struct MdStepArgs {
+  int n;
+  const R *pos_in;  // positions before the drift (== pos_out except in the double-buffered bonded variant)
+  R *pos_out;
+  R *vel;
+  const R *f;
+  const R *mass, *vcoeff;
+  R dt, half_dt, gamma;
+  uint64_t seed, noise_step, row0;
+  const R *ref;
+  R thresh2;
+  int *flags;
+  int parity;
+  typename Vec<R>::T4 *sorted;
+  const int *inv;
+  const R *qs;
+};
+
+// fb = extra force on atom i that is not in `f` (the inline bonded force), added before the division
+// by the mass exactly like the separate bonded kernel's `forces[i] += fb`
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
-__global__ void md_step_kernel(int n, R *__restrict__ pos, R *__restrict__ vel, const R *__restrict__ f,
-                               const R *__restrict__ mass, const R *__restrict__ vcoeff, R dt, R half_dt, R gamma,
-                               uint64_t seed, uint64_t noise_step, uint64_t row0, const R *__restrict__ ref,
-                               PairConsts<R> c, R thresh2, int *flags, int parity,
-                               typename Vec<R>::T4 *__restrict__ sorted, const int *__restrict__ inv,
-                               const R *__restrict__ qs) {
+__device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairConsts<R> &c, int i, size_t off,
+                                             uint64_t row0, const R (&fb)[3], bool add_fb) {
 #pragma clang fp contract(off)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (CHECK && i == 0) flags[parity ^ 1] = 0;
-  if (i >= n) return;
-  if (!CHECK) {  // replica batch (all-pairs systems): blockIdx.y = replica
-    const size_t off = (size_t)blockIdx.y * 3 * n;
-    pos += off;
-    vel += off;
-    f += off;
-    row0 += (uint64_t)blockIdx.y * (uint64_t)n;
-  }
-  const R m = mass[i];
+  const R *pos_in = s.pos_in + off;
+  R *pos_out = s.pos_out + off, *vel = s.vel + off;
+  const R *f = s.f + off;
+  const R m = s.mass[i];
   R v[3], a[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     v[k] = vel[3 * i + k];
-    a[k] = f[3 * i + k] / m;
+    R fk = f[3 * i + k];
+    if (add_fb) fk += fb[k];
+    a[k] = fk / m;
   }
   if (SECOND) {
     if (LANGEVIN) {
-      const R vc = vcoeff[i];
+      const R vc = s.vcoeff[i];
       R g[3];
-      normal3<R>(seed, noise_step, row0 + (uint64_t)i, g[0], g[1], g[2]);
+      normal3<R>(s.seed, s.noise_step, row0 + (uint64_t)i, g[0], g[1], g[2]);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) v[k] += -gamma * v[k] * dt + g[k] * vc;
+      for (int k = 0; k < 3; ++k) v[k] += -s.gamma * v[k] * s.dt + g[k] * vc;
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] += half_dt * a[k];
+    for (int k = 0; k < 3; ++k) v[k] += s.half_dt * a[k];
   }
   if (FIRST) {
     R p[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      p[k] = pos[3 * i + k] + (v[k] * dt + R(0.5) * a[k] * dt * dt);
-      v[k] = v[k] + half_dt * a[k];
-      pos[3 * i + k] = p[k];
+      p[k] = pos_in[3 * i + k] + (v[k] * s.dt + R(0.5) * a[k] * s.dt * s.dt);
+      v[k] = v[k] + s.half_dt * a[k];
+      pos_out[3 * i + k] = p[k];
     }
     if (CHECK) {
       // keep the cell-sorted copy the pair kernel reads current (on rebuild steps place_sorted_kernel
@@ -858,17 +877,47 @@ __global__ void md_step_kernel(int n, R *__restrict__ pos, R *__restrict__ vel, 
       sv.x = p[0];
       sv.y = p[1];
       sv.z = p[2];
-      sv.w = qs[i];
-      sorted[inv[i]] = sv;
-      const R dx = min_image(p[0] - ref[3 * i + 0], c.box[0], c.invbox[0]);
-      const R dy = min_image(p[1] - ref[3 * i + 1], c.box[1], c.invbox[1]);
-      const R dz = min_image(p[2] - ref[3 * i + 2], c.box[2], c.invbox[2]);
+      sv.w = s.qs[i];
+      s.sorted[s.inv[i]] = sv;
+      const R dx = min_image(p[0] - s.ref[3 * i + 0], c.box[0], c.invbox[0]);
+      const R dy = min_image(p[1] - s.ref[3 * i + 1], c.box[1], c.invbox[1]);
+      const R dz = min_image(p[2] - s.ref[3 * i + 2], c.box[2], c.invbox[2]);
       const R d2 = dx * dx + dy * dy + dz * dz;
-      if (!(d2 <= thresh2)) flags[parity] = 1;
+      if (!(d2 <= s.thresh2)) s.flags[s.parity] = 1;
     }
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) vel[3 * i + k] = v[k];
+}
+
+template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
+__global__ void md_step_kernel(MdStepArgs<R> s, PairConsts<R> c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (CHECK && i == 0) s.flags[s.parity ^ 1] = 0;
+  if (i >= s.n) return;
+  // replica batch (all-pairs systems, never with CHECK): blockIdx.y = replica
+  const size_t off = CHECK ? 0 : (size_t)blockIdx.y * 3 * s.n;
+  const uint64_t row0 = s.row0 + (CHECK ? 0 : (uint64_t)blockIdx.y * (uint64_t)s.n);
+  const R none[3] = {0, 0, 0};
+  md_step_atom<R, SECOND, LANGEVIN, FIRST, CHECK>(s, c, i, off, row0, none, false);
+}
+
+// Interior steps of a cell-list MD run with a light topology (water, ions): the bonded force of the
+// previous step's positions is evaluated HERE, per atom, instead of by a bonded kernel of its own
+// (one launch and one read-modify-write pass over `forces` less per step; bit-identical: the same
+// eval_entry sequence, added to the stored pair force before the division by the mass).  Partner
+// positions must be the undrifted ones, so the step reads pos_in and writes pos_out (two buffers).
+template <typename R, bool LANGEVIN, bool CHECK>
+__global__ void md_step_bonded_kernel(MdStepArgs<R> s, PairConsts<R> c, BondedArgs<R> A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (CHECK && i == 0) s.flags[s.parity ^ 1] = 0;
+  if (i >= s.n) return;
+  R fx = 0, fy = 0, fz = 0;
+  double e[TMDHIP_NENERGY];  // energies are not wanted on interior steps (dead stores)
+  for (int q = A.atom_off[i], qe = A.atom_off[i + 1]; q < qe; ++q)
+    eval_entry<R>(A, s.pos_in, (unsigned)A.atom_ent[q], fx, fy, fz, e);
+  const R fb[3] = {fx, fy, fz};
+  md_step_atom<R, true, LANGEVIN, true, CHECK>(s, c, i, 0, s.row0, fb, true);
 }
 
 __global__ void halve_count_kernel(unsigned long long *c) { *c >>= 1; }
@@ -915,11 +964,12 @@ struct Replica {
   ListGeom lg{1, 64, 0, 0};
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
+  DevBuf pos_alt;  // second position buffer of tmdhip_md_run's double-buffered integrator kernel
   DevBuf flags;  // int[4]: flags[0..1] rebuild parity, [2] overflow, [3] rebuild counter
   DevBuf paircount;  // unsigned long long
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref,
-                      &nlist, &nneigh, &flags, &paircount})
+                      &nlist, &nneigh, &flags, &paircount, &pos_alt})
       b->release();
   }
 };
@@ -950,6 +1000,8 @@ struct tmdhip_ctx {
 
 namespace tmd {
 void bonded_release(tmdhip_ctx *ctx);  // bonded.hip
+bool bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A);   // bonded.hip
+bool bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A);  // bonded.hip
 void *&ctx_bonded_slot(tmdhip_ctx *ctx) { return ctx->bonded; }
 const tmdhip_nonbonded_desc &ctx_desc(const tmdhip_ctx *ctx) { return ctx->d; }
 const void *ctx_scaled_charges(const tmdhip_ctx *ctx) { return ctx->qs.p; }
@@ -1142,7 +1194,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
       const size_t shfast = shmem + 2048;  // garbage type fields of padding entries stay inside the allocation
       const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
 #define TMD_LAUNCH_FAST_T(L, A, B)                                                                                  \
-  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L, A, B, ENERGY>), dim3(blocks), dim3(256), shfast, st, n,          \
+  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L, A, B, ENERGY>), dim3((blocks + 7) / 8 * 8), dim3(256), shfast, st, n, \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
                      rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,                   \
                      ctx->escratch.as<double>())
@@ -1387,49 +1439,69 @@ int upload_params(tmdhip_ctx *ctx) {
 namespace {
 
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST>
-void launch_md_step(int n, R *pos, R *vel, const R *f, const R *mass, const R *vcoeff, double dt, double gamma,
-                    uint64_t seed, uint64_t noise_step, uint64_t row0, bool check, const R *ref,
-                    const PairConsts<R> &c, R thresh2, int *flags, int parity, typename Vec<R>::T4 *sorted,
-                    const int *inv, const R *qs, hipStream_t st, int nrep = 1) {
-  const dim3 grid((n + 255) / 256, check ? 1 : nrep), block(256);
+void launch_md_step(const MdStepArgs<R> &a, const PairConsts<R> &c, bool check, hipStream_t st, int nrep = 1) {
+  const dim3 grid((a.n + 255) / 256, check ? 1 : nrep), block(256);
   if (check)
-    hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, true>), grid, block, 0, st, n, pos, vel, f, mass,
-                       vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity,
-                       sorted, inv, qs);
+    hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, true>), grid, block, 0, st, a, c);
   else
-    hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, false>), grid, block, 0, st, n, pos, vel, f, mass,
-                       vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed, noise_step, row0, ref, c, thresh2, flags, parity,
-                       sorted, inv, qs);
+    hipLaunchKernelGGL((md_step_kernel<R, SECOND, LANGEVIN, FIRST, false>), grid, block, 0, st, a, c);
+}
+
+template <typename R>
+void launch_md_step_bonded(const MdStepArgs<R> &a, const PairConsts<R> &c, const BondedArgs<R> &A, bool langevin,
+                           bool check, hipStream_t st) {
+  const dim3 grid((a.n + 255) / 256), block(256);
+  if (langevin && check) hipLaunchKernelGGL((md_step_bonded_kernel<R, true, true>), grid, block, 0, st, a, c, A);
+  else if (langevin) hipLaunchKernelGGL((md_step_bonded_kernel<R, true, false>), grid, block, 0, st, a, c, A);
+  else if (check) hipLaunchKernelGGL((md_step_bonded_kernel<R, false, true>), grid, block, 0, st, a, c, A);
+  else hipLaunchKernelGGL((md_step_bonded_kernel<R, false, false>), grid, block, 0, st, a, c, A);
 }
 
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
+  using R4 = typename Vec<R>::T4;
   const int n = ctx->d.natoms;
   const int nrep = (int)ctx->rep.size();
   const bool langevin = d->vcoeff_dev != nullptr;
-  const R *mass = (const R *)d->mass_dev, *vc = (const R *)d->vcoeff_dev;
   const R half_skin = (R)(0.5 * ctx->skin);
   const size_t stride = (size_t)n * 3;
+  MdStepArgs<R> a{};
+  a.n = n;
+  a.mass = (const R *)d->mass_dev;
+  a.vcoeff = (const R *)d->vcoeff_dev;
+  a.dt = (R)d->dt;
+  a.half_dt = (R)(0.5 * d->dt);
+  a.gamma = (R)d->gamma;
+  a.seed = d->seed;
+  a.thresh2 = half_skin * half_skin;
+  a.qs = ctx->qs.as<R>();
+  // where each replica's positions currently live (caller's tensor, or the context's second buffer while
+  // the bonded force is evaluated inside the integrator kernel) and whether the bonded force of the
+  // last evaluation is still owed to `forces`
+  std::vector<R *> cur(nrep);
+  std::vector<char> owed(nrep, 0);
+  for (int r = 0; r < nrep; ++r) cur[r] = (R *)d->pos_dev + r * stride;
+
   for (int it = 0; it <= d->niter; ++it) {
     const bool first = it < d->niter, second = it > 0;
+    a.noise_step = d->step0 + (uint64_t)(it > 0 ? it - 1 : 0);
     if (nrep > 1 && (ctx->algorithm == TMDHIP_ALGO_ALLPAIRS || ctx->d.terms == 0)) {
       // small systems are launch-bound: one launch of every kernel serves all replicas
-      R *pos = (R *)d->pos_dev, *vel = (R *)d->vel_dev, *f = (R *)d->forces_dev;
+      R *pos = (R *)d->pos_dev, *f = (R *)d->forces_dev;
       const PairConsts<R> c = make_consts<R>(ctx, d->box_host);
-      const uint64_t noise_step = d->step0 + (uint64_t)(it > 0 ? it - 1 : 0);
-#define TMD_MD(S, L, F)                                                                                       \
-  launch_md_step<R, S, L, F>(n, pos, vel, f, mass, vc, d->dt, d->gamma, d->seed, noise_step, 0, false, nullptr, \
-                             c, R(0), nullptr, 0, nullptr, nullptr, nullptr, st, nrep)
+      a.pos_in = a.pos_out = pos;
+      a.vel = (R *)d->vel_dev;
+      a.f = f;
+      a.row0 = 0;
       if (second && first) {
-        if (langevin) TMD_MD(true, true, true);
-        else TMD_MD(true, false, true);
+        if (langevin) launch_md_step<R, true, true, true>(a, c, false, st, nrep);
+        else launch_md_step<R, true, false, true>(a, c, false, st, nrep);
       } else if (first) {
-        TMD_MD(false, false, true);
+        launch_md_step<R, false, false, true>(a, c, false, st, nrep);
       } else {
-        if (langevin) TMD_MD(true, true, false);
-        else TMD_MD(true, false, false);
+        if (langevin) launch_md_step<R, true, true, false>(a, c, false, st, nrep);
+        else launch_md_step<R, true, false, false>(a, c, false, st, nrep);
       }
-#undef TMD_MD
       TMD_HIP(hipGetLastError());
       if (!first) continue;
       int flags_c = TMDHIP_WANT_FORCES;
@@ -1450,32 +1522,42 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
     for (int r = 0; r < nrep; ++r) {
       Replica &rp = ctx->rep[r];
       const double *box = d->box_host + 3 * r;
-      R *pos = (R *)d->pos_dev + r * stride, *vel = (R *)d->vel_dev + r * stride, *f = (R *)d->forces_dev + r * stride;
+      R *home = (R *)d->pos_dev + r * stride, *f = (R *)d->forces_dev + r * stride;
       const PairConsts<R> c = make_consts<R>(ctx, box);
       bool list = ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0;
       // the displacement test can ride on the integrator kernel when a list exists for this box
       const bool check = first && list && rp.have_list && box[0] == rp.box[0] && box[1] == rp.box[1] && box[2] == rp.box[2];
-      const int parity = (int)(rp.step & 1);
-      const uint64_t noise_step = d->step0 + (uint64_t)(it > 0 ? it - 1 : 0);
-      const uint64_t row0 = (uint64_t)r * (uint64_t)n;
-      const R *ref = rp.ref.as<R>();
-      int *flags = rp.flags.as<int>();
-#define TMD_MD(S, L, F) \
-  launch_md_step<R, S, L, F>(n, pos, vel, f, mass, vc, d->dt, d->gamma, d->seed, noise_step, row0, check, ref, c, \
-                             half_skin * half_skin, flags, parity, rp.sorted.as<typename Vec<R>::T4>(),          \
-                             rp.inv.as<int>(), ctx->qs.as<R>(), st)
-      if (second && first) {
-        if (langevin) TMD_MD(true, true, true);
-        else TMD_MD(true, false, true);
+      a.vel = (R *)d->vel_dev + r * stride;
+      a.f = f;
+      a.row0 = (uint64_t)r * (uint64_t)n;
+      a.ref = rp.ref.as<R>();
+      a.flags = rp.flags.as<int>();
+      a.parity = (int)(rp.step & 1);
+      a.sorted = rp.sorted.as<R4>();
+      a.inv = rp.inv.as<int>();
+      a.pos_in = a.pos_out = cur[r];
+      BondedArgs<R> A;
+      if (owed[r]) {
+        // second && first always holds here: the bonded force of step it-1 is evaluated from the
+        // undrifted positions in cur[r], the drifted ones go to the other buffer
+        if (!tmd::bonded_inline_args(ctx, box, A)) return fail("tmdhip_md_run: inline bonded state lost");
+        R *other = cur[r] == home ? rp.pos_alt.as<R>() : home;
+        a.pos_out = other;
+        launch_md_step_bonded<R>(a, c, A, langevin, check, st);
+        cur[r] = other;
+        owed[r] = 0;
+      } else if (second && first) {
+        if (langevin) launch_md_step<R, true, true, true>(a, c, check, st);
+        else launch_md_step<R, true, false, true>(a, c, check, st);
       } else if (first) {
-        TMD_MD(false, false, true);
+        launch_md_step<R, false, false, true>(a, c, check, st);
       } else {
-        if (langevin) TMD_MD(true, true, false);
-        else TMD_MD(true, false, false);
+        if (langevin) launch_md_step<R, true, true, false>(a, c, check, st);
+        else launch_md_step<R, true, false, false>(a, c, check, st);
       }
-#undef TMD_MD
       TMD_HIP(hipGetLastError());
       if (!first) continue;
+      R *pos = cur[r];
       // forces of step `it` (forces.py:122-319): nonbonded stores (list path) or accumulates into zeros
       int flags_c = TMDHIP_WANT_FORCES;
       double *en = nullptr;
@@ -1499,8 +1581,19 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       } else {
         TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride, st));
       }
-      TMD_TRY(tmdhip_compute_bonded(ctx, r, pos, box, f, en, flags_c, st));
+      // interior step of a list run with a light topology: the next integrator kernel evaluates this
+      // step's bonded force itself (md_step_bonded_kernel); `forces` holds the pair part until then
+      if (list && rp.have_list && it + 1 < d->niter && tmd::bonded_inline_args(ctx, box, A)) {
+        TMD_TRY(rp.pos_alt.ensure(sizeof(R) * stride));
+        owed[r] = 1;
+      } else {
+        TMD_TRY(tmdhip_compute_bonded(ctx, r, pos, box, f, en, flags_c, st));
+      }
     }
+  }
+  for (int r = 0; r < nrep; ++r) {
+    R *home = (R *)d->pos_dev + r * stride;
+    if (cur[r] != home) TMD_HIP(hipMemcpyAsync(home, cur[r], sizeof(R) * stride, hipMemcpyDeviceToDevice, st));
   }
   return 0;
 }
