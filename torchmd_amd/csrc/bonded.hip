@@ -58,11 +58,12 @@ struct Bonded {
   uint32_t terms14 = 0;
   int bonds_use_cutoff = 0;
   DevArr atom_off, atom_ent;
+  DevArr arec;  // AtomRec<R>[natoms][max_entries_per_atom] for light topologies
   DevArr bond_idx, bond_prm, angle_idx, angle_prm;
   DevArr dih_idx, dih_start, dih_prm, imp_idx, imp_start, imp_prm;
   DevArr p14_idx, p14_prm;
   void release() {
-    for (DevArr *a : {&entry_f, &atom_off, &atom_ent, &bond_idx, &bond_prm, &angle_idx, &angle_prm, &dih_idx, &dih_start,
+    for (DevArr *a : {&entry_f, &atom_off, &atom_ent, &arec, &bond_idx, &bond_prm, &angle_idx, &angle_prm, &dih_idx, &dih_start,
                       &dih_prm, &imp_idx, &imp_start, &imp_prm, &p14_idx, &p14_prm})
       a->release();
   }
@@ -111,8 +112,7 @@ __global__ __launch_bounds__(256) void bonded_atom_kernel(int natoms, BondedArgs
   R fx = 0, fy = 0, fz = 0;
   double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (a < natoms) {
-    for (int q = A.atom_off[a], qe = A.atom_off[a + 1]; q < qe; ++q)
-      eval_entry<R>(A, pos, (unsigned)A.atom_ent[q], fx, fy, fz, e);
+    eval_atom<R>(A, pos, a, fx, fy, fz, e);
     if (forces) {
       forces[3 * a + 0] += fx;
       forces[3 * a + 1] += fy;
@@ -277,6 +277,31 @@ int set_bonded(tmdhip_ctx *ctx, Bonded *b, const tmdhip_bonded_desc *d) {
   }
   TMD_TRY(b->atom_off.upload(off.data(), off.size()));
   TMD_TRY(b->atom_ent.upload(ent.data(), ent.size()));
+  if (b->max_entries_per_atom <= kAtomCentricLimit && b->nentries > 0) {
+    // per-atom records with the bond / angle partners and parameters inline (bonded_math.h: AtomRec)
+    const int K = b->max_entries_per_atom;
+    std::vector<AtomRec<R>> recs((size_t)n * K);
+    for (auto &r : recs) r = AtomRec<R>{kNoRec, 0, 0, R(0), R(0)};
+    const R *bprm = (const R *)d->bond_prm_host, *aprm = (const R *)d->angle_prm_host;
+    for (int a = 0; a < n; ++a)
+      for (size_t k = 0; k < per_atom[a].size(); ++k) {
+        const unsigned e = per_atom[a][k];
+        const unsigned kind = e >> 28;
+        const int role = (int)((e >> kIdxBits) & 3u), t = (int)(e & ((1u << kIdxBits) - 1u));
+        AtomRec<R> r{e, 0, 0, R(0), R(0)};
+        if (kind == KBOND) {
+          r.a = d->bond_idx_host[2 * t + (role == 0 ? 1 : 0)];
+          r.p0 = bprm[2 * t], r.p1 = bprm[2 * t + 1];
+        } else if (kind == KANGLE) {
+          const int32_t *ix = d->angle_idx_host + 3 * t;
+          r.a = role == 0 ? ix[1] : ix[0];
+          r.b = role == 2 ? ix[1] : ix[2];
+          r.p0 = aprm[2 * t], r.p1 = aprm[2 * t + 1];
+        }
+        recs[(size_t)a * K + k] = r;
+      }
+    TMD_TRY(b->arec.upload(recs.data(), recs.size()));
+  }
   b->terms14 = d->terms14;
   b->bonds_use_cutoff = d->bonds_use_cutoff;
   return 0;
@@ -294,6 +319,8 @@ R host_r2max(double cutoff) {
 
 template <typename R>
 void fill_args(tmdhip_ctx *ctx, const Bonded *b, const double *box, BondedArgs<R> &A) {
+  A.arec = b->arec.as<AtomRec<R>>();
+  A.arec_stride = b->max_entries_per_atom;
   A.atom_off = b->atom_off.as<int>();
   A.atom_ent = b->atom_ent.as<int>();
   A.bond_idx = b->bond_idx.as<int>();

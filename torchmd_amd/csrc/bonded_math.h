@@ -15,8 +15,23 @@ struct Box3 {
   R box[3], invbox[3];
 };
 
+// Per-atom record of the atom-centric kernels (light topologies): the entry word plus, for bonds and
+// angles, the partner atoms and the two parameters inline, so that evaluating an atom's terms is
+// "read my records -> read the partners' positions" instead of four dependent loads
+// (atom_off -> atom_ent -> idx/prm -> pos).  a/b: bond = (partner, -); angle = the two other atoms in
+// idx-column order.  Torsions and 1-4 pairs keep the table lookup through the term index in `ent`.
+template <typename R>
+struct AtomRec {
+  unsigned ent;  // kind << 28 | role << 26 | term index; kNoRec = unused slot
+  int a, b;
+  R p0, p1;
+};
+constexpr unsigned kNoRec = 0xFFFFFFFFu;
+
 template <typename R>
 struct BondedArgs {
+  const AtomRec<R> *arec;  // [natoms][arec_stride], null for heavy topologies
+  int arec_stride;
   const int *atom_off, *atom_ent;
   const int *bond_idx;
   const R *bond_prm;
@@ -67,15 +82,13 @@ __device__ __forceinline__ void dsincos(double a, double *s, double *c) { sincos
 // forces.py:122-143 + evaluate_bonds 494-503.  The reference drops bonds with dist > cutoff when a
 // cutoff is set (same decision arithmetic as the nonbonded filter).  role 0 = first atom.
 template <typename R>
-__device__ __forceinline__ void bond_term(const BondedArgs<R> &A, const R *__restrict__ pos, int t, int role,
-                                          R &fx, R &fy, R &fz, double &e) {
+__device__ __forceinline__ void bond_core(const BondedArgs<R> &A, const R *__restrict__ pos, int i, int j, R k0,
+                                          R d0, int role, R &fx, R &fy, R &fz, double &e) {
 #pragma clang fp contract(off)  // same rounding whether or not the energy is live (inline use)
-  const int i = A.bond_idx[2 * t], j = A.bond_idx[2 * t + 1];
   const V3<R> d = wrapped_delta(pos, i, j, A.b);
   const R r2 = norm2(d.x, d.y, d.z);
   if (!(r2 <= A.bond_r2max)) return;
   const R r = dsqrt(r2);
-  const R k0 = A.bond_prm[2 * t], d0 = A.bond_prm[2 * t + 1];
   const R x = r - d0;
   if (role == 0) e += (double)(k0 * x * x);
   const R fs = R(2) * k0 * x / r;  // unitvec * force_coeff ; F_i -= , F_j +=
@@ -85,15 +98,20 @@ __device__ __forceinline__ void bond_term(const BondedArgs<R> &A, const R *__res
   fz += sgn * d.z * fs;
 }
 
+template <typename R>
+__device__ __forceinline__ void bond_term(const BondedArgs<R> &A, const R *__restrict__ pos, int t, int role,
+                                          R &fx, R &fy, R &fz, double &e) {
+  bond_core<R>(A, pos, A.bond_idx[2 * t], A.bond_idx[2 * t + 1], A.bond_prm[2 * t], A.bond_prm[2 * t + 1], role, fx,
+               fy, fz, e);
+}
+
 // forces.py:145-161 + evaluate_angles 506-539.  roles 0,1,2 = idx columns (1 = vertex)
 template <typename R>
-__device__ __forceinline__ void angle_term(const BondedArgs<R> &A, const R *__restrict__ pos, int t, int role,
-                                           R &fx, R &fy, R &fz, double &e) {
+__device__ __forceinline__ void angle_core(const BondedArgs<R> &A, const R *__restrict__ pos, int a0, int a1,
+                                           int a2, R k0, R th0, int role, R &fx, R &fy, R &fz, double &e) {
 #pragma clang fp contract(off)  // same rounding whether or not the energy is live (inline use)
-  const int a0 = A.angle_idx[3 * t], a1 = A.angle_idx[3 * t + 1], a2 = A.angle_idx[3 * t + 2];
   const V3<R> r21 = wrapped_delta(pos, a0, a1, A.b);
   const V3<R> r23 = wrapped_delta(pos, a2, a1, A.b);
-  const R k0 = A.angle_prm[2 * t], th0 = A.angle_prm[2 * t + 1];
   const R dot = r23.x * r21.x + r23.y * r21.y + r23.z * r21.z;
   const R n21 = R(1) / dsqrt(r21.x * r21.x + r21.y * r21.y + r21.z * r21.z);
   const R n23 = R(1) / dsqrt(r23.x * r23.x + r23.y * r23.y + r23.z * r23.z);
@@ -116,6 +134,13 @@ __device__ __forceinline__ void angle_term(const BondedArgs<R> &A, const R *__re
   } else {
     fx -= f0x + f2x, fy -= f0y + f2y, fz -= f0z + f2z;
   }
+}
+
+template <typename R>
+__device__ __forceinline__ void angle_term(const BondedArgs<R> &A, const R *__restrict__ pos, int t, int role,
+                                           R &fx, R &fy, R &fz, double &e) {
+  angle_core<R>(A, pos, A.angle_idx[3 * t], A.angle_idx[3 * t + 1], A.angle_idx[3 * t + 2], A.angle_prm[2 * t],
+                A.angle_prm[2 * t + 1], role, fx, fy, fz, e);
 }
 
 // forces.py:163-183 / 238-258 + evaluate_torsion 542-605.  The terms of torsion t are rows
@@ -226,6 +251,37 @@ __device__ __forceinline__ void eval_entry(const BondedArgs<R> &A, const R *__re
                     e[TMDHIP_E_IMPROPERS]);
   } else {
     pair14_term<R>(A, pos, t, role, fx, fy, fz, e[TMDHIP_E_LJ], e[TMDHIP_E_ELECTROSTATICS]);
+  }
+}
+
+// the same, from the per-atom record of atom `self` (bit-identical: same core functions, same order)
+template <typename R>
+__device__ __forceinline__ void eval_rec(const BondedArgs<R> &A, const R *__restrict__ pos, int self,
+                                         const AtomRec<R> &rec, R &fx, R &fy, R &fz, double *e) {
+  const unsigned kind = rec.ent >> 28;
+  const int role = (int)((rec.ent >> kIdxBits) & 3u);
+  if (kind == KBOND) {
+    bond_core<R>(A, pos, role == 0 ? self : rec.a, role == 0 ? rec.a : self, rec.p0, rec.p1, role, fx, fy, fz,
+                 e[TMDHIP_E_BONDS]);
+  } else if (kind == KANGLE) {
+    const int a0 = role == 0 ? self : rec.a;
+    const int a1 = role == 1 ? self : (role == 0 ? rec.a : rec.b);
+    const int a2 = role == 2 ? self : rec.b;
+    angle_core<R>(A, pos, a0, a1, a2, rec.p0, rec.p1, role, fx, fy, fz, e[TMDHIP_E_ANGLES]);
+  } else {
+    eval_entry<R>(A, pos, rec.ent, fx, fy, fz, e);
+  }
+}
+
+// all bonded terms of atom `self` (atom-centric scheme)
+template <typename R>
+__device__ __forceinline__ void eval_atom(const BondedArgs<R> &A, const R *__restrict__ pos, int self, R &fx, R &fy,
+                                          R &fz, double *e) {
+  const AtomRec<R> *rec = A.arec + (size_t)self * A.arec_stride;
+  for (int k = 0; k < A.arec_stride; ++k) {
+    const AtomRec<R> r = rec[k];
+    if (r.ent == kNoRec) break;
+    eval_rec<R>(A, pos, self, r, fx, fy, fz, e);
   }
 }
 

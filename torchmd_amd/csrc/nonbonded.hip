@@ -955,8 +955,7 @@ __global__ void md_step_bonded_kernel(MdStepArgs<R> s, PairConsts<R> c, BondedAr
   if (i >= s.n) return;
   R fx = 0, fy = 0, fz = 0;
   double e[TMDHIP_NENERGY];  // energies are not wanted on interior steps (dead stores)
-  for (int q = A.atom_off[i], qe = A.atom_off[i + 1]; q < qe; ++q)
-    eval_entry<R>(A, s.pos_in, (unsigned)A.atom_ent[q], fx, fy, fz, e);
+  eval_atom<R>(A, s.pos_in, i, fx, fy, fz, e);
   const R fb[3] = {fx, fy, fz};
   md_step_atom<R, true, LANGEVIN, true, CHECK>(s, c, i, 0, s.row0, fb, true);
 }
