@@ -1032,6 +1032,8 @@ struct tmdhip_ctx {
   void *bonded = nullptr;
   // timing of the dominant kernel
   bool timing = false;
+  int timing_stride = 1;    // every n-th launch is timed
+  int64_t timing_seen = 0;  // launches since timing was enabled
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   double timing_ms = 0;
@@ -1447,7 +1449,10 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     TMD_HIP(hipMemsetAsync(pc, 0, sizeof(unsigned long long), st));
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->timing) {
+  // every `timing_stride`-th launch is bracketed by events: an event pair costs ~3 us of stream time,
+  // so timing every launch would slow down the very loop being measured
+  const bool timed = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0;
+  if (timed) {
     if (ctx->events_used >= 4096) TMD_TRY(tmdhip_timing_read(ctx, nullptr, nullptr, 0));
     if (ctx->events_used == ctx->events.size()) {
       hipEvent_t a, b;
@@ -1465,7 +1470,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, overwrite, energies, pc, st)));
   else
     TMD_TRY((launch_list_pair<R, false>(ctx, rp, c, f, overwrite, energies, pc, st)));
-  if (ctx->timing) TMD_HIP(hipEventRecord(e1, st));
+  if (timed) TMD_HIP(hipEventRecord(e1, st));
   if (pc) hipLaunchKernelGGL(halve_count_kernel, dim3(1), dim3(1), 0, st, pc);
   return 0;
 }
@@ -1874,6 +1879,8 @@ int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica) {
 int tmdhip_timing_enable(tmdhip_ctx *ctx, int on) {
   if (!ctx) return fail("tmdhip_timing_enable: null ctx");
   ctx->timing = on != 0;
+  ctx->timing_stride = on > 1 ? on : 1;
+  ctx->timing_seen = 0;
   return 0;
 }
 

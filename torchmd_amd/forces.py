@@ -524,9 +524,10 @@ class Forces:
             "ncell": tuple(st.ncell),
         }
 
-    def enable_timing(self, pos, on=True):
+    def enable_timing(self, pos, on=True, every=1):
+        """HIP events around every `every`-th launch of the list pair kernel (an event pair costs ~3 us)."""
         eng = self._engine(pos.detach())
-        L.check(eng.lib.tmdhip_timing_enable(eng.ctx, 1 if on else 0))
+        L.check(eng.lib.tmdhip_timing_enable(eng.ctx, max(1, int(every)) if on else 0))
 
     def read_timing(self, pos, reset=True):
         """(total ms, launches) of the list pair kernel measured with HIP events on the launch stream."""
