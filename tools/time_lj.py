@@ -36,7 +36,7 @@ def main():
     f.compute(s.pos, s.box, s.forces)
     integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=85.0)
     integ.step(200)
-    f.enable_timing(s.pos, True)
+    f.enable_timing(s.pos, True, every=16)
     f.read_timing(s.pos)
     r0 = f.stats(s.pos)["n_rebuilds"]
     torch.cuda.synchronize()

@@ -327,22 +327,29 @@ __device__ __forceinline__ size_t list_slot(const ListGeom &lg, int a, int k) {
 // chunk of 64 candidates the wave loops over the atoms i of its cell (wave-uniform data), tests
 // |d|^2 <= rlist^2 and the exclusions, and appends the hits of atom i with a ballot / prefix-popcount
 // compaction.  Entry order per atom is fixed by the stencil order -> lists are bit-reproducible.
-template <typename R>
+template <typename R, bool LOOP>
 __global__ __launch_bounds__(64) void build_list_kernel(
     int n, const typename Vec<R>::T4 *__restrict__ sorted, const int *__restrict__ stype,
     const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
-    unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag) {
+    unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
+    int ncell) {
   if (*flag == 0) return;
   using R4 = typename Vec<R>::T4;
   __shared__ int seg_start[128];
   __shared__ int seg_prefix[129];
   __shared__ int seg_code[128];  // periodic image of the stencil cell: 2 bits per axis, 0:-L 1:0 2:+L
   const int lane = threadIdx.x;
-  const int cell = blockIdx.x;
+  int wmax = 0;
+  // LOOP: the grid is capped and a block walks several cells (a launch that returns at once on the steps
+  // without a rebuild still costs time proportional to its block count: the 343k cells of the 10^6-atom
+  // LJ box = 100 us per step).  Systems with fewer cells keep one cell per block (no loop: faster code).
+  int cell = blockIdx.x;
+  do {
   const int cs = cell_start[cell], ce = cell_start[cell + 1];
   if (cell == 0 && lane == 0) status[1] += 1;  // flags[3]: number of rebuilds
-  if (cs == ce) return;
+  if (cs == ce) continue;
+  __syncthreads();  // LDS tables of the previous cell are no longer read
   const int cz = cell % g.nc[2], cy = (cell / g.nc[2]) % g.nc[1], cx = cell / (g.nc[2] * g.nc[1]);
   // stencil segments: a segment is a run of cells along z (contiguous in the cell-sorted arrays) of one
   // (x, y) stencil row, clipped to the cells that can hold an atom within rlist of this cell
@@ -429,7 +436,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   __shared__ int s_eb[64], s_more[64], s_cnt[64];
   const int apw_shift = 6 - lg.lpa_shift;
   const unsigned kmask = (unsigned)lg.lpa - 1u;
-  int wmax = 0;
   for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
     const int iend = min(ib + 64, ce);
     const int ni = iend - ib;
@@ -556,6 +562,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     if (lane < ni) nneigh[ib + lane] = min(mycnt, lg.maxn);
     wmax = max(wmax, lane < ni ? mycnt : 0);
   }
+  } while (LOOP && (cell += gridDim.x) < ncell);
   // flags[2] = largest neighbour count ever seen; > maxn means a list was truncated (overflow)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
@@ -1163,7 +1170,12 @@ bool plan_grid(const tmdhip_ctx *ctx, const double *box, const double *lo, const
   // candidate volume but the build takes 345 us instead of 200: a build wave works on one cell and its
   // fixed costs (stencil set-up, staging the cell's atoms and exclusions, one candidate load per chunk)
   // are then amortised over 4 atoms instead of 14.  The kernel supports it (zreach), the planner stops at 2.
-  for (int m = 2; m >= 1; --m) {
+  int mmax = 2;
+  if (const char *e = std::getenv("TMDHIP_STENCIL")) {  // tuning override: largest stencil half-width tried
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 3) mmax = v;
+  }
+  for (int m = mmax; m >= 1; --m) {
     bool ok = true;
     int nc[3];
     for (int k = 0; k < 3; ++k) {
@@ -1366,10 +1378,17 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
     hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.order.as<int>(),
                        rp.sorted.as<R4>(), flag);
   const R rl = (R)ctx->rlist;
-  hipLaunchKernelGGL((build_list_kernel<R>), dim3(rp.ncell), dim3(64), 0, st, n, rp.sorted.as<R4>(),
-                     rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
-                     ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
-                     rp.nneigh.as<int>(), flags + 2, flag);
+  constexpr int kMaxBuildBlocks = 16384;
+  if (rp.ncell <= kMaxBuildBlocks)
+    hipLaunchKernelGGL((build_list_kernel<R, false>), dim3(rp.ncell), dim3(64), 0, st, n, rp.sorted.as<R4>(),
+                       rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
+                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
+                       rp.nneigh.as<int>(), flags + 2, flag, rp.ncell);
+  else
+    hipLaunchKernelGGL((build_list_kernel<R, true>), dim3(kMaxBuildBlocks), dim3(64), 0, st, n, rp.sorted.as<R4>(),
+                       rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
+                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
+                       rp.nneigh.as<int>(), flags + 2, flag, rp.ncell);
   TMD_HIP(hipGetLastError());
   return 0;
 }
