@@ -50,7 +50,7 @@ def ns_per_day(steps, seconds, timestep_fs=TIMESTEP_FS):
     return steps / seconds * timestep_fs * 1e-6 * 86400.0  # reference run.py:19,279 (FS2NS)
 
 
-def build_system(nside, device, dtype, seed):
+def build_system(nside, device, dtype, seed, skin=None):
     from torchmd_amd.builders import tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import maxwell_boltzmann
@@ -64,7 +64,7 @@ def build_system(nside, device, dtype, seed):
     system.set_box(box)
     torch.manual_seed(seed)
     system.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
-    forces = Forces(par, terms=TERMS, cutoff=CUTOFF, rfa=True)
+    forces = Forces(par, terms=TERMS, cutoff=CUTOFF, rfa=True, **({} if skin is None else {"skin": skin}))
     return mol, par, system, forces, box
 
 
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--nside", type=int, default=32, help="molecules per box edge (32 -> 98 304 atoms)")
     ap.add_argument("--relax-steps", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skin", type=float, default=None, help="Verlet skin in A (default: the library's 1.2)")
     args = ap.parse_args()
 
     from torchmd_amd.integrator import Integrator
@@ -131,7 +132,7 @@ def main():
     fan = ReplicaFanout(total_replicas=world, device=device)
 
     dtype = torch.float32
-    mol, par, system, forces, box = build_system(args.nside, device, dtype, seed=1 + rank)
+    mol, par, system, forces, box = build_system(args.nside, device, dtype, seed=1 + rank, skin=args.skin)
     fan.check_same_topology(mol.bonds, mol.angles, mol.charge)
     natoms = mol.numAtoms
 
