@@ -313,3 +313,48 @@ def test_replica_batched_md_matches_single_replica_runs():
         assert abs(ekb[r] - ek1[0]) < 1e-9 * max(1.0, abs(ek1[0]))
         assert abs(epb[r] - ep1[0]) < 1e-9 * max(1.0, abs(ep1[0]))
     assert np.abs(pb[0] - pb[2]).max() > 1e-3
+
+
+def test_replica_batched_langevin_equals_stepwise_loop():
+    """Batched all-pairs MD (one launch per kernel for all replicas) with the Langevin thermostat against
+    the step-by-step Python loop over the stateless integrator kernels: same noise rows (replica * natoms +
+    atom), same trajectory."""
+    import numpy as np
+
+    from _golden import GoldenParameters, load
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator
+    from torchmd_amd.systems import System
+
+    class ZeroExternal:  # forces the Integrator onto its generic Python loop
+        def calculate(self, pos, box):
+            return torch.zeros(pos.shape[0], device=pos.device), torch.zeros_like(pos)
+
+    g = load("water291")
+    dev = torch.device("cuda:0")
+    par = GoldenParameters(g, torch.float64)
+    pos0 = np.asarray(g["pos"], dtype=np.float64).reshape(-1, 3)
+    box0 = np.asarray(g["box"], dtype=np.float64).reshape(-1)[:3]
+    n, R = pos0.shape[0], 3
+    rng = np.random.default_rng(3)
+    starts = np.stack([pos0 + 0.02 * r * rng.standard_normal(pos0.shape) for r in range(R)], axis=2)
+    vel0 = torch.tensor(0.01 * rng.standard_normal((R, n, 3)))
+    out = []
+    for ext in (None, ZeroExternal()):
+        s = System(n, R, torch.float64, dev)
+        s.set_positions(starts)
+        s.set_box(np.stack([box0 * (1 + 0.01 * r) for r in range(R)], axis=1))
+        s.set_velocities(vel0)
+        f = Forces(par, terms=["bonds", "angles", "electrostatics", "lj"], cutoff=7.3, rfa=True, external=ext)
+        f.compute(s.pos, s.box, s.forces)
+        torch.manual_seed(9)
+        integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+        res = [integ.step(6), integ.step(1)]
+        assert f.stats(s.pos)["algorithm"] == "allpairs"
+        out.append((s.pos.cpu(), s.vel.cpu(), res))
+    (p0, v0, r0), (p1, v1, r1) = out
+    # the all-pairs kernel combines partial forces with float atomics: equality up to summation order
+    assert (p0 - p1).abs().max().item() < 1e-10 and (v0 - v1).abs().max().item() < 1e-10
+    for a, b in zip(r0, r1):
+        assert np.allclose(a[0], b[0], rtol=1e-9) and np.allclose(a[1], b[1], rtol=1e-9)
+    assert (p0[0] - p0[2]).abs().max().item() > 1e-3
