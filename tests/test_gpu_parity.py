@@ -561,3 +561,44 @@ def test_replica_batch_matches_single_replica_calls(which):
         assert (Fb[r] - F1[0]).abs().max().item() <= 1e-9 * max(1.0, F1.abs().max().item()), r
     # the three replicas really differ
     assert abs(pots_b[0]["lj"] - pots_b[2]["lj"]) > 1e-3
+
+
+@pytest.mark.parametrize("mode", ["reference", "exact"])
+def test_packed_kernel_switching_variants(mode):
+    """LJ switching in the packed fp32 list kernel (both force flavours, with and without energies)
+    against the generic fp64 list kernel on the 5 184-atom water box.  LJ only: the switched LJ force
+    vanishes at the cutoff, so the handful of pairs whose cutoff decision differs between fp32 and fp64
+    coordinates does not matter (with the reaction field each such pair is a 0.05 kcal/mol/A jump); the
+    reference flavour with LJ + reaction field is checked against the fp32 oracle by
+    test_celllist_term_variants_vs_oracle."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev = _dev()
+    mol, pos, box = tip3p_box(12, seed=17)
+    terms = ["lj"]
+    out = {}
+    for prec in ("f64", "f32"):
+        dt = PREC[prec]
+        par = Parameters(water_forcefield(mol), mol, ["lj", "electrostatics", "bonds", "angles"], precision=dt)
+        f = Forces(par, terms=terms, cutoff=9.0, switch_dist=7.5, algorithm="celllist", switch_mode=mode)
+        p, b = pos_tensor(pos, 1, dt, dev), box_tensor(box, 1, dt, dev)
+        F_only = torch.zeros_like(p)
+        f._evaluate(p, b, F_only, False, True)  # forces-only variant
+        F = torch.zeros_like(p)
+        pots = f.compute(p, b, F, returnDetails=True)  # energy variant
+        out[prec] = (F_only.double().cpu(), F.double().cpu(), pots[0])
+    F64, F32 = out["f64"], out["f32"]
+    scale = 1.0 + F64[1].abs()
+    assert ((F64[0] - F64[1]).abs() / scale).max().item() < 1e-10
+    assert ((F32[0] - F64[1]).abs() / scale).max().item() < 2e-4  # fp32 against fp64 arithmetic
+    assert ((F32[1] - F64[1]).abs() / scale).max().item() < 2e-4
+    for t in terms:
+        assert abs(F32[2][t] - F64[2][t]) <= 2e-5 * 50 * max(1.0, abs(F64[2][t])), t
+    # the switch really acts: energies differ from the unswitched ones
+    par = Parameters(water_forcefield(mol), mol, ["lj", "electrostatics", "bonds", "angles"], precision=torch.float32)
+    f0 = Forces(par, terms=terms, cutoff=9.0, algorithm="celllist")
+    p, b = pos_tensor(pos, 1, torch.float32, dev), box_tensor(box, 1, torch.float32, dev)
+    e0 = f0.compute(p, b, torch.zeros_like(p), returnDetails=True)[0]
+    assert abs(e0["lj"] - F32[2]["lj"]) > 1.0

@@ -720,7 +720,7 @@ __device__ __forceinline__ v2f min_image2(v2f d, float box, float invbox) {
   return __builtin_elementwise_fma(-k, v2f{box, box}, d);
 }
 
-template <int LPA, bool LJ, bool ELEC, bool ENERGY>
+template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH>
 __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
@@ -769,6 +769,7 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   const char *tbase = reinterpret_cast<const char *>(stab);
   const v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, piz = {pi.z, pi.z}, piw = {pi.w, pi.w};
   const float two_krf = 2.0f * c.krf;
+  const float sw_ir = c.inv_switch_range, sw_t0 = -c.switch_dist * c.inv_switch_range;
 
   v2f fx = {0.f, 0.f}, fy = {0.f, 0.f}, fz = {0.f, 0.f};
   v2f e_lj = {0.f, 0.f}, e_el = {0.f, 0.f};  // per-lane fp32 partial sums (~55 pairs), reduced in fp64
@@ -802,22 +803,41 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
       const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
       const bool h0 = valid[u] && (r2.x <= c.r2max), h1 = valid[u + 1] && (r2.y <= c.r2max);
       // forces only: rejected entries may produce inf/NaN below, the final select discards them
-      const v2f r2s = ENERGY ? v2f{h0 ? r2.x : 1.0f, h1 ? r2.y : 1.0f} : r2;
+      const v2f r2s = ENERGY ? v2f{h0 ? r2.x : 1.0f, h1 ? r2.y : 1.0f} : r2;  // (SWITCH: still discarded)
       const v2f rinv = {__frsqrt_rn(r2s.x), __frsqrt_rn(r2s.y)};
       const v2f rinv2 = rinv * rinv;
       const v2f rinv6 = rinv2 * rinv2 * rinv2;
       // (dE_lj/dr + dE_el/dr) / r  with a12 = -12 A, b6 = 6 B; two_krf = 0 gives plain Coulomb
       v2f fs = {0.f, 0.f};
+      v2f sw = {1.f, 1.f};  // switching function S(r) of the LJ term (forces.py:402-412), 1 below switch_dist
       if (LJ) {
         const v2f a12 = {ab[u].x, ab[u + 1].x}, b6 = {ab[u].y, ab[u + 1].y};
         fs = __builtin_elementwise_fma(a12, rinv6, b6) * (rinv6 * rinv2);
+        if (SWITCH) {
+          // t = (r - r_s)/(r_c - r_s) clamped at 0: S = 1 + t^3 (-10 + t (15 - 6 t)),
+          // S' = t^2 (-30 + t (60 - 30 t)) / (r_c - r_s);  (dE/dr)/r = S f + E S' x, x = 1/r (exact) or
+          // 1/r^2 (the reference's explicit-force expression divides the switching term by r once more)
+          const v2f r = r2s * rinv;
+          v2f t = __builtin_elementwise_fma(r, v2f{sw_ir, sw_ir}, v2f{sw_t0, sw_t0});
+          t = v2f{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f)};
+          const v2f t2 = t * t;
+          const v2f p = __builtin_elementwise_fma(t, __builtin_elementwise_fma(t, v2f{-6.f, -6.f}, v2f{15.f, 15.f}),
+                                                  v2f{-10.f, -10.f});
+          sw = __builtin_elementwise_fma(t2 * t, p, v2f{1.f, 1.f});
+          const v2f dq = __builtin_elementwise_fma(
+              t, __builtin_elementwise_fma(t, v2f{-30.f * sw_ir, -30.f * sw_ir}, v2f{60.f * sw_ir, 60.f * sw_ir}),
+              v2f{-30.f * sw_ir, -30.f * sw_ir});
+          const v2f elj = (__builtin_elementwise_fma(a12 * (-1.0f / 12.0f), rinv6, b6 * (-1.0f / 6.0f))) * rinv6;
+          const v2f x = c.switch_reference_mode ? rinv2 : rinv;
+          fs = __builtin_elementwise_fma(sw, fs, elj * (t2 * dq) * x);
+        }
       }
       if (ELEC) fs += (piw * pjw) * (two_krf - rinv2 * rinv);
       if (ENERGY) {
         const v2f hm = {h0 ? 1.0f : 0.0f, h1 ? 1.0f : 0.0f};
         if (LJ) {  // E = (A r^-6 - B) r^-6 with the table holding (-12 A, 6 B)
           const v2f a12 = {ab[u].x, ab[u + 1].x}, b6 = {ab[u].y, ab[u + 1].y};
-          e_lj += hm * ((a12 * (-1.0f / 12.0f)) * rinv6 - b6 * (1.0f / 6.0f)) * rinv6;
+          e_lj += hm * sw * ((a12 * (-1.0f / 12.0f)) * rinv6 - b6 * (1.0f / 6.0f)) * rinv6;
         }
         if (ELEC) e_el += hm * (piw * pjw) * (rinv + c.krf * r2s - c.crf);  // krf = crf = 0: plain Coulomb
       }
@@ -1259,14 +1279,20 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const size_t shmem = (size_t)ctx->d.ntypes * ctx->d.ntypes * sizeof(R2);
   // packed-fp32 kernel covers LJ and/or electrostatics (reaction field or plain Coulomb) without switching
   const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
-  const bool fast = only_lj_el && !c.switch_on;
+  const bool fast = only_lj_el;  // (switching, if any, acts on the LJ term and is a kernel variant)
   if constexpr (std::is_same<R, float>::value) {
     // packed-fp32 kernel: needs 32-bit byte offsets into sorted_xyzq and the 7-bit type field
     if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= 128 && n < (1 << 24)) {
       const size_t shfast = shmem + 2048;  // garbage type fields of padding entries stay inside the allocation
       const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
-#define TMD_LAUNCH_FAST_T(L, A, B)                                                                                  \
-  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L, A, B, ENERGY>), dim3((blocks + 7) / 8 * 8), dim3(256), shfast, st, n, \
+#define TMD_LAUNCH_FAST_T(L, A, B)       \
+  if (c.switch_on && A) {               \
+    TMD_LAUNCH_FAST_S(L, A, B, true);   \
+  } else {                              \
+    TMD_LAUNCH_FAST_S(L, A, B, false);  \
+  }
+#define TMD_LAUNCH_FAST_S(L, A, B, S)                                                                               \
+  hipLaunchKernelGGL((list_pair_fast_f32_kernel<L, A, B, ENERGY, S>), dim3((blocks + 7) / 8 * 8), dim3(256), shfast, st, n, \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
                      rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,                   \
                      ctx->escratch.as<double>())
@@ -1289,6 +1315,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
       }
 #undef TMD_LAUNCH_FAST
 #undef TMD_LAUNCH_FAST_T
+#undef TMD_LAUNCH_FAST_S
       TMD_HIP(hipGetLastError());
       if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
       return 0;
@@ -1300,7 +1327,8 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
                      ctx->tab.as<R2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
                      overwrite, ctx->escratch.as<double>(), paircount)
   // the generic kernel's branch-free FAST=1 body hard-codes LJ + electrostatics (krf = 0: plain Coulomb)
-  const bool fast_generic = fast && !ENERGY && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS);
+  const bool fast_generic =
+      fast && !c.switch_on && !ENERGY && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS);
 #define TMD_LAUNCH_LPA(L)     \
   if (fast_generic) {         \
     TMD_LAUNCH(L, 1);         \
