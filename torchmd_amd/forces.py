@@ -88,11 +88,25 @@ class _Engine:
         need_tab = terms & (L.TERM_LJ | L.TERM_REPULSION | L.TERM_REPULSIONCG)
         if need_tab:
             A, B = owner._lj_tables()
-            d.ntypes = int(A.shape[0])
-            d.types_host = ptr(np.ascontiguousarray(par.mapped_atom_types.detach().cpu().numpy().astype(np.int32)))
-            d.lj_A_host = ptr(_np_real(A, dtype))
-            d.lj_B_host = ptr(_np_real(B, dtype))
+            A_np, B_np = _np_real(A, dtype), _np_real(B, dtype)
+            types = par.mapped_atom_types.detach().cpu().numpy().astype(np.int64)
+            # Type names that share their LJ parameters (most of a protein force field's) are merged into
+            # one class: the pair kernels keep the [T,T] table in LDS, so a smaller T means more resident
+            # waves.  Rows of (A | B) identical  <=>  same sigma and epsilon  <=>  identical columns.
+            _, first, inverse = np.unique(np.concatenate([A_np, B_np], axis=1), axis=0, return_index=True,
+                                          return_inverse=True)
+            inverse = np.asarray(inverse).reshape(-1)
+            if len(first) < A_np.shape[0]:
+                A_np = np.ascontiguousarray(A_np[np.ix_(first, first)])
+                B_np = np.ascontiguousarray(B_np[np.ix_(first, first)])
+                types = inverse[types]
+            self.ntypes = int(A_np.shape[0])
+            d.ntypes = self.ntypes
+            d.types_host = ptr(np.ascontiguousarray(types.astype(np.int32)))
+            d.lj_A_host = ptr(A_np)
+            d.lj_B_host = ptr(B_np)
         else:
+            self.ntypes = 1
             d.ntypes = 1
             d.types_host = ptr(np.zeros(n, dtype=np.int32))
         d.charges_host = ptr(_np_real(par.charges, dtype))
