@@ -182,6 +182,14 @@ typedef struct tmdhip_md_desc {
 } tmdhip_md_desc;
 int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
 
+/* Atomic systems only (no exclusions, no bonded terms): replace the atom set of the context — new count,
+ * types and charges; the LJ table and all options stay — and mark atoms with index >= nactive (<= 0: none)
+ * as passive: they act on the others but get no neighbour list and zero force.  Used by the spatial domain
+ * decomposition (a brick's own atoms followed by its halo images) at every atom migration instead of
+ * re-creating the context; synchronises the device; the next compute re-plans and rebuilds. */
+int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, const void *charges_host,
+                        int nactive);
+
 /* Drop the neighbour list of a replica: the next tmdhip_compute_nonbonded rebuilds it (used after the
  * caller has changed positions out of band, and by the rebuild timing tool). */
 int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica);

@@ -67,5 +67,17 @@ t0 = time.perf_counter()
 ds.step(N, timestep_fs=1.0)
 torch.cuda.synchronize()
 print(f"unsynchronised loop: {(time.perf_counter() - t0) / N * 1e6:.1f} us/step")
+if len(sys.argv) > 2:  # profile of one forced migration
+    import cProfile
+    import pstats
+
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    ds.migrate()
+    ds.compute_forces()
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
 d.forces_engine.close()
 dist.destroy_process_group()

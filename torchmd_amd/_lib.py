@@ -141,6 +141,7 @@ SIGNATURES = {
     "tmdhip_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "tmdhip_md_run": (C.c_int, [C.c_void_p, C.POINTER(MdDesc), C.c_void_p]),
     "tmdhip_invalidate_list": (C.c_int, [C.c_void_p, C.c_int]),
+    "tmdhip_update_atoms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "tmdhip_get_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Stats)]),
     "tmdhip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tmdhip_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

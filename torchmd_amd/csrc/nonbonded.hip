@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
-    int ncell) {
+    int ncell, int nactive) {
   if (*flag == 0) return;
   using R4 = typename Vec<R>::T4;
   __shared__ int seg_start[128];
@@ -452,6 +452,8 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       if constexpr (sizeof(R) == 4) p.w = __uint_as_float(rowoff);
       else p.w = __longlong_as_double((long long)rowoff);
       const int oi = order[a];
+      // passive atoms (original index >= nactive: halo images of a domain) get no list: parked out of reach
+      if (oi >= nactive) p.x = (R)-1e18;
       const int eb = excl_off[oi], ne = excl_off[oi + 1] - eb;
       s_rec0[lane] = p;
       s_eb[lane] = eb + (EXS - 1);
@@ -1054,6 +1056,8 @@ struct tmdhip_ctx {
   DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
   std::vector<double> boxes_host;  // what `boxes` currently holds
   int max_excl = 0;
+  int nactive = 0x7fffffff;  // atoms with original index >= nactive get empty lists (tmdhip_update_atoms)
+  int nexcl = 0;             // entries of the exclusion CSR
   std::vector<Replica> rep;
   // bonded part lives in bonded.hip
   void *bonded = nullptr;
@@ -1411,12 +1415,12 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
     hipLaunchKernelGGL((build_list_kernel<R, false>), dim3(rp.ncell), dim3(64), 0, st, n, rp.sorted.as<R4>(),
                        rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
                        ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
-                       rp.nneigh.as<int>(), flags + 2, flag, rp.ncell);
+                       rp.nneigh.as<int>(), flags + 2, flag, rp.ncell, ctx->nactive);
   else
     hipLaunchKernelGGL((build_list_kernel<R, true>), dim3(kMaxBuildBlocks), dim3(64), 0, st, n, rp.sorted.as<R4>(),
                        rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
                        ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
-                       rp.nneigh.as<int>(), flags + 2, flag, rp.ncell);
+                       rp.nneigh.as<int>(), flags + 2, flag, rp.ncell, ctx->nactive);
   TMD_HIP(hipGetLastError());
   return 0;
 }
@@ -1767,6 +1771,7 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
         return cleanup(fail("tmdhip_create: exclusion rows must be sorted and unique"));
     }
   }
+  ctx->nexcl = nex;
   if (ctx->excl_off.ensure(sizeof(int) * (n + 1))) return cleanup(-1);
   if (ctx->excl_idx.ensure(sizeof(int) * std::max(nex, 1))) return cleanup(-1);
   (void)hipMemcpy(ctx->excl_off.p, desc->excl_offsets_host, sizeof(int) * (n + 1), hipMemcpyHostToDevice);
@@ -1857,6 +1862,41 @@ int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, 
   }
   return f32 ? launch_allpairs<float>(ctx, pos_dev, box_host, forces_dev, energies_dev, flags, pc, st)
              : launch_allpairs<double>(ctx, pos_dev, box_host, forces_dev, energies_dev, flags, pc, st);
+}
+
+int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, const void *charges_host,
+                        int nactive) {
+  if (!ctx || !types_host) return fail("tmdhip_update_atoms: null argument");
+  if (natoms <= 0 || natoms >= (1 << 24)) return fail("tmdhip_update_atoms: natoms out of range");
+  if (ctx->nexcl != 0 || ctx->bonded) return fail("tmdhip_update_atoms: only for atomic systems (no exclusions, no bonded terms)");
+  if ((ctx->d.terms & TMDHIP_TERM_ELECTROSTATICS) && !charges_host)
+    return fail("tmdhip_update_atoms: electrostatics needs charges");
+  for (int i = 0; i < natoms; ++i)
+    if (types_host[i] < 0 || types_host[i] >= ctx->d.ntypes) return fail("tmdhip_update_atoms: atom type out of range");
+  TMD_HIP(hipDeviceSynchronize());  // nothing may still be reading the old per-atom arrays
+  const int n = natoms;
+  ctx->d.natoms = n;
+  ctx->nactive = nactive > 0 ? nactive : 0x7fffffff;
+  TMD_TRY(ctx->types.ensure(sizeof(int) * n));
+  TMD_HIP(hipMemcpy(ctx->types.p, types_host, sizeof(int) * n, hipMemcpyHostToDevice));
+  const double s = std::sqrt(kElecFactor);
+  TMD_TRY(ctx->qs.ensure((size_t)ctx->real_size * n));
+  if (ctx->d.dtype == TMDHIP_F32) {
+    std::vector<float> q(n);
+    for (int i = 0; i < n; ++i) q[i] = charges_host ? (float)((double)((const float *)charges_host)[i] * s) : 0.f;
+    TMD_HIP(hipMemcpy(ctx->qs.p, q.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+  } else {
+    std::vector<double> q(n);
+    for (int i = 0; i < n; ++i) q[i] = charges_host ? ((const double *)charges_host)[i] * s : 0.0;
+    TMD_HIP(hipMemcpy(ctx->qs.p, q.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  TMD_TRY(ctx->excl_off.ensure(sizeof(int) * ((size_t)n + 1)));
+  TMD_HIP(hipMemset(ctx->excl_off.p, 0, sizeof(int) * ((size_t)n + 1)));
+  for (auto &rp : ctx->rep) {  // the next compute re-plans the grid, re-sizes the buffers and rebuilds
+    rp.have_list = false;
+    rp.lg.maxn = 0;
+  }
+  return 0;
 }
 
 int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {

@@ -279,14 +279,19 @@ class Domain:
     def _build_engine(self, nhalo):
         from .forces import Forces
 
-        if self.forces_engine is not None:
-            self.forces_engine.close()
         q = torch.cat([self.charges, self.halo_charges]).cpu()
         t = torch.cat([self.types, self.halo_types]).cpu()
         m = torch.cat([self.masses, torch.ones(nhalo, dtype=self.dtype, device=self.device)]).cpu()
         par = _local_parameters(q, t, m, self.A, self.B)
-        self.forces_engine = Forces(par, terms=self.terms, cutoff=self.cutoff, **self.engine_kwargs)
         n = self.nown + nhalo
+        if self.forces_engine is None:
+            self.forces_engine = Forces(par, terms=self.terms, cutoff=self.cutoff, **self.engine_kwargs)
+            # create the context now, then mark the halo atoms passive
+            self.forces_engine._engine(torch.empty(1, n, 3, dtype=self.dtype, device=self.device))
+        # the device context and its buffers survive migrations: only the atom set is swapped; halo atoms
+        # (index >= nown) are passive: they get no neighbour list, so neither forces nor energy are
+        # computed on them (own-halo pairs then count half in the energy, as they should)
+        self.forces_engine.update_atoms(par, nactive=self.nown)
         self.local_forces = torch.zeros(1, n, 3, dtype=self.dtype, device=self.device)
         self.zero_box = torch.zeros(1, 3, 3, dtype=self.dtype, device=self.device)
 

@@ -67,6 +67,8 @@ class _Engine:
         self.lib = lib
         self.ctx = C.c_void_p()
         self.nreplicas = nreplicas
+        self.dtype = dtype
+        self.type_map = None  # type id -> LJ class when classes were merged
         par = owner.par
         n = owner.natoms
         keep = []  # numpy arrays that must outlive the create call
@@ -100,6 +102,7 @@ class _Engine:
                 A_np = np.ascontiguousarray(A_np[np.ix_(first, first)])
                 B_np = np.ascontiguousarray(B_np[np.ix_(first, first)])
                 types = inverse[types]
+                self.type_map = inverse
             self.ntypes = int(A_np.shape[0])
             d.ntypes = self.ntypes
             d.types_host = ptr(np.ascontiguousarray(types.astype(np.int32)))
@@ -283,6 +286,31 @@ class Forces:
         self._engines = {}
         self._box_cache = None
         self._ava_idx = None
+
+    def update_atoms(self, parameters, nactive=None):
+        """Atomic systems only (no bonded terms, no exclusions): swap in a new atom set — `parameters`
+        with the same LJ table but other atoms (count, types, charges) — keeping the device contexts and
+        their buffers; atoms with index >= `nactive` become passive (they act on the others but get no
+        neighbour list and zero force).  Used by the domain decomposition at every atom migration."""
+        if any(t in self.energies for t in self.bonded) or len(self._excl_csr[1]):
+            raise RuntimeError("update_atoms is only available for atomic systems")
+        self.par = parameters
+        self.natoms = len(parameters.masses)
+        self._excl_csr = (np.zeros(self.natoms + 1, dtype=np.int32), np.zeros(0, dtype=np.int32))
+        self._ava_idx = None
+        types0 = parameters.mapped_atom_types.detach().cpu().numpy().astype(np.int64)
+        for eng in self._engines.values():
+            types = np.ascontiguousarray((eng.type_map[types0] if eng.type_map is not None else types0).astype(np.int32))
+            if types.max(initial=0) >= eng.ntypes:
+                raise RuntimeError("update_atoms: atom type outside the context's LJ table")
+            q = _np_real(parameters.charges, eng.dtype)
+            L.check(
+                eng.lib.tmdhip_update_atoms(eng.ctx, self.natoms, types.ctypes.data_as(C.c_void_p),
+                                            q.ctypes.data_as(C.c_void_p), int(nactive) if nactive else 0),
+                "tmdhip_update_atoms",
+            )
+            eng.ebuf.zero_()
+        self._nactive = nactive
 
     def close(self):
         """Release the device contexts (they are re-created on the next compute())."""
