@@ -41,6 +41,16 @@ def test_forces_equal_single_domain(world, grid):
     assert (F - Fr[0]).abs().max().item() < 1e-9
     halo = [d.local_pos.shape[1] - d.nown for d in ds.domains.values()]
     assert all(h > 0 for h in halo)
+    # energy: halo atoms are passive, so a brick counts its own-own pairs fully and own-halo pairs half;
+    # the bricks' energies add up to the single-domain total
+    from torchmd_amd import _lib as L
+
+    e_dd = sum(float(d.compute(want_energy=True)[0, L.ENERGY_SLOT["lj"]].item()) for d in ds.domains.values())
+    e_ref = ref.compute(p, b, Fr, returnDetails=True)[0]["lj"]
+    assert abs(e_dd - e_ref) <= 1e-9 * abs(e_ref)
+    # and no force is computed on the halo atoms
+    for d in ds.domains.values():
+        assert d.local_forces[0, d.nown:].abs().max().item() == 0.0
 
 
 def test_trajectory_equal_single_domain():
