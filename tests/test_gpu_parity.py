@@ -602,3 +602,50 @@ def test_packed_kernel_switching_variants(mode):
     p, b = pos_tensor(pos, 1, torch.float32, dev), box_tensor(box, 1, torch.float32, dev)
     e0 = f0.compute(p, b, torch.zeros_like(p), returnDetails=True)[0]
     assert abs(e0["lj"] - F32[2]["lj"]) > 1.0
+
+
+def test_tiny_systems_and_odd_sizes():
+    """Edge sizes: 1 atom (no pair at all), 2 atoms (one pair: analytic LJ), 3 water atoms (every pair
+    excluded), 63 / 65 / 129 argon atoms (partial tiles of the all-pairs kernel) against the oracle, and
+    several such replicas batched in one launch."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.io import Topology
+    from torchmd_amd.parameters import Parameters
+
+    dev, dt = _dev(), torch.float64
+    mol, pos, box = lj_box(6, seed=2)  # 216 argon atoms
+    sig, eps = 3.345, 0.238
+    for n in (1, 2, 63, 65, 129):
+        sub = Topology(atomtype=np.array(["AR"] * n, dtype=object), charge=np.zeros(n), masses=np.full(n, 39.95))
+        par = Parameters(argon_forcefield(sub), sub, ["lj"], precision=dt)
+        p = pos[:n].copy()
+        if n == 2:
+            p[1] = p[0] + np.array([3.9, 0.3, -0.2])
+        f = Forces(par, terms=["lj"], cutoff=9.0)
+        R = 3
+        pt = torch.tensor(np.stack([p + 0.01 * r for r in range(R)]), dtype=dt, device=dev)
+        bt = box_tensor(box, R, dt, dev)
+        F = torch.full_like(pt, 3.0)
+        pots = f.compute(pt, bt, F, returnDetails=True)
+        if n == 1:
+            assert F.abs().max().item() == 0.0 and pots[0]["lj"] == 0.0
+            continue
+        po, Fo, _ = orc.compute(par, pt[:1].cpu(), bt[:1].cpu(), ["lj"], cutoff=9.0)
+        assert (F[0].cpu() - Fo[0]).abs().max().item() < 1e-10
+        assert abs(pots[0]["lj"] - po[0]["lj"]) < 1e-10 * max(1.0, abs(po[0]["lj"]))
+        assert (F[1] - F[0]).abs().max().item() < 1e-9  # rigid shift of all atoms: same forces
+        if n == 2:
+            r = np.linalg.norm(p[1] - p[0])
+            e = 4 * eps * ((sig / r) ** 12 - (sig / r) ** 6)
+            assert abs(pots[0]["lj"] - e) < 1e-6  # (sigma/epsilon pass through float32 like the reference's)
+    # one water molecule: all three pairs are excluded -> nonbonded terms vanish, bonded ones remain
+    wmol, wpos, wbox = tip3p_box(1, seed=1)
+    par = Parameters(water_forcefield(wmol), wmol, ["lj", "electrostatics", "bonds", "angles"], precision=dt)
+    f = Forces(par, terms=["lj", "electrostatics", "bonds", "angles"], cutoff=9.0)
+    pt, bt = pos_tensor(wpos, 1, dt, dev), torch.zeros(1, 3, 3, dtype=dt, device=dev)
+    F = torch.zeros_like(pt)
+    pots = f.compute(pt, bt, F, returnDetails=True)
+    assert pots[0]["lj"] == 0.0 and pots[0]["electrostatics"] == 0.0
+    assert F.sum(dim=1).abs().max().item() < 1e-9  # internal forces only
