@@ -53,7 +53,6 @@ struct Bonded {
   int natoms = 0;
   int nentries = 0;
   int max_entries_per_atom = 0;
-  DevArr entry_f;  // per-entry forces of the two-kernel path (real [nreplicas][3*nentries])
   int dih_amber = 1, imp_amber = 1;
   uint32_t terms14 = 0;
   int bonds_use_cutoff = 0;
@@ -63,7 +62,7 @@ struct Bonded {
   DevArr dih_idx, dih_start, dih_prm, imp_idx, imp_start, imp_prm;
   DevArr p14_idx, p14_prm;
   void release() {
-    for (DevArr *a : {&entry_f, &atom_off, &atom_ent, &arec, &bond_idx, &bond_prm, &angle_idx, &angle_prm, &dih_idx, &dih_start,
+    for (DevArr *a : {&atom_off, &atom_ent, &arec, &bond_idx, &bond_prm, &angle_idx, &angle_prm, &dih_idx, &dih_start,
                       &dih_prm, &imp_idx, &imp_start, &imp_prm, &p14_idx, &p14_prm})
       a->release();
   }
@@ -123,45 +122,30 @@ __global__ __launch_bounds__(256) void bonded_atom_kernel(int natoms, BondedArgs
 }
 
 // (2) heavy topologies (proteins: an atom sits in dozens of torsions; one thread walking them is a chain
-// of dependent global loads, measured 102 us for alanine dipeptide's 688 atoms): thread = (atom, term)
-// entry writes its force to a per-entry buffer, then thread = atom sums its contiguous entries.
-// Still no atomics and a fixed summation order.
+// of dependent global loads, measured 102 us for alanine dipeptide's 688 atoms): one WAVE per atom, the
+// lanes take the atom's (term, role) entries, the three force components are reduced across the wave with
+// a fixed butterfly.  One launch, no atomics on the forces, bit-reproducible.
 template <typename R>
-__global__ __launch_bounds__(256) void bonded_entry_kernel(int nentries, BondedArgs<R> A, const R *__restrict__ pos,
-                                                           R *__restrict__ entry_f, double *__restrict__ energies,
-                                                           int want_e, const R *__restrict__ boxes, int natoms) {
-  R *none = nullptr;
-  replica_view(A, pos, none, energies, boxes, natoms);
-  entry_f += (size_t)blockIdx.y * 3 * nentries;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bonded_wave_kernel(int natoms, BondedArgs<R> A, const R *__restrict__ pos,
+                                                          R *__restrict__ forces, double *__restrict__ energies,
+                                                          int want_e, const R *__restrict__ boxes) {
+  replica_view(A, pos, forces, energies, boxes, natoms);
+  const int lane = threadIdx.x & 63;
+  const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  R fx = 0, fy = 0, fz = 0;
   double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (q < nentries) {
-    R fx = 0, fy = 0, fz = 0;
-    eval_entry<R>(A, pos, (unsigned)A.atom_ent[q], fx, fy, fz, e);
-    entry_f[3 * q + 0] = fx;
-    entry_f[3 * q + 1] = fy;
-    entry_f[3 * q + 2] = fz;
+  if (a < natoms)
+    for (int q = A.atom_off[a] + lane, qe = A.atom_off[a + 1]; q < qe; q += 64)
+      eval_entry<R>(A, pos, (unsigned)A.atom_ent[q], fx, fy, fz, e);
+  fx = wave_sum(fx);
+  fy = wave_sum(fy);
+  fz = wave_sum(fz);
+  if (lane == 0 && a < natoms && forces) {
+    forces[3 * a + 0] += fx;
+    forces[3 * a + 1] += fy;
+    forces[3 * a + 2] += fz;
   }
   if (want_e) flush_energies(e, energies);
-}
-
-template <typename R>
-__global__ __launch_bounds__(256) void bonded_sum_kernel(int natoms, const int *__restrict__ atom_off,
-                                                         const R *__restrict__ entry_f, R *__restrict__ forces,
-                                                         int nentries) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= natoms) return;
-  entry_f += (size_t)blockIdx.y * 3 * nentries;  // blockIdx.y = replica
-  forces += (size_t)blockIdx.y * 3 * natoms;
-  R fx = 0, fy = 0, fz = 0;
-  for (int q = atom_off[a], qe = atom_off[a + 1]; q < qe; ++q) {
-    fx += entry_f[3 * q + 0];
-    fy += entry_f[3 * q + 1];
-    fz += entry_f[3 * q + 2];
-  }
-  forces[3 * a + 0] += fx;
-  forces[3 * a + 1] += fy;
-  forces[3 * a + 2] += fz;
 }
 
 template <typename R>
@@ -271,10 +255,6 @@ int set_bonded(tmdhip_ctx *ctx, Bonded *b, const tmdhip_bonded_desc *d) {
   for (int a = 0; a < n; ++a) std::copy(per_atom[a].begin(), per_atom[a].end(), ent.begin() + off[a]);
   b->nentries = off[n];
   for (int a = 0; a < n; ++a) b->max_entries_per_atom = std::max(b->max_entries_per_atom, off[a + 1] - off[a]);
-  if (b->max_entries_per_atom > kAtomCentricLimit) {
-    std::vector<R> zeros((size_t)3 * off[n] * ctx_nreplicas(ctx), R(0));  // one slab per replica (batched launches)
-    TMD_TRY(b->entry_f.upload(zeros.data(), zeros.size()));
-  }
   TMD_TRY(b->atom_off.upload(off.data(), off.size()));
   TMD_TRY(b->atom_ent.upload(ent.data(), ent.size()));
   if (b->max_entries_per_atom <= kAtomCentricLimit && b->nentries > 0) {
@@ -365,12 +345,8 @@ int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box,
     hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((n + 255) / 256, nrep), dim3(256), 0, st, n, A,
                        (const R *)pos_v, forces, ctx_energy_scratch(ctx), we, boxes);
   } else {
-    const int ne = b->nentries;
-    hipLaunchKernelGGL((bonded_entry_kernel<R>), dim3((ne + 255) / 256, nrep), dim3(256), 0, st, ne, A,
-                       (const R *)pos_v, b->entry_f.as<R>(), ctx_energy_scratch(ctx), we, boxes, n);
-    if (forces)
-      hipLaunchKernelGGL((bonded_sum_kernel<R>), dim3((n + 255) / 256, nrep), dim3(256), 0, st, n,
-                         b->atom_off.as<int>(), b->entry_f.as<R>(), forces, ne);
+    hipLaunchKernelGGL((bonded_wave_kernel<R>), dim3((n + 3) / 4, nrep), dim3(256), 0, st, n, A, (const R *)pos_v,
+                       forces, ctx_energy_scratch(ctx), we, boxes);
   }
   TMD_HIP(hipGetLastError());
   if (we) TMD_TRY(fold_energies(ctx, en, st, nrep));

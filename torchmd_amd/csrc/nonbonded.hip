@@ -891,6 +891,7 @@ struct MdStepArgs {
   R *pos_out;
   R *vel;
   const R *f;
+  R *f_zero;  // non-null: clear the force after reading it (the all-pairs kernel that follows accumulates)
   const R *mass, *vcoeff;
   R dt, half_dt, gamma;
   uint64_t seed, noise_step, row0;
@@ -920,6 +921,11 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
     R fk = f[3 * i + k];
     if (add_fb) fk += fb[k];
     a[k] = fk / m;
+  }
+  if (s.f_zero) {
+    R *fz = s.f_zero + off;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fz[3 * i + k] = R(0);
   }
   if (SECOND) {
     if (LANGEVIN) {
@@ -1234,6 +1240,8 @@ bool plan_grid(const tmdhip_ctx *ctx, const double *box, const double *lo, const
   return false;
 }
 
+constexpr int kForcesZeroed = 1 << 17;  // internal: the integrator kernel has already cleared `forces`
+
 template <typename R>
 int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *forces, double *energies,
                     int flags, unsigned long long *paircount, hipStream_t st, int nrep = 1) {
@@ -1246,7 +1254,7 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
     boxes = (const R *)tmd::set_boxes(ctx, box, st);
     if (!boxes) return fail("could not upload the replica boxes");
   }
-  if ((flags & TMDHIP_OVERWRITE_FORCES) && (flags & TMDHIP_WANT_FORCES))
+  if ((flags & TMDHIP_OVERWRITE_FORCES) && (flags & TMDHIP_WANT_FORCES) && !(flags & kForcesZeroed))
     TMD_HIP(hipMemsetAsync(forces, 0, sizeof(R) * 3 * (size_t)n * nrep, st));  // partial sums are combined with atomics
   const int nb = (n + 63) / 64;
   // split the j range so that ~1024 waves are in flight even for a few hundred atoms (each block then
@@ -1606,6 +1614,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       a.pos_in = a.pos_out = pos;
       a.vel = (R *)d->vel_dev;
       a.f = f;
+      a.f_zero = (first && ctx->d.terms != 0) ? f : nullptr;  // saves the zero-fill launch of the all-pairs path
       a.row0 = 0;
       if (second && first) {
         if (langevin) launch_md_step<R, true, true, true>(a, c, false, st, nrep);
@@ -1626,7 +1635,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       }
       if (ctx->d.terms != 0) {
         for (auto &rp : ctx->rep) rp.n_compute++;
-        TMD_TRY(launch_allpairs<R>(ctx, pos, d->box_host, f, en, flags_c | TMDHIP_OVERWRITE_FORCES, nullptr, st, nrep));
+        TMD_TRY(launch_allpairs<R>(ctx, pos, d->box_host, f, en, flags_c | TMDHIP_OVERWRITE_FORCES | kForcesZeroed,
+                                   nullptr, st, nrep));
       } else {
         TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride * nrep, st));
       }
@@ -1643,6 +1653,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       const bool check = first && list && rp.have_list && box[0] == rp.box[0] && box[1] == rp.box[1] && box[2] == rp.box[2];
       a.vel = (R *)d->vel_dev + r * stride;
       a.f = f;
+      a.f_zero = (first && !list && ctx->d.terms != 0) ? f : nullptr;
+      const bool zeroed = a.f_zero != nullptr;
       a.row0 = (uint64_t)r * (uint64_t)n;
       a.ref = rp.ref.as<R>();
       a.flags = rp.flags.as<int>();
@@ -1691,7 +1703,9 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
             return rc;
           }
         }
-        if (!list) TMD_TRY(launch_allpairs<R>(ctx, pos, box, f, en, flags_c | TMDHIP_OVERWRITE_FORCES, nullptr, st));
+        if (!list)
+          TMD_TRY(launch_allpairs<R>(ctx, pos, box, f, en,
+                                     flags_c | TMDHIP_OVERWRITE_FORCES | (zeroed ? kForcesZeroed : 0), nullptr, st));
       } else {
         TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride, st));
       }
