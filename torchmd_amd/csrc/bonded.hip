@@ -357,18 +357,18 @@ int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box,
 
 namespace tmd {
 // Arguments for evaluating the bonded force of an atom inline in the MD-step kernel (nonbonded.hip).
-// False when there are no bonded terms or the topology is too heavy for the atom-centric scheme.
-bool bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A) {
+// 0: no bonded terms; 1: light topology (thread per atom, per-atom records); 2: heavy (wave per atom).
+int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A) {
   const Bonded *b = (const Bonded *)ctx_bonded_slot(ctx);
-  if (!b || b->nentries == 0 || b->max_entries_per_atom > kAtomCentricLimit) return false;
+  if (!b || b->nentries == 0) return 0;
   fill_args<float>(ctx, b, box, A);
-  return true;
+  return b->max_entries_per_atom <= kAtomCentricLimit ? 1 : 2;
 }
-bool bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A) {
+int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A) {
   const Bonded *b = (const Bonded *)ctx_bonded_slot(ctx);
-  if (!b || b->nentries == 0 || b->max_entries_per_atom > kAtomCentricLimit) return false;
+  if (!b || b->nentries == 0) return 0;
   fill_args<double>(ctx, b, box, A);
-  return true;
+  return b->max_entries_per_atom <= kAtomCentricLimit ? 1 : 2;
 }
 }  // namespace tmd
 

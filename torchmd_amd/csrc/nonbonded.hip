@@ -978,21 +978,36 @@ __global__ void md_step_kernel(MdStepArgs<R> s, PairConsts<R> c) {
   md_step_atom<R, SECOND, LANGEVIN, FIRST, CHECK>(s, c, i, off, row0, none, false);
 }
 
-// Interior steps of a cell-list MD run with a light topology (water, ions): the bonded force of the
-// previous step's positions is evaluated HERE, per atom, instead of by a bonded kernel of its own
-// (one launch and one read-modify-write pass over `forces` less per step; bit-identical: the same
-// eval_entry sequence, added to the stored pair force before the division by the mass).  Partner
-// positions must be the undrifted ones, so the step reads pos_in and writes pos_out (two buffers).
+// Interior steps of an MD run: the bonded force of the previous step's positions is evaluated HERE
+// instead of by a bonded kernel of its own (one launch and one read-modify-write pass over `forces` less
+// per step; bit-identical to the separate kernels: the same device functions in the same order, added to
+// the stored pair force before the division by the mass).  Partner positions must be the undrifted ones,
+// so the step reads pos_in and writes pos_out (two buffers).  Light topologies only (thread per atom,
+// per-atom records): for proteins a wave-per-atom variant with lane 0 integrating was measured slower than
+// the separate bonded_wave_kernel (alanine dipeptide 47 vs 42.5 us/step: the two phases serialise inside
+// each wave).  Without CHECK (all-pairs systems) blockIdx.y is the replica.
 template <typename R, bool LANGEVIN, bool CHECK>
-__global__ void md_step_bonded_kernel(MdStepArgs<R> s, PairConsts<R> c, BondedArgs<R> A) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (CHECK && i == 0) s.flags[s.parity ^ 1] = 0;
-  if (i >= s.n) return;
+__global__ __launch_bounds__(256) void md_step_bonded_kernel(MdStepArgs<R> s, PairConsts<R> c, BondedArgs<R> A,
+                                                             const R *__restrict__ boxes) {
+  if (CHECK && blockIdx.x == 0 && threadIdx.x == 0) s.flags[s.parity ^ 1] = 0;
+  const int rep = CHECK ? 0 : (int)blockIdx.y;
+  const size_t off = (size_t)rep * 3 * s.n;
+  const uint64_t row0 = s.row0 + (uint64_t)rep * (uint64_t)s.n;
+  if (!CHECK && boxes) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      A.b.box[k] = boxes[6 * rep + k];
+      A.b.invbox[k] = boxes[6 * rep + 3 + k];
+    }
+  }
+  const R *pos = s.pos_in + off;
   R fx = 0, fy = 0, fz = 0;
   double e[TMDHIP_NENERGY];  // energies are not wanted on interior steps (dead stores)
-  eval_atom<R>(A, s.pos_in, i, fx, fy, fz, e);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n) return;
+  eval_atom<R>(A, pos, i, fx, fy, fz, e);
   const R fb[3] = {fx, fy, fz};
-  md_step_atom<R, true, LANGEVIN, true, CHECK>(s, c, i, 0, s.row0, fb, true);
+  md_step_atom<R, true, LANGEVIN, true, CHECK>(s, c, i, off, row0, fb, true);
 }
 
 __global__ void halve_count_kernel(unsigned long long *c) { *c >>= 1; }
@@ -1060,6 +1075,7 @@ struct tmdhip_ctx {
   DevBuf types, qs, tab, excl_off, excl_idx;
   DevBuf escratch;  // nreplicas x kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
   DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
+  DevBuf pos_alt_all;  // second position buffer [nreplicas][natoms][3] of the batched MD loop
   std::vector<double> boxes_host;  // what `boxes` currently holds
   int max_excl = 0;
   int nactive = 0x7fffffff;  // atoms with original index >= nactive get empty lists (tmdhip_update_atoms)
@@ -1079,8 +1095,8 @@ struct tmdhip_ctx {
 
 namespace tmd {
 void bonded_release(tmdhip_ctx *ctx);  // bonded.hip
-bool bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A);   // bonded.hip
-bool bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A);  // bonded.hip
+int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A);   // bonded.hip
+int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A);  // bonded.hip
 void *&ctx_bonded_slot(tmdhip_ctx *ctx) { return ctx->bonded; }
 const tmdhip_nonbonded_desc &ctx_desc(const tmdhip_ctx *ctx) { return ctx->d; }
 const void *ctx_scaled_charges(const tmdhip_ctx *ctx) { return ctx->qs.p; }
@@ -1571,12 +1587,14 @@ void launch_md_step(const MdStepArgs<R> &a, const PairConsts<R> &c, bool check, 
 
 template <typename R>
 void launch_md_step_bonded(const MdStepArgs<R> &a, const PairConsts<R> &c, const BondedArgs<R> &A, bool langevin,
-                           bool check, hipStream_t st) {
-  const dim3 grid((a.n + 255) / 256), block(256);
-  if (langevin && check) hipLaunchKernelGGL((md_step_bonded_kernel<R, true, true>), grid, block, 0, st, a, c, A);
-  else if (langevin) hipLaunchKernelGGL((md_step_bonded_kernel<R, true, false>), grid, block, 0, st, a, c, A);
-  else if (check) hipLaunchKernelGGL((md_step_bonded_kernel<R, false, true>), grid, block, 0, st, a, c, A);
-  else hipLaunchKernelGGL((md_step_bonded_kernel<R, false, false>), grid, block, 0, st, a, c, A);
+                           bool check, const R *boxes, int nrep, hipStream_t st) {
+  const dim3 grid((a.n + 255) / 256, check ? 1 : nrep), block(256);
+#define TMD_MSB(L, C) hipLaunchKernelGGL((md_step_bonded_kernel<R, L, C>), grid, block, 0, st, a, c, A, boxes)
+  if (langevin && check) TMD_MSB(true, true);
+  else if (langevin) TMD_MSB(true, false);
+  else if (check) TMD_MSB(false, true);
+  else TMD_MSB(false, false);
+#undef TMD_MSB
 }
 
 template <typename R>
@@ -1603,20 +1621,48 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   std::vector<R *> cur(nrep);
   std::vector<char> owed(nrep, 0);
   for (int r = 0; r < nrep; ++r) cur[r] = (R *)d->pos_dev + r * stride;
+  // the same for the replica-batched all-pairs mode (all replicas move together)
+  R *const home_all = (R *)d->pos_dev;
+  R *bcur = home_all;
+  bool bowed = false;
 
   for (int it = 0; it <= d->niter; ++it) {
     const bool first = it < d->niter, second = it > 0;
     a.noise_step = d->step0 + (uint64_t)(it > 0 ? it - 1 : 0);
     if (nrep > 1 && (ctx->algorithm == TMDHIP_ALGO_ALLPAIRS || ctx->d.terms == 0)) {
       // small systems are launch-bound: one launch of every kernel serves all replicas
-      R *pos = (R *)d->pos_dev, *f = (R *)d->forces_dev;
+      for (int r = 0; r < nrep; ++r) {  // leftovers of a cell-list context that fell back to all pairs in this call
+        R *home = home_all + r * stride;
+        if (owed[r]) {
+          TMD_TRY(tmdhip_compute_bonded(ctx, r, cur[r], d->box_host + 3 * r, (R *)d->forces_dev + r * stride, nullptr,
+                                        TMDHIP_WANT_FORCES, st));
+          owed[r] = 0;
+        }
+        if (cur[r] != home) {
+          TMD_HIP(hipMemcpyAsync(home, cur[r], sizeof(R) * stride, hipMemcpyDeviceToDevice, st));
+          cur[r] = home;
+        }
+      }
+      R *f = (R *)d->forces_dev;
       const PairConsts<R> c = make_consts<R>(ctx, d->box_host);
-      a.pos_in = a.pos_out = pos;
+      a.pos_in = a.pos_out = bcur;
       a.vel = (R *)d->vel_dev;
       a.f = f;
       a.f_zero = (first && ctx->d.terms != 0) ? f : nullptr;  // saves the zero-fill launch of the all-pairs path
       a.row0 = 0;
-      if (second && first) {
+      BondedArgs<R> A;
+      if (bowed) {
+        // (second && first) the bonded force of step it-1 is evaluated inside the integrator kernel from
+        // the undrifted positions in bcur; the drifted ones go to the other buffer
+        const bool ok = tmd::bonded_inline_args(ctx, d->box_host, A) == 1;
+        const R *boxes = (const R *)tmd::set_boxes(ctx, d->box_host, st);
+        if (!ok || !boxes) return fail("tmdhip_md_run: inline bonded state lost");
+        R *other = bcur == home_all ? ctx->pos_alt_all.as<R>() : home_all;
+        a.pos_out = other;
+        launch_md_step_bonded<R>(a, c, A, langevin, false, boxes, nrep, st);
+        bcur = other;
+        bowed = false;
+      } else if (second && first) {
         if (langevin) launch_md_step<R, true, true, true>(a, c, false, st, nrep);
         else launch_md_step<R, true, false, true>(a, c, false, st, nrep);
       } else if (first) {
@@ -1627,6 +1673,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       }
       TMD_HIP(hipGetLastError());
       if (!first) continue;
+      R *pos = bcur;
       int flags_c = TMDHIP_WANT_FORCES;
       double *en = nullptr;
       if (it == d->niter - 1 && d->energies_dev) {
@@ -1640,7 +1687,12 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       } else {
         TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride * nrep, st));
       }
-      TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos, d->box_host, f, en, flags_c, st));
+      if (it + 1 < d->niter && tmd::bonded_inline_args(ctx, d->box_host, A) == 1) {
+        TMD_TRY(ctx->pos_alt_all.ensure(sizeof(R) * stride * nrep));
+        bowed = true;  // the next integrator kernel evaluates this step's bonded force itself
+      } else {
+        TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos, d->box_host, f, en, flags_c, st));
+      }
       continue;
     }
     for (int r = 0; r < nrep; ++r) {
@@ -1666,10 +1718,10 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       if (owed[r]) {
         // second && first always holds here: the bonded force of step it-1 is evaluated from the
         // undrifted positions in cur[r], the drifted ones go to the other buffer
-        if (!tmd::bonded_inline_args(ctx, box, A)) return fail("tmdhip_md_run: inline bonded state lost");
+        if (tmd::bonded_inline_args(ctx, box, A) != 1) return fail("tmdhip_md_run: inline bonded state lost");
         R *other = cur[r] == home ? rp.pos_alt.as<R>() : home;
         a.pos_out = other;
-        launch_md_step_bonded<R>(a, c, A, langevin, check, st);
+        launch_md_step_bonded<R>(a, c, A, langevin, check, nullptr, 1, st);
         cur[r] = other;
         owed[r] = 0;
       } else if (second && first) {
@@ -1709,9 +1761,11 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       } else {
         TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride, st));
       }
-      // interior step of a list run with a light topology: the next integrator kernel evaluates this
-      // step's bonded force itself (md_step_bonded_kernel); `forces` holds the pair part until then
-      if (list && rp.have_list && it + 1 < d->niter && tmd::bonded_inline_args(ctx, box, A)) {
+      // interior step: the next integrator kernel evaluates this step's bonded force itself
+      // (md_step_bonded_kernel); `forces` holds the pair part until then.  (All-pairs contexts with several
+      // replicas take the batched branch above from the next iteration on.)
+      if (((list && rp.have_list) || (!list && nrep == 1)) && it + 1 < d->niter &&
+          tmd::bonded_inline_args(ctx, box, A) == 1) {
         TMD_TRY(rp.pos_alt.ensure(sizeof(R) * stride));
         owed[r] = 1;
       } else {
@@ -1719,6 +1773,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       }
     }
   }
+  if (bcur != home_all)
+    TMD_HIP(hipMemcpyAsync(home_all, bcur, sizeof(R) * stride * nrep, hipMemcpyDeviceToDevice, st));
   for (int r = 0; r < nrep; ++r) {
     R *home = (R *)d->pos_dev + r * stride;
     if (cur[r] != home) TMD_HIP(hipMemcpyAsync(home, cur[r], sizeof(R) * stride, hipMemcpyDeviceToDevice, st));
@@ -1825,7 +1881,7 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
 void tmdhip_destroy(tmdhip_ctx *ctx) {
   if (!ctx) return;
   for (auto &rp : ctx->rep) rp.release();
-  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->escratch, &ctx->boxes})
+  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all})
     b->release();
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
