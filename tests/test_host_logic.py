@@ -333,3 +333,28 @@ def test_halo_exchange_gloo(tmp_path, world):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_merge_lj_types_preserves_every_pair_parameter():
+    """Types with identical LJ rows are merged before the table goes to the device: every (atom, atom)
+    pair must still see the same A and B."""
+    import numpy as np
+    import torch
+
+    from _golden import GoldenParameters, load
+    from torchmd_amd.forces import merge_lj_types
+
+    for name, expect in (("ala2", 9), ("thrombin", 16), ("water291", 2)):
+        par = GoldenParameters(load(name), torch.float64)
+        A, B = (t.numpy() for t in par.get_AB())
+        types = par.mapped_atom_types.numpy().astype(np.int64)
+        A2, B2, t2, tmap = merge_lj_types(A, B, types)
+        assert A2.shape[0] == expect
+        sample = np.random.default_rng(0).integers(0, len(types), size=(2000, 2))
+        i, j = sample[:, 0], sample[:, 1]
+        assert np.array_equal(A[types[i], types[j]], A2[t2[i], t2[j]])
+        assert np.array_equal(B[types[i], types[j]], B2[t2[i], t2[j]])
+        if tmap is None:
+            assert A2 is A and t2 is types
+        else:
+            assert np.array_equal(tmap[types], t2)

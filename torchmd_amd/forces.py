@@ -59,6 +59,20 @@ def _close_all_engines():
         eng.close()
 
 
+def merge_lj_types(A, B, types):
+    """Merge atom types that share their LJ parameters (most type names of a protein force field do).
+    The pair kernels keep the [T,T] table in LDS, so a smaller T means more resident waves.  Rows of
+    (A | B) identical  <=>  same sigma and epsilon  <=>  identical columns.  Returns the compacted tables,
+    the remapped per-atom types and the type -> class map (None when nothing was merged)."""
+    _, first, inverse = np.unique(np.concatenate([A, B], axis=1), axis=0, return_index=True, return_inverse=True)
+    inverse = np.asarray(inverse).reshape(-1)
+    if len(first) == A.shape[0]:
+        return A, B, types, None
+    A2 = np.ascontiguousarray(A[np.ix_(first, first)])
+    B2 = np.ascontiguousarray(B[np.ix_(first, first)])
+    return A2, B2, inverse[types], inverse
+
+
 class _Engine:
     """One tmdhip context = (device, dtype, nreplicas) instance of a Forces object."""
 
@@ -92,17 +106,7 @@ class _Engine:
             A, B = owner._lj_tables()
             A_np, B_np = _np_real(A, dtype), _np_real(B, dtype)
             types = par.mapped_atom_types.detach().cpu().numpy().astype(np.int64)
-            # Type names that share their LJ parameters (most of a protein force field's) are merged into
-            # one class: the pair kernels keep the [T,T] table in LDS, so a smaller T means more resident
-            # waves.  Rows of (A | B) identical  <=>  same sigma and epsilon  <=>  identical columns.
-            _, first, inverse = np.unique(np.concatenate([A_np, B_np], axis=1), axis=0, return_index=True,
-                                          return_inverse=True)
-            inverse = np.asarray(inverse).reshape(-1)
-            if len(first) < A_np.shape[0]:
-                A_np = np.ascontiguousarray(A_np[np.ix_(first, first)])
-                B_np = np.ascontiguousarray(B_np[np.ix_(first, first)])
-                types = inverse[types]
-                self.type_map = inverse
+            A_np, B_np, types, self.type_map = merge_lj_types(A_np, B_np, types)
             self.ntypes = int(A_np.shape[0])
             d.ntypes = self.ntypes
             d.types_host = ptr(np.ascontiguousarray(types.astype(np.int32)))
