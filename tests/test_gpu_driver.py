@@ -77,3 +77,39 @@ def test_water_conf_end_to_end(tmp_path):
         com = traj[:, :, -1].reshape(97, 3, 3).mean(axis=1)
         assert (com > -1e-3).all() and (com < g["box"] + 1e-3).all()
     assert os.path.exists(log / "input.yaml")
+
+
+def test_external_plugin_equals_forces():
+    """The reference's plugin protocol `External(file, embeddings, device, **kw).calculate(pos, box) ->
+    (energy[R], forces[R,N,3])`: nonbonded terms through the hook + bonded terms in `Forces` == all terms in
+    `Forces` (tests/water, 2 replicas)."""
+    import numpy as np
+
+    from _golden import GoldenParameters, box_tensor, load, pos_tensor
+    from torchmd_amd.external import External
+    from torchmd_amd.forces import Forces
+
+    g = load("water291")
+    dev = torch.device("cuda:0")
+    par = GoldenParameters(g, torch.float64)
+    p = pos_tensor(g["pos"], 2, torch.float64, dev)
+    p[1] += 0.01 * torch.randn_like(p[1])
+    b = box_tensor(g["box"], 2, torch.float64, dev)
+    full = Forces(par, terms=["bonds", "angles", "lj", "electrostatics"], cutoff=7.3, rfa=True)
+    F_full = torch.zeros_like(p)
+    e_full = full.compute(p, b, F_full, returnDetails=True)
+    ext = External(par, None, device="cuda:0", terms=["lj", "electrostatics"], cutoff=7.3, rfa=True)
+    energy, forces = ext.calculate(p, b)
+    assert energy.shape == (2,) and forces.shape == p.shape
+    for r in range(2):
+        assert abs(energy[r].item() - (e_full[r]["lj"] + e_full[r]["electrostatics"])) < 1e-9 * abs(energy[r].item())
+    split = Forces(par, terms=["bonds", "angles"], external=ext, cutoff=7.3)
+    F_split = torch.zeros_like(p)
+    e_split = split.compute(p, b, F_split, returnDetails=True)
+    assert (F_split - F_full).abs().max().item() < 1e-9
+    for r in range(2):
+        assert abs(e_split[r]["external"] - energy[r].item()) < 1e-9
+        assert abs(sum(e_split[r].values()) - sum(e_full[r].values())) < 1e-9 * abs(sum(e_full[r].values()))
+    with pytest.raises(ValueError, match="nonbonded terms only"):
+        External(par, None, device="cuda:0", terms=["bonds"])
+    assert np.isfinite(forces.cpu().numpy()).all()

@@ -358,3 +358,36 @@ def test_merge_lj_types_preserves_every_pair_parameter():
             assert A2 is A and t2 is types
         else:
             assert np.array_equal(tmap[types], t2)
+
+
+def test_external_plugin_config(tmp_path):
+    """`torchmd_amd.external.External` (the reference's plugin hook, run.py:185-209): configuration file
+    -> Parameters without a GPU, option validation, and the no-CPU-path contract."""
+    import yaml
+
+    from torchmd_amd.builders import TIP3P_FF
+    from torchmd_amd.external import External
+
+    psf = tmp_path / "w.psf"
+    psf.write_text(
+        "PSF\n\n       1 !NTITLE\n REMARKS one water\n\n       3 !NATOM\n"
+        "       1 W    1    TIP3 OH2  OT    -0.834000       15.9994           0\n"
+        "       2 W    1    TIP3 H1   HT     0.417000        1.0080           0\n"
+        "       3 W    1    TIP3 H2   HT     0.417000        1.0080           0\n\n"
+        "       3 !NBOND: bonds\n       1       2       1       3       2       3\n\n"
+        "       1 !NTHETA: angles\n       2       1       3\n\n"
+    )
+    (tmp_path / "ff.yaml").write_text(yaml.safe_dump(TIP3P_FF))
+    conf = tmp_path / "nb.yaml"
+    conf.write_text(yaml.safe_dump({"topology": "w.psf", "forcefield": "ff.yaml", "terms": ["lj", "electrostatics"],
+                                    "cutoff": 9.0, "rfa": True}))
+    opts, par = External._from_file(str(conf))
+    assert opts == {"terms": ["lj", "electrostatics"], "cutoff": 9.0, "rfa": True}
+    assert par.natoms == 3 and abs(float(par.charges.sum())) < 1e-6
+    assert sorted(map(tuple, par.get_exclusions(("bonds", "angles", "1-4")))) == [(0, 1), (0, 2), (0, 2), (1, 2)] or \
+        len(par.get_exclusions(("bonds", "angles", "1-4"))) >= 3
+    with pytest.raises(RuntimeError, match="ROCm device only"):
+        External(str(conf), [0], device="cpu")
+    (tmp_path / "bad.yaml").write_text(yaml.safe_dump({"forcefield": "ff.yaml"}))
+    with pytest.raises(ValueError, match="topology"):
+        External._from_file(str(tmp_path / "bad.yaml"))
