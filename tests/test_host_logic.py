@@ -391,3 +391,24 @@ def test_external_plugin_config(tmp_path):
     (tmp_path / "bad.yaml").write_text(yaml.safe_dump({"forcefield": "ff.yaml"}))
     with pytest.raises(ValueError, match="topology"):
         External._from_file(str(tmp_path / "bad.yaml"))
+
+
+def test_compat_install_registers_reference_module_names():
+    """`torchmd_amd.compat.install()`: `from torchmd.forces import Forces` resolves to this package."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torchmd_amd.compat as c\n"
+        "names = c.install()\n"
+        "from torchmd.forces import Forces\n"
+        "from torchmd.integrator import Integrator, maxwell_boltzmann\n"
+        "from torchmd.systems import System\n"
+        "import torchmd_amd.forces, torchmd_amd.integrator\n"
+        "assert Forces is torchmd_amd.forces.Forces and Integrator is torchmd_amd.integrator.Integrator\n"
+        "assert 'torchmd.forces' in names and 'torchmd.parameters' in names\n"
+        "print('ok')\n"
+    ) % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr
