@@ -649,3 +649,50 @@ def test_tiny_systems_and_odd_sizes():
     pots = f.compute(pt, bt, F, returnDetails=True)
     assert pots[0]["lj"] == 0.0 and pots[0]["electrostatics"] == 0.0
     assert F.sum(dim=1).abs().max().item() < 1e-9  # internal forces only
+
+
+def test_minimum_image_known_geometry():
+    """The reference's tiny periodic fixtures (tests/data/2watersperiodic, sodiumperiodic: two molecules
+    15.1 A apart in a 19.3 A box, i.e. 4.2 A across the boundary): the periodic evaluation must equal the
+    same molecules brought together by one box vector in an open box, and the oracle; two unit charges give
+    Coulomb's law at the minimum-image distance."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.io import Topology
+    from torchmd_amd.parameters import Parameters
+
+    dev, dt = _dev(), torch.float64
+    box = np.array([19.339, 19.125, 19.140])
+    mol, pos, _ = tip3p_box(2, seed=4)  # 8 waters: keep two
+    mol2 = Topology(atomtype=mol.atomtype[:6], charge=mol.charge[:6], masses=mol.masses[:6],
+                    bonds=mol.bonds[(mol.bonds < 6).all(axis=1)], angles=mol.angles[(mol.angles < 6).all(axis=1)])
+    p = pos[:6].copy()
+    p[:3] += np.array([2.0, 5.0, 5.0]) - p[0]
+    p[3:] += np.array([17.1, 5.3, 4.8]) - p[3]
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol2), mol2, terms, precision=dt)
+    f = Forces(par, terms=terms, cutoff=9.0, rfa=True)
+    pt, bt = pos_tensor(p, 1, dt, dev), box_tensor(box, 1, dt, dev)
+    F = torch.zeros_like(pt)
+    e_per = f.compute(pt, bt, F, returnDetails=True)[0]
+    q = p.copy()
+    q[3:, 0] -= box[0]  # the image next to molecule 1
+    Fo = torch.zeros_like(pt)
+    e_open = f.compute(pos_tensor(q, 1, dt, dev), torch.zeros_like(bt), Fo, returnDetails=True)[0]
+    for t in terms:
+        assert abs(e_per[t] - e_open[t]) < 1e-10 * max(1.0, abs(e_open[t])), t
+    assert (F - Fo).abs().max().item() < 1e-10
+    assert abs(e_per["electrostatics"]) > 1e-3  # the molecules do interact across the boundary
+    po, Fr, _ = orc.compute(par, pt.cpu(), bt.cpu(), terms, cutoff=9.0, rfa=True)
+    assert (F.cpu() - Fr).abs().max().item() < 1e-10
+    # two ions: plain Coulomb at the minimum-image distance
+    ions = Topology(atomtype=np.array(["OT", "OT"], dtype=object), charge=np.array([1.0, 1.0]), masses=np.array([22.99, 22.99]))
+    ipar = Parameters(water_forcefield(ions), ions, ["electrostatics"], precision=dt)
+    ipos = np.array([[2.0, 5.0, 5.0], [17.1, 5.0, 5.0]])
+    fi = Forces(ipar, terms=["electrostatics"], cutoff=9.0)
+    Fi = torch.zeros(1, 2, 3, dtype=dt, device=dev)
+    ei = fi.compute(pos_tensor(ipos, 1, dt, dev), bt, Fi, returnDetails=True)[0]["electrostatics"]
+    r = box[0] - 15.1
+    assert abs(ei - 332.06371307417066 / r) < 1e-9
+    assert abs(Fi[0, 0, 0].item() - 332.06371307417066 / r**2) < 1e-9  # pushed apart: +x on the left ion
