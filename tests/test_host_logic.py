@@ -412,3 +412,28 @@ def test_compat_install_registers_reference_module_names():
     ) % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr
+
+
+def test_driver_external_hook(tmp_path):
+    """`torchmd_amd.run.load_external` follows the reference's plugin protocol (run.py:185-209)."""
+    import sys
+
+    from torchmd_amd.run import load_external
+
+    (tmp_path / "myplugin.py").write_text(
+        "class External:\n"
+        "    def __init__(self, file, embeddings, device=None, **kw):\n"
+        "        self.file, self.embeddings, self.device, self.kw = file, embeddings, device, kw\n"
+        "    def calculate(self, pos, box):\n"
+        "        return pos.sum(dim=(1, 2)) * 0, pos * 0\n"
+    )
+    sys.path.insert(0, str(tmp_path))
+    try:
+        ext = load_external({"module": "myplugin", "file": "model.ckpt", "embeddings": [1, 8, 1], "scale": 2.0}, 3, "cpu")
+    finally:
+        sys.path.remove(str(tmp_path))
+    assert ext.file == "model.ckpt" and ext.kw == {"scale": 2.0} and ext.device == "cpu"
+    assert tuple(ext.embeddings.shape) == (3, 3)
+    assert load_external(None, 1, "cpu") is None
+    with pytest.raises(ValueError, match="module"):
+        load_external({"file": "x"}, 1, "cpu")

@@ -122,6 +122,27 @@ def load_molecule(args):
     return mol, prmtop
 
 
+def load_external(conf, replicas, device):
+    """The reference's plugin hook (`torchmd/run.py:185-209`): `conf = {module, file, embeddings, ...}` ->
+    `import_module(module).External(file, embeddings, device=device, **rest)`; `embeddings` is a list or the
+    name of a `.npy` file, repeated per replica.  The object's `calculate(pos, box)` must return
+    `(energy[R], forces[R,N,3])` (consumed by `Forces.compute`, reference `forces.py:321-326`)."""
+    if conf is None:
+        return None
+    import importlib
+
+    conf = dict(conf)
+    try:
+        module, file = conf.pop("module"), conf.pop("file")
+    except KeyError as e:
+        raise ValueError(f"external: missing key {e.args[0]!r} (needs 'module' and 'file')") from None
+    emb = conf.pop("embeddings", None)
+    if isinstance(emb, str):
+        emb = np.load(emb).astype(int)
+    embeddings = None if emb is None else torch.tensor(emb).repeat(replicas, 1)
+    return importlib.import_module(module).External(file, embeddings, device=device, **conf)
+
+
 def setup(args):
     torch.manual_seed(args.seed)
     device = torch.device(args.device)
@@ -137,14 +158,13 @@ def setup(args):
     terms = args.forceterms if args.forceterms else ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
     print("Force terms: ", terms)
     parameters = Parameters(ff, mol, terms, precision=precision, device="cpu")
-    if args.external is not None:
-        raise NotImplementedError("external calculators are passed programmatically (Forces(external=...))")
+    external = load_external(args.external, args.replicas, device)
     system = System(mol.numAtoms, args.replicas, precision, device)
     system.set_positions(mol.coords)
     system.set_box(mol.box)
     system.set_velocities(maxwell_boltzmann(parameters.masses, args.temperature, args.replicas))
-    forces = Forces(parameters, terms=terms, cutoff=args.cutoff, rfa=args.rfa, switch_dist=args.switch_dist,
-                    exclusions=tuple(args.exclusions))
+    forces = Forces(parameters, terms=terms, external=external, cutoff=args.cutoff, rfa=args.rfa,
+                    switch_dist=args.switch_dist, exclusions=tuple(args.exclusions))
     return mol, system, forces
 
 
