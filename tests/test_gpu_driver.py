@@ -113,3 +113,39 @@ def test_external_plugin_equals_forces():
     with pytest.raises(ValueError, match="nonbonded terms only"):
         External(par, None, device="cuda:0", terms=["bonds"])
     assert np.isfinite(forces.cpu().numpy()).all()
+
+
+def test_minimizers_lower_the_energy_of_a_water_box():
+    """The three minimisers of `torchmd_amd.minimizers` (reference `minimizers.py`) on the real engine: the
+    jittered 648-atom water box relaxes (L-BFGS-B on explicit forces, torch LBFGS on the differentiable
+    potential, conjugate gradient)."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.minimizers import minimize_bfgs, minimize_cg, minimize_pytorch_bfgs
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = torch.device("cuda:0"), torch.float64
+    mol, pos, box = tip3p_box(6, seed=8)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+
+    def fresh():
+        s = System(mol.numAtoms, 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True)
+        return s, f, f.compute(s.pos, s.box, s.forces)[0]
+
+    s, f, e0 = fresh()
+    minimize_bfgs(s, f, fmax=0.5, steps=30)
+    e1 = f.compute(s.pos, s.box, s.forces)[0]
+    assert e1 < e0 - 50.0
+    s, f, e0 = fresh()
+    en = minimize_pytorch_bfgs(s, f, steps=2, max_iter=10)
+    e2 = f.compute(s.pos, s.box, s.forces)[0]
+    assert en.shape[0] == 1 and e2 < e0 - 50.0
+    s, f, e0 = fresh()
+    minimize_cg(s, f, steps=6)
+    e3 = f.compute(s.pos, s.box, s.forces)[0]
+    assert e3 < e0 - 50.0

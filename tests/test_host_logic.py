@@ -437,3 +437,46 @@ def test_driver_external_hook(tmp_path):
     assert load_external(None, 1, "cpu") is None
     with pytest.raises(ValueError, match="module"):
         load_external({"file": "x"}, 1, "cpu")
+
+
+def test_minimizers_on_a_mock_potential():
+    """`torchmd_amd.minimizers` (mirror of the reference's `minimizers.py`) only need the duck type
+    `compute(pos, box, forces, ...)`: an anisotropic harmonic well on CPU tensors has its minimum found by
+    all three (L-BFGS-B, torch LBFGS, conjugate gradient)."""
+    import types
+
+    from torchmd_amd.minimizers import minimize_bfgs, minimize_cg, minimize_pytorch_bfgs
+
+    torch.manual_seed(0)
+    n = 7
+    centre = torch.randn(1, n, 3, dtype=torch.float64)
+    k = torch.tensor([1.0, 4.0, 0.5], dtype=torch.float64)
+
+    class Well:
+        def compute(self, pos, box, forces, returnDetails=False, explicit_forces=True, toNumpy=True,
+                    calculateForces=True):
+            d = pos - centre
+            e = (0.5 * k * d * d).sum(dim=(1, 2))
+            if forces is not None:
+                with torch.no_grad():
+                    forces[:] = -(k * d).detach()
+            return [float(v) for v in e] if toNumpy else [v for v in e]
+
+    def system():
+        return types.SimpleNamespace(pos=centre + torch.randn(1, n, 3, dtype=torch.float64),
+                                     box=torch.zeros(1, 3, 3, dtype=torch.float64),
+                                     forces=torch.zeros(1, n, 3, dtype=torch.float64), nreplicas=1, natoms=n)
+
+    s = system()
+    res = minimize_bfgs(s, Well(), fmax=1e-6, steps=200)
+    assert res.fun < 1e-10 and (s.pos - centre).abs().max() < 1e-5
+    s = system()
+    energies = minimize_pytorch_bfgs(s, Well(), steps=5, max_iter=20)
+    assert energies.shape[0] == 1 and energies[0, -1] < 1e-8 and (s.pos - centre).abs().max() < 1e-3
+    s = system()
+    last = minimize_cg(s, Well(), steps=60, threshold=1e-2)  # (the line search resolves 1 % of its interval)
+    assert last < 59 and (s.pos - centre).abs().max() < 2e-2 and s.forces.abs().max() < 1e-2
+    assert minimize_bfgs(s, Well(), steps=0) is None and minimize_pytorch_bfgs(s, Well(), steps=0) is None
+    two = types.SimpleNamespace(pos=torch.zeros(2, n, 3), box=None, forces=None)
+    with pytest.raises(RuntimeError, match="replicas"):
+        minimize_bfgs(two, Well())

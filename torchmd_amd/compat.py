@@ -19,7 +19,7 @@ import sys
 import types
 
 HOT_PATH = ("forces", "integrator", "systems", "wrapper")
-MIRRORS = ("parameters", "forcefields", "run")
+MIRRORS = ("parameters", "forcefields", "run", "minimizers")
 
 
 def install(everything: bool = False):

@@ -25,6 +25,7 @@ from . import io as tio
 from .forcefields import ForceField
 from .forces import Forces
 from .integrator import Integrator, maxwell_boltzmann
+from .minimizers import minimize_bfgs
 from .parameters import Parameters
 from .systems import System
 from .wrapper import Wrapper
@@ -166,27 +167,6 @@ def setup(args):
     forces = Forces(parameters, terms=terms, external=external, cutoff=args.cutoff, rfa=args.rfa,
                     switch_dist=args.switch_dist, exclusions=tuple(args.exclusions))
     return mol, system, forces
-
-
-def minimize_bfgs(system, forces, steps=1000):
-    """L-BFGS-B on the potential of replica 0 (what the reference's `minimize_bfgs` does with scipy,
-    `torchmd/minimizers.py:8-51`); every evaluation is one `forces.compute` on the device."""
-    from scipy.optimize import minimize
-
-    if system.pos.shape[0] != 1:
-        raise RuntimeError("System minimization currently doesn't support replicas")
-    n = system.pos.shape[1]
-
-    def fun(x):
-        system.pos[:] = torch.as_tensor(x.reshape(1, n, 3), dtype=system.pos.dtype, device=system.pos.device)
-        e = forces.compute(system.pos, system.box, system.forces)[0]
-        return e, -system.forces.detach().cpu().numpy().astype(np.float64).reshape(-1)
-
-    x0 = system.pos.detach().cpu().numpy().astype(np.float64).reshape(-1)
-    res = minimize(fun, x0, method="L-BFGS-B", jac=True, options={"maxiter": steps, "disp": False})
-    system.pos[:] = torch.as_tensor(res.x.reshape(1, n, 3), dtype=system.pos.dtype, device=system.pos.device)
-    print(f"minimize: {res.nit} iterations, Epot {res.fun:.4f}")
-    return res
 
 
 class FrameStager:
