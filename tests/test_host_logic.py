@@ -51,6 +51,12 @@ def test_capi_argument_validation_without_gpu():
     assert lib.tmdhip_first_vv(7, 1, 1, None, None, None, None, 0.1, None) < 0
     assert "dtype" in _lib.last_error()
     assert lib.tmdhip_compute_nonbonded(None, 0, None, None, None, None, 0, None) < 0
+    assert lib.tmdhip_compute_bonded(None, _lib.ALL_REPLICAS, None, None, None, None, 0, None) < 0
+    assert lib.tmdhip_update_atoms(None, 10, None, None, 0) < 0
+    assert "null" in _lib.last_error()
+    assert lib.tmdhip_md_run(None, None, None) < 0
+    assert lib.tmdhip_check(None, 0, None) < 0
+    assert lib.tmdhip_timing_enable(None, 1) < 0
 
 
 def test_no_cpu_fallback():

@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void md_step_bonded_kernel(MdStepArgs<R> s, Pa
   }
   const R *pos = s.pos_in + off;
   R fx = 0, fy = 0, fz = 0;
-  double e[TMDHIP_NENERGY];  // energies are not wanted on interior steps (dead stores)
+  double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.n) return;
   eval_atom<R>(A, pos, i, fx, fy, fz, e);
