@@ -193,7 +193,11 @@ class _Engine:
         # the nonbonded kernels *store* forces when asked to (the cell-list pair kernel owns every atom
         # exactly once; the all-pairs path zero-fills internally), which saves a zero-fill pass here
         self.stores_forces = self.has_nonbonded
-        self.ebuf = torch.zeros(nreplicas, L.NENERGY, dtype=torch.float64, device=device)
+        # per-term energies [R, NENERGY] followed by the kinetic energies [R] in ONE buffer, so that
+        # Integrator.step reads everything back with a single device-to-host copy
+        self.comb = torch.zeros(nreplicas * (L.NENERGY + 1), dtype=torch.float64, device=device)
+        self.ebuf = self.comb[: nreplicas * L.NENERGY].view(nreplicas, L.NENERGY)
+        self.kebuf = self.comb[nreplicas * L.NENERGY:]
         _LIVE_ENGINES.add(self)
         del keep
 
@@ -541,6 +545,9 @@ class Forces:
         stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
         L.check(eng.lib.tmdhip_md_run(eng.ctx, C.byref(d), stream), "tmdhip_md_run")
         return eng.ebuf
+
+    def energy_columns(self):
+        return [L.ENERGY_SLOT[n] for n in self.energies if n in L.ENERGY_SLOT]
 
     def total_energy_from(self, ebuf, ext):
         cols = [L.ENERGY_SLOT[n] for n in self.energies if n in L.ENERGY_SLOT]

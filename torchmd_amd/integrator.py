@@ -180,22 +180,37 @@ class Integrator:
                     )
                 self._nstep += 1
 
+            eng = self.forces._engine(s.pos) if (fast and niter > 0) else None
             if self.batch is None:
-                if self._ke is None or self._ke.shape[0] != R or self._ke.device != dev:
-                    self._ke = torch.zeros(R, dtype=torch.float64, device=dev)
+                if eng is not None:
+                    kebuf = eng.kebuf  # shares one buffer with the energies: a single read-back below
+                else:
+                    if self._ke is None or self._ke.shape[0] != R or self._ke.device != dev:
+                        self._ke = torch.zeros(R, dtype=torch.float64, device=dev)
+                    kebuf = self._ke
                 L.check(
                     lib.tmdhip_kinetic_energy(code, R, N, s.vel.data_ptr(), self.masses.data_ptr(),
-                                              self._ke.data_ptr(), _stream(dev)),
+                                              kebuf.data_ptr(), _stream(dev)),
                     "tmdhip_kinetic_energy",
                 )
-                ke = self._ke
+                ke = kebuf
             else:
                 ke = kinetic_energy(self.masses, s.vel, self.batch).flatten().to(torch.float64)
-            if fast and niter > 0:
-                tot = self.forces.total_energy_from(ebuf, ext)
-                host = torch.cat([ke.flatten(), tot]).cpu().numpy()
-                Ekin, pot = host[: ke.numel()], [float(v) for v in host[ke.numel():]]
-                if not self.forces._verify(self.forces._engine(s.pos), s.pos):
+            if eng is not None:
+                if self.batch is None and ebuf is eng.ebuf:
+                    host = eng.comb.cpu().numpy()  # the only synchronising call of step()
+                    e = host[: R * L.NENERGY].reshape(R, L.NENERGY)
+                    Ekin = host[R * L.NENERGY:].copy()
+                    cols = self.forces.energy_columns()
+                    tot = e[:, cols].sum(axis=1) if cols else np.zeros(R)
+                    if ext is not None:
+                        tot = tot + ext.cpu().numpy()
+                    pot = [float(v) for v in tot]
+                else:
+                    tot = self.forces.total_energy_from(ebuf, ext)
+                    host = torch.cat([ke.flatten(), tot]).cpu().numpy()
+                    Ekin, pot = host[: ke.numel()], [float(v) for v in host[ke.numel():]]
+                if not self.forces._verify(eng, s.pos):
                     raise RuntimeError(
                         "a neighbour list overflowed during Integrator.step(); the trajectory since the previous "
                         "step() call is invalid (capacity has been grown — restart from the last saved state)"
