@@ -703,8 +703,9 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
 // minimum image, |d|^2, LJ and reaction-field maths becomes a v_pk_* instruction), gathers j through
 // 32-bit byte offsets against a scalar base (saddr addressing, no 64-bit address arithmetic), and
 // reads a pre-scaled (-12A, 6B) table from LDS.  Same decision arithmetic (bit-exact) as pair_math.h:
-// packed ops round exactly like their scalar forms.  Terms: LJ + reaction-field electrostatics, no
-// switching, forces only (the water benchmark); everything else takes list_pair_kernel.
+// packed ops round exactly like their scalar forms.  Terms: LJ and/or electrostatics (plain Coulomb or
+// reaction field), optionally the LJ switching function (SWITCH) and the per-term energies (ENERGY);
+// repulsion terms, fp64 and pair counting take list_pair_kernel.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
@@ -1305,7 +1306,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const int waves = (n + apw - 1) / apw;
   const int blocks = (waves + 3) / 4;
   const size_t shmem = (size_t)ctx->d.ntypes * ctx->d.ntypes * sizeof(R2);
-  // packed-fp32 kernel covers LJ and/or electrostatics (reaction field or plain Coulomb) without switching
+  // packed-fp32 kernel covers LJ (with or without switching) and/or electrostatics (reaction field or plain Coulomb)
   const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
   const bool fast = only_lj_el;  // (switching, if any, acts on the LJ term and is a kernel variant)
   if constexpr (std::is_same<R, float>::value) {
