@@ -486,3 +486,38 @@ def test_minimizers_on_a_mock_potential():
     two = types.SimpleNamespace(pos=torch.zeros(2, n, 3), box=None, forces=None)
     with pytest.raises(RuntimeError, match="replicas"):
         minimize_bfgs(two, Well())
+
+
+def test_utils_mirror(tmp_path):
+    """`torchmd_amd.utils` (reference `utils.py`): monitor CSV, option files, xyz export."""
+    import argparse
+    import csv
+
+    import numpy as np
+
+    from torchmd_amd.utils import LoadFromFile, LogWriter, save_argparse, xyz_writer
+
+    log = LogWriter(str(tmp_path), ("iter", "epot"), header={"run": 1}, name="m.csv")
+    log.write_row({"iter": 1, "epot": -2.5})
+    log.f.close()
+    lines = (tmp_path / "m.csv").read_text().splitlines()
+    assert lines[0].startswith("# {") and lines[1] == "iter,epot,t"
+    row = next(csv.DictReader(lines[1:]))
+    assert row["iter"] == "1" and float(row["epot"]) == -2.5 and float(row["t"]) >= 0
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--conf", type=open, action=LoadFromFile)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--name", default="x")
+    (tmp_path / "c.yaml").write_text("steps: 9\nname: y\n")
+    ns = ap.parse_args(["--conf", str(tmp_path / "c.yaml")])
+    assert ns.steps == 9 and ns.name == "y"
+    (tmp_path / "c.txt").write_text("steps=11\nname=z\n")
+    ns = ap.parse_args(["--conf", str(tmp_path / "c.txt")])
+    assert ns.steps == 11 and ns.name == "z"
+    save_argparse(ns, str(tmp_path / "out.yaml"), exclude="conf")
+    assert "steps: 11" in (tmp_path / "out.yaml").read_text()
+    traj = np.arange(2 * 3 * 2, dtype=float).reshape(2, 3, 2)
+    np.save(tmp_path / "t.npy", traj)
+    xyz_writer(str(tmp_path / "t.npy"), str(tmp_path / "t.xyz"), ["O", "H"])
+    out = (tmp_path / "t.xyz").read_text().splitlines()
+    assert out[0] == "2" and out[2].startswith("O 0.0 2.0 4.0") and len(out) == 8

@@ -19,7 +19,7 @@ import sys
 import types
 
 HOT_PATH = ("forces", "integrator", "systems", "wrapper")
-MIRRORS = ("parameters", "forcefields", "run", "minimizers")
+MIRRORS = ("parameters", "forcefields", "run", "minimizers", "utils")
 
 
 def install(everything: bool = False):

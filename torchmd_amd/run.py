@@ -26,6 +26,7 @@ from .forcefields import ForceField
 from .forces import Forces
 from .integrator import Integrator, maxwell_boltzmann
 from .minimizers import minimize_bfgs
+from .utils import LogWriter
 from .parameters import Parameters
 from .systems import System
 from .wrapper import Wrapper
@@ -199,20 +200,6 @@ class FrameStager:
         for ev in self.events:
             ev.synchronize()
         return np.ascontiguousarray(self.buf[: self.count, replica].numpy().transpose(1, 2, 0))
-
-
-class LogWriter:
-    def __init__(self, path, keys, name="monitor.csv"):
-        self.keys = tuple(keys) + ("t",)
-        self.fh = open(os.path.join(path, name), "wt")
-        self.writer = csv.DictWriter(self.fh, fieldnames=self.keys)
-        self.writer.writeheader()
-        self.t0 = time.time()
-
-    def write_row(self, row):
-        row = dict(row, t=time.time() - self.t0)
-        self.writer.writerow(row)
-        self.fh.flush()
 
 
 def dynamics(args, mol, system, forces):
