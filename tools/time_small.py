@@ -18,7 +18,7 @@ from torchmd_amd.integrator import Integrator, maxwell_boltzmann  # noqa: E402
 from torchmd_amd.systems import System  # noqa: E402
 
 
-def run(name, terms, R, steps=4000, **kw):
+def run(name, terms, R, steps=4000, tutorial_loop=False, **kw):
     g = load(name)
     dev = torch.device("cuda:0")
     par = GoldenParameters(g, torch.float32)
@@ -32,12 +32,28 @@ def run(name, terms, R, steps=4000, **kw):
     f.compute(s.pos, s.box, s.forces)
     integ = Integrator(s, f, 1.0, dev, gamma=0.1, T=300.0)
     integ.step(500)
+    wrapper = logw = None
+    if tutorial_loop:  # what the reference's tutorial does every 10 steps besides stepping (tutorial.ipynb:747-748)
+        import tempfile
+
+        from torchmd_amd.utils import LogWriter
+        from torchmd_amd.wrapper import Wrapper
+
+        wrapper = Wrapper(n, g["mol_bonds"], dev)
+        logw = LogWriter(tempfile.mkdtemp(), keys=("iter", "ns", "epot", "ekin", "etot", "T"))
+        traj = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps // 10):
+    for i in range(steps // 10):
         ek, ep, T = integ.step(10)  # energies read back every 10 steps like the tutorial's output period
+        if tutorial_loop:
+            wrapper.wrap(s.pos, s.box)
+            traj.append(s.pos.detach().cpu().numpy().copy())
+            logw.write_row({"iter": i * 10, "ns": 1e-6 * i * 10, "epot": ep[0], "ekin": ek[0], "etot": ep[0] + ek[0], "T": T[0]})
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if tutorial_loop:
+        name += " (tutorial loop: wrap + host copy + CSV row every 10 steps)"
     print(f"{name}: {n} atoms x {R} replicas, {el / steps * 1e6:.1f} us/step = {steps / el * 1e-6 * 86400:.0f} ns/day per replica, "
           f"T={T[0]:.0f} K, Epot={ep[0]:.1f}, algorithm={f.stats(s.pos)['algorithm']}")
 
@@ -45,6 +61,7 @@ def run(name, terms, R, steps=4000, **kw):
 if __name__ == "__main__":
     all7 = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
     run("ala2", all7, 1, cutoff=9.0, switch_dist=7.5, rfa=True)
+    run("ala2", all7, 1, tutorial_loop=True, cutoff=9.0, switch_dist=7.5, rfa=True)
     for R in (2, 16, 64):  # replicas share every launch (batched all-pairs / bonded / integrator kernels)
         run("water291", ["lj", "bonds", "angles", "electrostatics"], R, steps=2000, cutoff=7.3)
     run("ala2", all7, 16, steps=2000, cutoff=9.0, switch_dist=7.5, rfa=True)
