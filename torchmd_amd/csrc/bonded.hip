@@ -68,22 +68,6 @@ struct Bonded {
   }
 };
 
-__device__ __forceinline__ void wave_energy(double e, double *dst) {
-  const double s = wave_sum(e);
-  if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(dst, s);  // dst: this wave's scratch row
-}
-
-
-__device__ __forceinline__ void flush_energies(const double *e, double *scratch) {
-  double *energies = energy_row(scratch);
-  wave_energy(e[TMDHIP_E_BONDS], energies + TMDHIP_E_BONDS);
-  wave_energy(e[TMDHIP_E_ANGLES], energies + TMDHIP_E_ANGLES);
-  wave_energy(e[TMDHIP_E_DIHEDRALS], energies + TMDHIP_E_DIHEDRALS);
-  wave_energy(e[TMDHIP_E_IMPROPERS], energies + TMDHIP_E_IMPROPERS);
-  wave_energy(e[TMDHIP_E_LJ], energies + TMDHIP_E_LJ);
-  wave_energy(e[TMDHIP_E_ELECTROSTATICS], energies + TMDHIP_E_ELECTROSTATICS);
-}
-
 // replica batch: blockIdx.y = replica; boxes[y] = {box[3], 1/box[3]} (null: single replica, box in A.b)
 template <typename R>
 __device__ __forceinline__ void replica_view(BondedArgs<R> &A, const R *__restrict__ &pos, R *__restrict__ &forces,

@@ -285,5 +285,22 @@ __device__ __forceinline__ void eval_atom(const BondedArgs<R> &A, const R *__res
   }
 }
 
+// per-term energies of a wave go to the wave's scratch row (pair_math.h: energy_row)
+__device__ __forceinline__ void wave_energy(double e, double *dst) {
+  const double s = wave_sum(e);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(dst, s);  // dst: this wave's scratch row
+}
+
+
+__device__ __forceinline__ void flush_energies(const double *e, double *scratch) {
+  double *energies = energy_row(scratch);
+  wave_energy(e[TMDHIP_E_BONDS], energies + TMDHIP_E_BONDS);
+  wave_energy(e[TMDHIP_E_ANGLES], energies + TMDHIP_E_ANGLES);
+  wave_energy(e[TMDHIP_E_DIHEDRALS], energies + TMDHIP_E_DIHEDRALS);
+  wave_energy(e[TMDHIP_E_IMPROPERS], energies + TMDHIP_E_IMPROPERS);
+  wave_energy(e[TMDHIP_E_LJ], energies + TMDHIP_E_LJ);
+  wave_energy(e[TMDHIP_E_ELECTROSTATICS], energies + TMDHIP_E_ELECTROSTATICS);
+}
+
 }  // namespace
 }  // namespace tmd

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64) void allpairs_kernel(
     int n, const R *__restrict__ pos, const R *__restrict__ qs, const int *__restrict__ types, int ntypes,
     const typename Vec<R>::T2 *__restrict__ tab, const int *__restrict__ excl_off,
     const int *__restrict__ excl_idx, PairConsts<R> c, int jchunk, R *__restrict__ forces,
-    double *__restrict__ energies, unsigned long long *__restrict__ paircount, const R *__restrict__ boxes) {
+    double *__restrict__ energies, unsigned long long *__restrict__ paircount, const R *__restrict__ boxes,
+    int nsplit, BondedArgs<R> B) {
   using R4 = typename Vec<R>::T4;
   __shared__ R4 sj[64];
   __shared__ int st[64];
@@ -74,6 +75,32 @@ __global__ __launch_bounds__(64) void allpairs_kernel(
     }
   }
   const int lane = threadIdx.x;
+  if ((int)blockIdx.y >= nsplit) {
+    // rows of the grid beyond the pair blocks: the bonded terms of heavy topologies ride on this launch
+    // (small systems are launch-bound).  One wave per atom like bonded_wave_kernel; the force joins the
+    // pair blocks' partial sums with atomics.
+    const int a = ((int)blockIdx.y - nsplit) * (int)gridDim.x + (int)blockIdx.x;
+    if (a >= n) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      B.b.box[k] = c.box[k];
+      B.b.invbox[k] = c.invbox[k];
+    }
+    R bx = 0, by = 0, bz = 0;
+    double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = B.atom_off[a] + lane, qe = B.atom_off[a + 1]; q < qe; q += 64)
+      eval_entry<R>(B, pos, (unsigned)B.atom_ent[q], bx, by, bz, e);
+    bx = wave_sum(bx);
+    by = wave_sum(by);
+    bz = wave_sum(bz);
+    if (lane == 0 && forces) {
+      unsafeAtomicAdd(&forces[3 * a + 0], bx);
+      unsafeAtomicAdd(&forces[3 * a + 1], by);
+      unsafeAtomicAdd(&forces[3 * a + 2], bz);
+    }
+    if (ENERGY) flush_energies(e, energies);
+    return;
+  }
   const int i = blockIdx.x * 64 + lane;
   const bool active = i < n;
   const int jbeg = blockIdx.y * jchunk;
@@ -1257,11 +1284,13 @@ bool plan_grid(const tmdhip_ctx *ctx, const double *box, const double *lo, const
   return false;
 }
 
+constexpr size_t kRideMaxAtoms = 2048;  // bonded terms ride on the all-pairs launch up to this many atoms
 constexpr int kForcesZeroed = 1 << 17;  // internal: the integrator kernel has already cleared `forces`
 
 template <typename R>
 int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *forces, double *energies,
-                    int flags, unsigned long long *paircount, hipStream_t st, int nrep = 1) {
+                    int flags, unsigned long long *paircount, hipStream_t st, int nrep = 1,
+                    const BondedArgs<R> *bonded = nullptr) {
   // nrep > 1: pos/forces/energies/box are the arrays of all replicas ([nrep][n][3], [nrep][8], [nrep][3])
   // and one launch (grid.z = replica) serves them all — small systems are launch-bound
   const int n = ctx->d.natoms;
@@ -1279,18 +1308,21 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
   int nsplit = std::max(1, std::min((n + 15) / 16, 1024 / std::max(nb * nrep, 1)));
   int jchunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
   nsplit = (n + jchunk - 1) / jchunk;
-  dim3 grid(nb, nsplit, nrep);
+  // `bonded` (heavy topologies, MD loop): n more one-wave blocks evaluate the bonded terms in the same launch
+  dim3 grid(nb, nsplit + (bonded ? (n + nb - 1) / nb : 0), nrep);
+  const BondedArgs<R> B = bonded ? *bonded : BondedArgs<R>{};
   R *f = (flags & TMDHIP_WANT_FORCES) ? (R *)forces : nullptr;
   using R2 = typename Vec<R>::T2;
   if (flags & TMDHIP_WANT_ENERGY)
     hipLaunchKernelGGL((allpairs_kernel<R, true>), grid, dim3(64), 0, st, n, (const R *)pos,
                        ctx->qs.as<R>(), ctx->types.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),
                        ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, ctx->escratch.as<double>(),
-                       paircount, boxes);
+                       paircount, boxes, nsplit, B);
   else
     hipLaunchKernelGGL((allpairs_kernel<R, false>), grid, dim3(64), 0, st, n, (const R *)pos,
                        ctx->qs.as<R>(), ctx->types.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(),
-                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, nullptr, paircount, boxes);
+                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), c, jchunk, f, nullptr, paircount, boxes, nsplit,
+                       B);
   TMD_HIP(hipGetLastError());
   if (flags & TMDHIP_WANT_ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st, nrep));
   return 0;
@@ -1681,18 +1713,26 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         flags_c |= TMDHIP_WANT_ENERGY;
         en = d->energies_dev;
       }
+      const int bmode = tmd::bonded_inline_args(ctx, d->box_host, A);  // 0 none, 1 light, 2 heavy topology
+      bool bonded_done = bmode == 0;
       if (ctx->d.terms != 0) {
         for (auto &rp : ctx->rep) rp.n_compute++;
+        // heavy topologies, few atoms in total (launch-bound): the bonded terms ride on the all-pairs launch
+        // (one wave per atom).  Measured: alanine dipeptide x1 39 -> 32 us/step, but x16 replicas 84 -> 94.
+        const bool ride = bmode == 2 && (size_t)n * nrep <= kRideMaxAtoms;
         TMD_TRY(launch_allpairs<R>(ctx, pos, d->box_host, f, en, flags_c | TMDHIP_OVERWRITE_FORCES | kForcesZeroed,
-                                   nullptr, st, nrep));
+                                   nullptr, st, nrep, ride ? &A : nullptr));
+        bonded_done = bonded_done || ride;
       } else {
         TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride * nrep, st));
       }
-      if (it + 1 < d->niter && tmd::bonded_inline_args(ctx, d->box_host, A) == 1) {
-        TMD_TRY(ctx->pos_alt_all.ensure(sizeof(R) * stride * nrep));
-        bowed = true;  // the next integrator kernel evaluates this step's bonded force itself
-      } else {
-        TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos, d->box_host, f, en, flags_c, st));
+      if (!bonded_done) {
+        if (it + 1 < d->niter && bmode == 1) {
+          TMD_TRY(ctx->pos_alt_all.ensure(sizeof(R) * stride * nrep));
+          bowed = true;  // the next integrator kernel evaluates this step's bonded force itself
+        } else {
+          TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos, d->box_host, f, en, flags_c, st));
+        }
       }
       continue;
     }
@@ -1756,9 +1796,14 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
             return rc;
           }
         }
-        if (!list)
+        if (!list) {
+          // heavy topology, small system: bonded terms in the same launch
+          const bool ride = tmd::bonded_inline_args(ctx, box, A) == 2 && (size_t)n <= kRideMaxAtoms;
           TMD_TRY(launch_allpairs<R>(ctx, pos, box, f, en,
-                                     flags_c | TMDHIP_OVERWRITE_FORCES | (zeroed ? kForcesZeroed : 0), nullptr, st));
+                                     flags_c | TMDHIP_OVERWRITE_FORCES | (zeroed ? kForcesZeroed : 0), nullptr, st, 1,
+                                     ride ? &A : nullptr));
+          if (ride) continue;  // forces (and energies) of this step are complete
+        }
       } else {
         TMD_HIP(hipMemsetAsync(f, 0, sizeof(R) * stride, st));
       }
