@@ -281,6 +281,31 @@ def test_parameters_match_reference_ala2():
     assert np.array_equal(tio.read_xsc(os.path.join(d, "input.xsc")), g["box"])
 
 
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("folder", ["thrombin-ligand-amber", "benzamidine-amber", "ligand-amber"])
+def test_parameters_match_reference_prmtop_fixtures(folder):
+    """Own prmtop reader + `PrmtopForceField` + `Parameters` against the reference's `Parameters` fed with
+    the same objects, on the reference's AMBER fixtures (protein + ligand complex, two ligands: impropers, many atom types)."""
+    from torchmd_amd import io as tio
+    from torchmd_amd.forcefields import PrmtopForceField
+    from torchmd_amd.parameters import Parameters
+
+    _, RefParameters = _ref_modules()
+    path = os.path.join("/root/reference/tests/data", folder, "structure.prmtop")
+    if not os.path.exists(path):
+        pytest.skip(f"no {path}")
+    mol, top = tio.read_prmtop(path)
+    ff = PrmtopForceField(mol, top)
+    terms = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+    mine = Parameters(ff, mol, terms, precision=torch.float64)
+    ref = RefParameters(ff, mol, terms, precision=torch.float64)
+    for name in ("bond", "angle", "dihedral", "improper", "nonbonded_14"):
+        assert _same_table(getattr(mine, name + "_params"), getattr(ref, name + "_params")), name
+    assert torch.equal(mine.nonbonded_params["params"], ref.nonbonded_params["params"])
+    assert torch.equal(mine.mapped_atom_types, ref.mapped_atom_types)
+    assert sorted(map(tuple, mine.get_exclusions())) == sorted(map(tuple, ref.get_exclusions()))
+
+
 _DD_WORKER = r"""
 import os, sys, itertools
 sys.path.insert(0, sys.argv[1])
