@@ -30,20 +30,71 @@ TIMESTEP_FS = 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-TIMING_STRIDE = 16
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
+
+
+def timing_stride(steps):
+    """HIP events bracket every launch of the pair kernel for short runs and every 16th for long ones (an
+    event pair costs ~3 us of stream time), so that any --steps >= 8 yields >= 8 timed launches."""
+    return 1 if steps < 128 else 16
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/): counters
     cannot be collected inside the timed run, so the figure of the same kernel + workload measured with
-    `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` is reported, with its provenance."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` is reported, with its provenance (file and the commit the
+    PMC pass was run on)."""
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     try:
         with open(path) as fh:
             d = json.load(fh)
-        return float(d["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        return float(d["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT), d.get("commit")
     except Exception:
-        return None, None
+        return None, None, None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks ourselves, exactly as the
+    driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`), and pass their exit
+    code on.  Rank 0 of the children prints the one JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """Launcher / collective plumbing without a GPU (CPU test, `--backend gloo --dry`): the same process
+    group set-up, barriers, max-over-ranks timing and observable gather as the real run, no MD."""
+    import torch.distributed as dist
+
+    from torchmd_amd.replicas import ReplicaFanout
+
+    if world > 1:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    fan = ReplicaFanout(total_replicas=world, device=torch.device("cpu"))
+    fan.check_same_topology(np.arange(4))
+    fan.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    fan.barrier()
+    elapsed = fan.max_over_ranks(time.perf_counter() - t0)
+    obs = fan.gather_observables([float(rank)], [float(-rank)], [300.0])
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher test)", "value": 0.0, "unit": "ns/day", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+                          "dry": True, "ranks_seen": [int(x) for x in obs[:, 0]]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def ns_per_day(steps, seconds, timestep_fs=TIMESTEP_FS):
@@ -95,6 +146,7 @@ def cpu_baseline(par, system, box, budget_s=20.0):
         "unit": "ns/day",
         "cores": torch.get_num_threads(),
         "kind": "port",
+        "source": "oracle (pinned port of the reference arithmetic; /root/reference does not exist on the GPU box)",
         "s_per_step": el / n,
         "sample": f"{n} MD steps of the same {pos.shape[1]}-atom box (oracle/torchmd_oracle.py md_step, "
         f"{len(pairs)} candidate pairs, list build excluded)",
@@ -109,15 +161,23 @@ def main():
     ap.add_argument("--nside", type=int, default=32, help="molecules per box edge (32 -> 98 304 atoms)")
     ap.add_argument("--relax-steps", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--skin", type=float, default=None, help="Verlet skin in A (default: the library's 1.2)")
+    ap.add_argument("--skin", type=float, default=None, help="Verlet skin in A (default: the library's)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --dry)")
+    ap.add_argument("--dry", action="store_true", help="launcher/collective plumbing only, no GPU work (CPU test)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     from torchmd_amd.integrator import Integrator
     from torchmd_amd.replicas import ReplicaFanout, env_rank_world
 
     rank, world, local_rank = env_rank_world()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -128,7 +188,7 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # nccl = RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=device)  # nccl = RCCL on ROCm
     fan = ReplicaFanout(total_replicas=world, device=device)
 
     dtype = torch.float32
@@ -147,7 +207,8 @@ def main():
     st0 = forces.stats(system.pos)
     # HIP events around every 16th launch of the pair kernel, spread over the whole timed region (an event
     # pair costs ~3 us of stream time: timing every launch slowed the loop from 84 to 91 us/step)
-    forces.enable_timing(system.pos, True, every=TIMING_STRIDE)
+    stride = timing_stride(args.steps)
+    forces.enable_timing(system.pos, True, every=stride)
     forces.read_timing(system.pos, reset=True)
     fan.barrier()
     torch.cuda.synchronize()
@@ -174,7 +235,7 @@ def main():
     pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
     achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
     step_bytes = 4.0 * pcut + 132.0 * natoms  # whole step incl. integrator
-    traffic, traffic_src = pmc_traffic() if (args.nside == 32) else (None, None)
+    traffic, traffic_src, traffic_commit = pmc_traffic() if (args.nside == 32) else (None, None, None)
 
     out = {
         "metric": "ns/day (aggregate over replicas), 100k-atom TIP3P water box, 9 A cutoff + reaction field",
@@ -220,10 +281,12 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_src,
+            "traffic_commit": traffic_commit,
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_kernel_us": pair_avg_s * 1e6,
             "launches_timed": int(pair_launches),
-            "timing": f"HIP events on the launch stream around every {TIMING_STRIDE}th pair-kernel launch of the timed region",
+            "timing": f"HIP events on the launch stream around every {stride}th pair-kernel launch of the timed region"
+            if stride > 1 else "HIP events on the launch stream around every pair-kernel launch of the timed region",
             "step_frac_of_hbm_roofline": (step_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
         },
     }
