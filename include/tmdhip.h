@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TMDHIP_ABI_VERSION 1
+#define TMDHIP_ABI_VERSION 2
 
 /* dtype */
 #define TMDHIP_F32 0
@@ -93,6 +93,10 @@ typedef struct tmdhip_nonbonded_desc {
   int32_t switch_mode;         /* TMDHIP_SWITCH_*                                          */
   int32_t algorithm;           /* TMDHIP_ALGO_*                                            */
   double skin;                 /* Verlet skin in Angstrom; <= 0: library default (1.2)     */
+  int32_t rebuild_every;       /* tmdhip_md_run enqueues the list-rebuild chain (5 launches that return at once
+                                  unless the device-side displacement test asked for a rebuild) on every E-th
+                                  step only; <= 0 or 1: every step (default)                   */
+  int32_t reserved0;
 } tmdhip_nonbonded_desc;
 
 /* Bonded topology (already expanded: one parameter row per instance).  Replaces the per-call
@@ -131,6 +135,9 @@ typedef struct tmdhip_stats {
   int32_t max_neighbours;   /* list capacity per atom                                       */
   int32_t overflow;         /* != 0: a list is currently truncated (see tmdhip_check)       */
   int32_t ncell[3];
+  int32_t violation;        /* != 0: the list outlived its skin between two scheduled rebuilds (see tmdhip_check) */
+  int32_t rebuild_every;
+  double skin;
 } tmdhip_stats;
 
 int tmdhip_abi_version(void);
@@ -157,9 +164,11 @@ int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, 
 int tmdhip_compute_bonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, const double *box_host,
                           void *forces_dev, double *energies_dev, int flags, void *stream);
 
-/* Synchronises `stream` and verifies that no device-side neighbour-list rebuild since the last check
- * ran out of list capacity.  Returns 0 = results valid, 1 = a list was truncated: the capacity has been
- * grown, the next compute rebuilds, and the caller must repeat the evaluation; negative = error. */
+/* Synchronises `stream` and verifies that the neighbour lists used since the last check were valid: no
+ * device-side rebuild ran out of list capacity, and no atom moved further than skin/2 on an MD step that
+ * did not enqueue the rebuild chain (tmdhip_nonbonded_desc.rebuild_every).  Returns 0 = results valid; 1 = not valid: capacity has been grown /
+ * the next compute rebuilds, and the caller must repeat the work (a plain evaluation is simply repeated; an
+ * MD batch is rewound with tmdhip_md_restore and run again); negative = error. */
 int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream);
 
 /* `niter` iterations of Integrator.step's loop (integrator.py:115-120) for every replica, enqueued from
@@ -181,6 +190,11 @@ typedef struct tmdhip_md_desc {
   double *energies_dev;                 /* [R*TMDHIP_NENERGY]: += energies of the LAST iteration, or NULL */
 } tmdhip_md_desc;
 int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
+/* Rewind: copy the state tmdhip_md_run saved at its entry (positions, velocities, forces of every replica)
+ * back into desc's buffers and make the next tmdhip_md_run enqueue the rebuild chain on every step (no
+ * scheduled-rebuild violation possible).  Used after tmdhip_check returned 1 for an MD batch; the noise
+ * stream is counter based, so the repeated batch is the same trajectory. */
+int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
 
 /* Atomic systems only (no exclusions, no bonded terms): replace the atom set of the context — new count,
  * types and charges; the LJ table and all options stay — and mark atoms with index >= nactive (<= 0: none)

@@ -18,6 +18,7 @@ LIBPATH = os.path.join(LIBDIR, "libtmdhip.so")
 SOURCES = ["nonbonded.hip", "bonded.hip", "integrator.hip"]
 HEADERS = ["common.h", "pair_math.h", "rng.h", "bonded_math.h", os.path.join("..", "..", "include", "tmdhip.h")]
 ARCH = "gfx950"
+FLAGS = ["-fno-slp-vectorize"]  # the SLP vectoriser packs the pair kernel into v_pk_* ops + v_mov transposes: measured slower
 
 
 def _hipcc():
@@ -35,8 +36,10 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > built for d in deps if os.path.exists(d))
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """Compile the library.  `extra_flags` / `out`: developer knobs for A/B builds (see TMDHIP_LIB in _lib.py)."""
+    target = out or LIBPATH
+    if not force and not out and not is_stale():
         return LIBPATH
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [
@@ -48,18 +51,22 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         "-shared",
         "-Wall",
         "-Wno-unused-function",
+        *FLAGS,
+        *extra_flags,
         *[os.path.join(CSRC, s) for s in SOURCES],
         "-o",
-        LIBPATH + ".tmp",
+        target + ".tmp",
     ]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
-    os.replace(LIBPATH + ".tmp", LIBPATH)
-    return LIBPATH
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    extra = [a for a in sys.argv[1:] if a.startswith("-f") or a.startswith("-m")]
+    out = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")), None)
+    print(build_library(force="--force" in sys.argv, verbose=True, extra_flags=extra, out=out))

@@ -10,9 +10,10 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(PKG, "lib", "libtmdhip.so")
+# TMDHIP_LIB: developer knob for A/B runs of differently built libraries (kernel experiments)
+LIBPATH = os.environ.get("TMDHIP_LIB") or os.path.join(PKG, "lib", "libtmdhip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, F64 = 0, 1
 TERM_LJ, TERM_ELECTROSTATICS, TERM_REPULSION, TERM_REPULSIONCG = 1, 2, 4, 8
 E_LJ, E_ELECTROSTATICS, E_REPULSION, E_REPULSIONCG, E_BONDS, E_ANGLES, E_DIHEDRALS, E_IMPROPERS = range(8)
@@ -62,6 +63,8 @@ class NonbondedDesc(C.Structure):
         ("switch_mode", C.c_int32),
         ("algorithm", C.c_int32),
         ("skin", C.c_double),
+        ("rebuild_every", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -120,6 +123,9 @@ class Stats(C.Structure):
         ("max_neighbours", C.c_int32),
         ("overflow", C.c_int32),
         ("ncell", C.c_int32 * 3),
+        ("violation", C.c_int32),
+        ("rebuild_every", C.c_int32),
+        ("skin", C.c_double),
     ]
 
 
@@ -140,6 +146,7 @@ SIGNATURES = {
     ),
     "tmdhip_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "tmdhip_md_run": (C.c_int, [C.c_void_p, C.POINTER(MdDesc), C.c_void_p]),
+    "tmdhip_md_restore": (C.c_int, [C.c_void_p, C.POINTER(MdDesc), C.c_void_p]),
     "tmdhip_invalidate_list": (C.c_int, [C.c_void_p, C.c_int]),
     "tmdhip_update_atoms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "tmdhip_get_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Stats)]),

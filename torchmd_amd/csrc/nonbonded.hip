@@ -14,9 +14,10 @@
 //   sorted_type  int32[N]
 //   order        int32[N]   cell-sorted slot -> original atom index
 //   nlist        uint32[G * maxn * APW]   G = ceil(N/APW) wave groups, APW = 64/LPA atoms per wave;
-//                entry k of the a-th atom of group g lives at  g*maxn*APW + (k/LPA)*64 + a*LPA + k%LPA
-//                so that one wave-wide load of iteration kk reads 64 consecutive words (256 B).
-//                entry = j (24 bit, sorted slot) | type_j << 24
+//                entry k of the a-th atom of group g belongs to lane l = a*LPA + k%LPA, iteration kk = k/LPA,
+//                and lives at  g*maxn*APW + ((kk/4)*64 + l)*4 + kk%4 : a lane's entries of four consecutive
+//                iterations are one 16-byte word, so one wave-wide dwordx4 load reads 1 KB of contiguous list.
+//                entry = type_j << 28 | j << 4 (j = sorted slot)
 //   nneigh       int32[N]
 #include <hip/hip_runtime.h>
 
@@ -213,22 +214,51 @@ __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
   return x - floor(x * invbox) * box;
 }
 
-// flags[p] = "rebuild requested in the step with parity p".  The check kernel of parity p may only
-// SET flags[p] and CLEAR flags[p^1]; every other kernel of that step only reads flags[p].
+// Device-side list bookkeeping of one replica: int flags[F_COUNT].
+//   F_REBUILD0/1  rebuild requested in the step with parity 0/1.  The check of a step with parity p may only
+//                 SET flags[p] and CLEAR flags[p^1]; every other kernel of that step only reads flags[p].
+//   F_MAXN        largest neighbour count seen by a build (> capacity: a list was truncated)
+//   F_NREBUILD    rebuild counter
+//   F_VIOLATION   sticky: the list outlived its skin on a step that did not enqueue the rebuild chain
+enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_COUNT = 8 };
+
+// Displacement test that drives the rebuilds (thresholds are squared distances).  The list (cutoff + skin) is
+// valid while no atom has moved further than skin/2 from `ref`.  The rebuild chain (5 launches that return at
+// once unless the flag is set: ~8 us per step at C3) is only enqueued on "eligible" steps — every E-th MD step,
+// decided on the host — so a rebuild is requested early, at `early2` < `hard2` = (skin/2)^2, and a
+// displacement beyond hard2 on a step without chain sets the sticky F_VIOLATION flag: the caller rewinds the
+// batch (tmdhip_md_restore) and repeats it with the chain on every step.
 template <typename R>
-__global__ void check_displacement_kernel(int n, const R *__restrict__ pos, const R *__restrict__ ref,
-                                          PairConsts<R> c, R thresh2, int *flags, int parity, int force) {
+struct ListCheck {
+  const R *ref;     // positions at the last list build, original atom order [3N]
+  R early2, hard2;
+  int *flags;
+  int parity;
+  int eligible;     // the rebuild chain is enqueued in this step
+};
+
+template <typename R>
+__device__ __forceinline__ void list_check_atom(const ListCheck<R> &k, const PairConsts<R> &c, int i, R px, R py, R pz) {
+  const R dx = min_image(px - k.ref[3 * i + 0], c.box[0], c.invbox[0]);
+  const R dy = min_image(py - k.ref[3 * i + 1], c.box[1], c.invbox[1]);
+  const R dz = min_image(pz - k.ref[3 * i + 2], c.box[2], c.invbox[2]);
+  const R d2 = dx * dx + dy * dy + dz * dz;
+  if (!(d2 <= k.early2)) k.flags[F_REBUILD0 + k.parity] = 1;  // NaN positions also force a rebuild
+  if (!k.eligible && !(d2 <= k.hard2)) k.flags[F_VIOLATION] = 1;
+}
+
+// thread 0 of the check of a step: the other parity's request is history
+__device__ __forceinline__ void list_check_clear(int *flags, int parity) { flags[F_REBUILD0 + (parity ^ 1)] = 0; }
+
+template <typename R>
+__global__ void check_displacement_kernel(int n, const R *__restrict__ pos, ListCheck<R> k, PairConsts<R> c, int force) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
-    flags[parity ^ 1] = 0;
-    if (force) flags[parity] = 1;
+    list_check_clear(k.flags, k.parity);
+    if (force) k.flags[F_REBUILD0 + k.parity] = 1;
   }
   if (i >= n || force) return;
-  const R dx = min_image(pos[3 * i + 0] - ref[3 * i + 0], c.box[0], c.invbox[0]);
-  const R dy = min_image(pos[3 * i + 1] - ref[3 * i + 1], c.box[1], c.invbox[1]);
-  const R dz = min_image(pos[3 * i + 2] - ref[3 * i + 2], c.box[2], c.invbox[2]);
-  const R d2 = dx * dx + dy * dy + dz * dz;
-  if (!(d2 <= thresh2)) flags[parity] = 1;  // NaN positions also force a rebuild
+  list_check_atom<R>(k, c, i, pos[3 * i + 0], pos[3 * i + 1], pos[3 * i + 2]);
 }
 
 template <typename R>
@@ -325,7 +355,7 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
 template <typename R>
 __global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const int *__restrict__ order,
                                      typename Vec<R>::T4 *__restrict__ sorted, const int *flag) {
-  if (*flag) return;  // place_sorted_kernel has just written everything
+  if (flag && *flag) return;  // place_sorted_kernel has just written everything
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
   const int i = order[a];
@@ -333,6 +363,13 @@ __global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const int
   sorted[a].y = pos[3 * i + 1];
   sorted[a].z = pos[3 * i + 2];
 }
+
+// list entry = type_j << 28 | j << 4 (j = cell-sorted slot, 24 bits): `entry & kEntryOffMask` is the byte offset
+// of atom j's float4 record, `entry >> 24` the byte offset of type j in a 16-byte-stride LDS table row (for
+// n <= 2^20).  Contexts with more than kEntryTypes LJ classes leave the type field 0 (kernels read stype[j]).
+constexpr unsigned kEntryOffMask = 0x0FFFFFF0u;  // byte offset of atom j's float4 record
+constexpr int kEntryTypes = 16;                  // LJ classes that fit the entry's type field
+constexpr float kR2Floor = 1.0e-2f;  // (0.1 A)^2: keeps 1/r^14 finite for the self entries that pad a column
 
 struct ListGeom {
   int lpa;        // lanes per atom in the pair kernel (power of two, 1..64)
@@ -344,8 +381,8 @@ struct ListGeom {
 __device__ __forceinline__ size_t list_slot(const ListGeom &lg, int a, int k) {
   const int apw_shift = 6 - lg.lpa_shift;
   const int g = a >> apw_shift, ain = a & (lg.apw - 1);
-  return ((size_t)g * lg.maxn << apw_shift) + ((size_t)(k >> lg.lpa_shift) << 6) + (ain << lg.lpa_shift) +
-         (k & (lg.lpa - 1));
+  const int kk = k >> lg.lpa_shift, l = (ain << lg.lpa_shift) + (k & (lg.lpa - 1));
+  return ((size_t)g * lg.maxn << apw_shift) + ((size_t)(((kk >> 2) << 6) + l) << 2) + (kk & 3);
 }
 
 // ---- K2: Verlet list build ---------------------------------------------------------------------
@@ -360,7 +397,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
-    int ncell, int nactive) {
+    int ncell, int nactive, int type_in_entry) {
   if (*flag == 0) return;
   using R4 = typename Vec<R>::T4;
   __shared__ int seg_start[128];
@@ -374,7 +411,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   int cell = blockIdx.x;
   do {
   const int cs = cell_start[cell], ce = cell_start[cell + 1];
-  if (cell == 0 && lane == 0) status[1] += 1;  // flags[3]: number of rebuilds
+  if (cell == 0 && lane == 0) status[1] += 1;  // flags[F_NREBUILD]
   if (cs == ce) continue;
   __syncthreads();  // LDS tables of the previous cell are no longer read
   const int cz = cell % g.nc[2], cy = (cell / g.nc[2]) % g.nc[1], cx = cell / (g.nc[2] * g.nc[1]);
@@ -475,7 +512,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       p.y = wrap_into_box(p.y, c.box[1], c.invbox[1]);
       p.z = wrap_into_box(p.z, c.box[2], c.invbox[2]);
       const unsigned rowoff = (((unsigned)(a >> apw_shift) * (unsigned)lg.maxn) << apw_shift) +
-                              ((unsigned)(a & (lg.apw - 1)) << lg.lpa_shift);
+                              ((unsigned)(a & (lg.apw - 1)) << (lg.lpa_shift + 2));
       if constexpr (sizeof(R) == 4) p.w = __uint_as_float(rowoff);
       else p.w = __longlong_as_double((long long)rowoff);
       const int oi = order[a];
@@ -524,7 +561,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       const int j = nx_j, code = nx_code;
       const bool valid = nx_valid;
       const unsigned oj = (unsigned)nx_order;
-      const unsigned entry = (unsigned)j | ((unsigned)nx_type << 24);
+      const unsigned entry = ((unsigned)j << 4) | (type_in_entry ? (unsigned)nx_type << 28 : 0u);
       if (q0 + 64 < ncand) fetch(q0 + 64);
       // candidate position as the periodic image that lies next to this cell: the i loop then needs
       // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
@@ -554,7 +591,8 @@ __global__ __launch_bounds__(64) void build_list_kernel(
           unsigned rowoff;
           if constexpr (sizeof(R) == 4) rowoff = __float_as_uint(pi.w);
           else rowoff = (unsigned)__double_as_longlong(pi.w);
-          nlist[rowoff + ((k >> lg.lpa_shift) << 6) + (k & kmask)] = entry;
+          const unsigned kk = k >> lg.lpa_shift;
+          nlist[rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u)] = entry;
         }
         s_cnt[t] = base + (int)__popcll(mask);  // every lane writes the same value
       };
@@ -648,7 +686,7 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
 #pragma unroll
   for (int o = 32; o >= LPA; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
   const int nkk = (nmax + LPA - 1) / LPA;
-  const unsigned *row = nlist + (size_t)wave * maxn * APW + lane;
+  const unsigned *row = nlist + (size_t)wave * maxn * APW + lane * 4;  // + (kk / 4) * 256 + kk % 4
 
   R fx = 0, fy = 0, fz = 0;
   R en[4] = {0, 0, 0, 0};
@@ -657,12 +695,15 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
     unsigned entry[UNROLL];
     R4 pj[UNROLL];
     bool valid[UNROLL];
+    int jdx[UNROLL], tj[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) entry[u] = (kk0 + u < nkk) ? row[(size_t)(kk0 + u) * 64] : 0u;
+    for (int u = 0; u < UNROLL; ++u) entry[u] = (kk0 + u < nkk) ? row[(size_t)(kk0 >> 2) * 256 + u] : 0u;
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       valid[u] = (kk0 + u) * LPA + sub < nn;
-      pj[u] = sorted[valid[u] ? (int)(entry[u] & 0xFFFFFFu) : aself];
+      jdx[u] = valid[u] ? (int)((entry[u] >> 4) & 0xFFFFFFu) : aself;
+      pj[u] = sorted[jdx[u]];
+      tj[u] = !valid[u] ? 0 : (ntypes <= kEntryTypes ? (int)(entry[u] >> 28) : stype[jdx[u]]);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -671,7 +712,7 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
       const R dz = min_image(pi.z - pj[u].z, c.box[2], c.invbox[2]);
       const R r2 = norm2(dx, dy, dz);
       const bool hit = valid[u] && (r2 <= c.r2max);
-      const R2 ab = stab[trow + (valid[u] ? (int)(entry[u] >> 24) : 0)];
+      const R2 ab = stab[trow + tj[u]];
       const R r2s = hit ? r2 : R(1);
       R fs;
       if (FAST == 1 && !ENERGY) {
@@ -722,33 +763,38 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
   }
 }
 
-// ---- K3f: packed-fp32 specialisation of the list pair kernel ------------------------------------
-// PMC (profiles/): the pair kernel is VALU-bound — 48 wave-instructions per 64 list entries at ~4
-// cycles each (SQ_ACTIVE_INST_VALU ~ 86 % of the kernel time), so the lever is instruction count.
-// On gfx950 a plain fp32 VALU op retires one result per lane, v_pk_{add,mul,fma}_f32 two.  This
-// kernel therefore evaluates list entries two at a time on float2 vectors (every add/mul/fma of the
-// minimum image, |d|^2, LJ and reaction-field maths becomes a v_pk_* instruction), gathers j through
-// 32-bit byte offsets against a scalar base (saddr addressing, no 64-bit address arithmetic), and
-// reads a pre-scaled (-12A, 6B) table from LDS.  Same decision arithmetic (bit-exact) as pair_math.h:
-// packed ops round exactly like their scalar forms.  Terms: LJ and/or electrostatics (plain Coulomb or
+// ---- K3f: lean fp32 specialisation of the list pair kernel ---------------------------------------
+// Issue-rate measurements on gfx950 (tools/ubench/valu_rates.hip, 8 waves per SIMD): a plain fp32 / integer
+// VALU op (v_fma_f32, v_mul, v_add, v_and, v_mov, v_cndmask) retires in ~2.3 cycles per wave, a PACKED op
+// (v_pk_fma/mul/add_f32) in ~4.3 — packing two entries into one instruction buys no ALU throughput on this
+// chip — 32-bit shifts and v_mul_u32_u24 run at half rate (4.2), v_cmp costs 5.3, v_rsq/v_rcp 8.2.  The first
+// version of this kernel evaluated entries two at a time on float2 vectors: 60 packed ops + 47 v_mov
+// (transposes of {pj[u].x, pj[u+1].x} into register pairs) per 4 entries = ~155 cycles per entry.  This
+// version is plain scalar code on the natural float4 record: ~32 full-rate ops + 1 v_cmp + 1 v_rsq per
+// entry (~85 cycles), no transposes, no shifts:
+//   entry = type << 28 | j << 4      -> gather offset = entry & 0x0FFFFFF0 (one v_and), LDS table address
+//                                       = (type_i << 8) | entry >> 24 (one SDWA v_or; table rows of 16 x 16 B)
+//   minimum image by the magic-number trick (3 ops per component, bit-exact, see min_image_magic)
+//   force scale factored as  rinv2 * ((a12 rinv6 + b6) rinv6 - qq rinv) + qq 2 krf   (9 ops)
+// Same decision arithmetic (bit-exact) as pair_math.h.  Terms: LJ and/or electrostatics (plain Coulomb or
 // reaction field), optionally the LJ switching function (SWITCH) and the per-term energies (ENERGY);
-// repulsion terms, fp64 and pair counting take list_pair_kernel.
-typedef float v2f __attribute__((ext_vector_type(2)));
+// repulsion terms, fp64, more than 16 LJ classes and pair counting take list_pair_kernel.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // k = round-half-even(d / box) by the magic-number trick: fma(d, 1/box, 1.5*2^23) - 1.5*2^23 is exact
-// round-to-nearest-even for |d/box| < 2^22 and is two packed instructions for two list entries, where
-// v_rndne_f32 has no packed form.  It differs from rndne(fl(d*invbox)) only when d/box lies within one
-// rounding error of a half-integer, i.e. |d| ~ box/2 >= cutoff, where the pair is rejected either way
-// (same argument as for d*invbox vs d/box in pair_math.h).  k is -1, 0 or 1 for every listed pair, so
-// box*k is exact and the fused d - box*k equals the reference's separately rounded `d - box*round(d/box)`.
-__device__ __forceinline__ v2f min_image2(v2f d, float box, float invbox) {
+// round-to-nearest-even for |d/box| < 2^22 (v_rndne_f32 would be a fourth instruction).  It differs from
+// rndne(fl(d*invbox)) only when d/box lies within one rounding error of a half-integer, i.e. |d| ~ box/2 >=
+// cutoff, where the pair is rejected either way (same argument as for d*invbox vs d/box in pair_math.h).
+// k is -1, 0 or 1 for every listed pair, so box*k is exact and the fused d - box*k equals the reference's
+// separately rounded `d - box*round(d/box)`.
+__device__ __forceinline__ float min_image_magic(float d, float box, float invbox) {
 #pragma clang fp contract(off)
-  const v2f magic = {12582912.0f, 12582912.0f};
-  const v2f t = __builtin_elementwise_fma(d, v2f{invbox, invbox}, magic);
-  const v2f k = t - magic;
-  return __builtin_elementwise_fma(-k, v2f{box, box}, d);
+  const float magic = 12582912.0f;
+  const float t = __builtin_fmaf(d, invbox, magic);
+  const float k = t - magic;
+  return __builtin_fmaf(-k, box, d);
 }
+
 
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH>
 __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
@@ -758,11 +804,12 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     double *__restrict__ energies) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
-  extern __shared__ __align__(16) unsigned char smem[];
-  float2 *stab = reinterpret_cast<float2 *>(smem);  // (-12 A, 6 B)
-  for (int t = threadIdx.x; t < ntypes * ntypes; t += blockDim.x) {
-    const float2 ab = tab[t];
-    stab[t] = make_float2(-12.0f * ab.x, 6.0f * ab.y);
+  __shared__ __align__(16) float4 stab[kEntryTypes * kEntryTypes];  // row of type i: 16 x {-12 A, 6 B, A, B}
+  for (int t = threadIdx.x; t < kEntryTypes * kEntryTypes; t += blockDim.x) {
+    const int ti = t >> 4, tj = t & 15;
+    float2 ab = make_float2(0.f, 0.f);
+    if (ti < ntypes && tj < ntypes) ab = tab[ti * ntypes + tj];
+    stab[t] = make_float4(-12.0f * ab.x, 6.0f * ab.y, ab.x, ab.y);
   }
   __syncthreads();
 
@@ -779,105 +826,116 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   const bool active = a < n;
   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
   int nn = 0;
-  unsigned trow8 = 0;  // byte offset of this atom's row of the LDS table
+  unsigned trow = 0;  // byte offset of this atom's row of the LDS table
   if (active) {
     pi = sorted[a];
     nn = nneigh[a];
-    trow8 = (unsigned)(stype[a] * ntypes) * 8u;
+    trow = (unsigned)stype[a] << 8;
   }
-  int nmax = nn;
-#pragma unroll
-  for (int o = 32; o >= LPA; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-  const int nkk = (nmax + LPA - 1) / LPA;
   const int myiters = (nn - sub + LPA - 1) / LPA;  // entries kk < myiters are real for this lane
-  const unsigned *row = nlist + (size_t)wave * maxn * APW + lane;
+  int itmax = myiters, itmin = myiters;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    itmax = max(itmax, __shfl_xor(itmax, o, 64));
+    itmin = min(itmin, __shfl_xor(itmin, o, 64));
+  }
+  const int nkk = __builtin_amdgcn_readfirstlane(itmax);
+  const int nfull = __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL;  // iterations every lane has entries for
+  // a lane's entries of iterations 4G .. 4G+3 are one 16-byte word at row4[G * 64]
+  const v4u *row4 = reinterpret_cast<const v4u *>(nlist + (size_t)wave * maxn * APW) + lane;
   // bounds-checked raw buffer over sorted_xyzq: lanes past the end of their list read whatever the
   // (uninitialised) padding entry points at — out-of-range offsets return 0 instead of faulting — and
-  // are discarded by `valid`; this removes every per-entry select from the address path
+  // are discarded by `valid`
   const __amdgpu_buffer_rsrc_t srsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(sorted), 0, n * 16, 0x00020000);
   const char *tbase = reinterpret_cast<const char *>(stab);
-  const v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, piz = {pi.z, pi.z}, piw = {pi.w, pi.w};
   const float two_krf = 2.0f * c.krf;
+  const float qi2k = pi.w * two_krf;
   const float sw_ir = c.inv_switch_range, sw_t0 = -c.switch_dist * c.inv_switch_range;
+  const float bx = c.box[0], by = c.box[1], bz = c.box[2];
+  const float ibx = c.invbox[0], iby = c.invbox[1], ibz = c.invbox[2];
+  const float r2max = c.r2max;
 
-  v2f fx = {0.f, 0.f}, fy = {0.f, 0.f}, fz = {0.f, 0.f};
-  v2f e_lj = {0.f, 0.f}, e_el = {0.f, 0.f};  // per-lane fp32 partial sums (~55 pairs), reduced in fp64
-  unsigned next[UNROLL];  // index words of the next group, fetched one group ahead of their use
-#pragma unroll
-  for (int u = 0; u < UNROLL; ++u) next[u] = row[(size_t)u * 64];  // rows are padded: always readable
-  for (int kk0 = 0; kk0 < nkk; kk0 += UNROLL) {
-    unsigned entry[UNROLL];
-    float4 pj[UNROLL];
-    float2 ab[UNROLL];
-    bool valid[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) entry[u] = next[u];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      valid[u] = kk0 + u < myiters;
-      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (entry[u] << 4) & 0x0FFFFFF0u, 0, 0);
-      pj[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
-                          __uint_as_float(raw.w));
-      if (LJ) ab[u] = *reinterpret_cast<const float2 *>(tbase + (trow8 + ((entry[u] >> 21) & 0x7F8u)));
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) next[u] = row[(size_t)(kk0 + UNROLL + u) * 64];
-#pragma unroll
-    for (int u = 0; u < UNROLL; u += 2) {
-      const v2f pjx = {pj[u].x, pj[u + 1].x}, pjy = {pj[u].y, pj[u + 1].y}, pjz = {pj[u].z, pj[u + 1].z};
-      const v2f pjw = {pj[u].w, pj[u + 1].w};
-      const v2f dx = min_image2(pix - pjx, c.box[0], c.invbox[0]);
-      const v2f dy = min_image2(piy - pjy, c.box[1], c.invbox[1]);
-      const v2f dz = min_image2(piz - pjz, c.box[2], c.invbox[2]);
-      const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-      const bool h0 = valid[u] && (r2.x <= c.r2max), h1 = valid[u + 1] && (r2.y <= c.r2max);
-      // forces only: rejected entries may produce inf/NaN below, the final select discards them
-      const v2f r2s = ENERGY ? v2f{h0 ? r2.x : 1.0f, h1 ? r2.y : 1.0f} : r2;  // (SWITCH: still discarded)
-      const v2f rinv = {__frsqrt_rn(r2s.x), __frsqrt_rn(r2s.y)};
-      const v2f rinv2 = rinv * rinv;
-      const v2f rinv6 = rinv2 * rinv2 * rinv2;
-      // (dE_lj/dr + dE_el/dr) / r  with a12 = -12 A, b6 = 6 B; two_krf = 0 gives plain Coulomb
-      v2f fs = {0.f, 0.f};
-      v2f sw = {1.f, 1.f};  // switching function S(r) of the LJ term (forces.py:402-412), 1 below switch_dist
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  float e_lj = 0.f, e_el = 0.f;  // per-lane fp32 partial sums (~55 pairs), reduced in fp64
+
+  auto body = [&](unsigned tofs, const v4u &raw, bool valid) {  // one list entry
+    const float pjx = __uint_as_float(raw.x), pjy = __uint_as_float(raw.y), pjz = __uint_as_float(raw.z);
+    const float pjw = __uint_as_float(raw.w);
+    const float dx = min_image_magic(pi.x - pjx, bx, ibx);
+    const float dy = min_image_magic(pi.y - pjy, by, iby);
+    const float dz = min_image_magic(pi.z - pjz, bz, ibz);
+    const float r2 = norm2(dx, dy, dz);
+    const bool hit = valid && (r2 <= r2max);
+    const float rinv = __frsqrt_rn(r2);
+    const float rinv2 = rinv * rinv;
+    const float rinv6 = rinv2 * rinv2 * rinv2;
+    float fs;  // (dE/dr) / r; rejected entries may produce inf/NaN here, the select below discards them
+    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LJ) ab = *reinterpret_cast<const float4 *>(tbase + (trow | tofs));
+    if (LJ && !SWITCH && ELEC) {
+      const float qq = pi.w * pjw;
+      const float p = __builtin_fmaf(ab.x, rinv6, ab.y) * rinv6;  // (a12 rinv6 + b6) rinv6
+      const float g = __builtin_fmaf(-qq, rinv, p);
+      fs = __builtin_fmaf(rinv2, g, qi2k * pjw);
+      if (ENERGY) e_lj += hit ? (__builtin_fmaf(ab.z, rinv6, -ab.w) * rinv6) : 0.f;
+    } else {
+      fs = 0.f;
+      float sw = 1.f;  // switching function S(r) of the LJ term (forces.py:402-412), 1 below switch_dist
       if (LJ) {
-        const v2f a12 = {ab[u].x, ab[u + 1].x}, b6 = {ab[u].y, ab[u + 1].y};
-        fs = __builtin_elementwise_fma(a12, rinv6, b6) * (rinv6 * rinv2);
+        fs = __builtin_fmaf(ab.x, rinv6, ab.y) * (rinv6 * rinv2);
         if (SWITCH) {
           // t = (r - r_s)/(r_c - r_s) clamped at 0: S = 1 + t^3 (-10 + t (15 - 6 t)),
           // S' = t^2 (-30 + t (60 - 30 t)) / (r_c - r_s);  (dE/dr)/r = S f + E S' x, x = 1/r (exact) or
           // 1/r^2 (the reference's explicit-force expression divides the switching term by r once more)
-          const v2f r = r2s * rinv;
-          v2f t = __builtin_elementwise_fma(r, v2f{sw_ir, sw_ir}, v2f{sw_t0, sw_t0});
-          t = v2f{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f)};
-          const v2f t2 = t * t;
-          const v2f p = __builtin_elementwise_fma(t, __builtin_elementwise_fma(t, v2f{-6.f, -6.f}, v2f{15.f, 15.f}),
-                                                  v2f{-10.f, -10.f});
-          sw = __builtin_elementwise_fma(t2 * t, p, v2f{1.f, 1.f});
-          const v2f dq = __builtin_elementwise_fma(
-              t, __builtin_elementwise_fma(t, v2f{-30.f * sw_ir, -30.f * sw_ir}, v2f{60.f * sw_ir, 60.f * sw_ir}),
-              v2f{-30.f * sw_ir, -30.f * sw_ir});
-          const v2f elj = (__builtin_elementwise_fma(a12 * (-1.0f / 12.0f), rinv6, b6 * (-1.0f / 6.0f))) * rinv6;
-          const v2f x = c.switch_reference_mode ? rinv2 : rinv;
-          fs = __builtin_elementwise_fma(sw, fs, elj * (t2 * dq) * x);
+          const float r = r2 * rinv;
+          const float t = fmaxf(__builtin_fmaf(r, sw_ir, sw_t0), 0.f);
+          const float t2 = t * t;
+          const float pp = __builtin_fmaf(t, __builtin_fmaf(t, -6.f, 15.f), -10.f);
+          sw = __builtin_fmaf(t2 * t, pp, 1.f);
+          const float dq = __builtin_fmaf(t, __builtin_fmaf(t, -30.f * sw_ir, 60.f * sw_ir), -30.f * sw_ir);
+          const float elj = __builtin_fmaf(ab.z, rinv6, -ab.w) * rinv6;
+          const float x = c.switch_reference_mode ? rinv2 : rinv;
+          fs = __builtin_fmaf(sw, fs, elj * (t2 * dq) * x);
         }
+        if (ENERGY) e_lj += hit ? sw * (__builtin_fmaf(ab.z, rinv6, -ab.w) * rinv6) : 0.f;
       }
-      if (ELEC) fs += (piw * pjw) * (two_krf - rinv2 * rinv);
-      if (ENERGY) {
-        const v2f hm = {h0 ? 1.0f : 0.0f, h1 ? 1.0f : 0.0f};
-        if (LJ) {  // E = (A r^-6 - B) r^-6 with the table holding (-12 A, 6 B)
-          const v2f a12 = {ab[u].x, ab[u + 1].x}, b6 = {ab[u].y, ab[u + 1].y};
-          e_lj += hm * sw * ((a12 * (-1.0f / 12.0f)) * rinv6 - b6 * (1.0f / 6.0f)) * rinv6;
-        }
-        if (ELEC) e_el += hm * (piw * pjw) * (rinv + c.krf * r2s - c.crf);  // krf = crf = 0: plain Coulomb
-      }
-      fs = v2f{h0 ? fs.x : 0.0f, h1 ? fs.y : 0.0f};
-      fx -= dx * fs;
-      fy -= dy * fs;
-      fz -= dz * fs;
+      if (ELEC) fs += (pi.w * pjw) * (two_krf - rinv2 * rinv);
     }
+    if (ENERGY && ELEC) e_el += hit ? (pi.w * pjw) * (rinv + c.krf * r2 - c.crf) : 0.f;  // krf = crf = 0: plain Coulomb
+    fs = hit ? fs : 0.f;
+    fx = __builtin_fmaf(-dx, fs, fx);
+    fy = __builtin_fmaf(-dy, fs, fy);
+    fz = __builtin_fmaf(-dz, fs, fz);
+  };
+
+  static_assert(UNROLL == 4, "one dwordx4 of list per lane and group");
+  // index words are fetched two groups (8 entries per lane, 2 KB per wave) ahead of their use
+  v4u nxa = row4[0], nxb = row4[64];  // rows are padded: always readable
+  int kk0 = 0;
+  for (; kk0 < nfull; kk0 += UNROLL) {  // every lane has real entries here: no validity test
+    const v4u cur = nxa;
+    nxa = nxb;
+    nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
+    const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
+    v4u raw[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) body(entry[u] >> 24, raw[u], true);  // (n <= 2^20: bits 24..27 are zero)
   }
-  float sx = fx.x + fx.y, sy = fy.x + fy.y, sz = fz.x + fz.y;
+  for (; kk0 < nkk; kk0 += UNROLL) {  // tail: per-lane validity
+    const v4u cur = nxa;
+    nxa = nxb;
+    nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
+    const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
+    v4u raw[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) body((entry[u] >> 24) & 0xF0u, raw[u], kk0 + u < myiters);  // padding words are garbage
+  }
+  float sx = fx, sy = fy, sz = fz;
 #pragma unroll
   for (int o = LPA >> 1; o > 0; o >>= 1) {
     sx += __shfl_xor(sx, o, 64);
@@ -898,11 +956,11 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   }
   if (ENERGY) {  // every pair is listed from both atoms: half of the sum
     if (LJ) {
-      const double s = wave_sum((double)e_lj.x + (double)e_lj.y);
+      const double s = wave_sum((double)e_lj);
       if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_LJ], 0.5 * s);
     }
     if (ELEC) {
-      const double s = wave_sum((double)e_el.x + (double)e_el.y);
+      const double s = wave_sum((double)e_el);
       if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_ELECTROSTATICS], 0.5 * s);
     }
   }
@@ -923,10 +981,7 @@ struct MdStepArgs {
   const R *mass, *vcoeff;
   R dt, half_dt, gamma;
   uint64_t seed, noise_step, row0;
-  const R *ref;
-  R thresh2;
-  int *flags;
-  int parity;
+  ListCheck<R> chk;  // displacement test that drives rebuilds / prunes (CHECK variants)
   typename Vec<R>::T4 *sorted;
   const int *inv;
   const R *qs;
@@ -983,11 +1038,7 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
       sv.z = p[2];
       sv.w = s.qs[i];
       s.sorted[s.inv[i]] = sv;
-      const R dx = min_image(p[0] - s.ref[3 * i + 0], c.box[0], c.invbox[0]);
-      const R dy = min_image(p[1] - s.ref[3 * i + 1], c.box[1], c.invbox[1]);
-      const R dz = min_image(p[2] - s.ref[3 * i + 2], c.box[2], c.invbox[2]);
-      const R d2 = dx * dx + dy * dy + dz * dz;
-      if (!(d2 <= s.thresh2)) s.flags[s.parity] = 1;
+      list_check_atom<R>(s.chk, c, i, p[0], p[1], p[2]);
     }
   }
 #pragma unroll
@@ -997,7 +1048,7 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
 __global__ void md_step_kernel(MdStepArgs<R> s, PairConsts<R> c) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (CHECK && i == 0) s.flags[s.parity ^ 1] = 0;
+  if (CHECK && i == 0) list_check_clear(s.chk.flags, s.chk.parity);
   if (i >= s.n) return;
   // replica batch (all-pairs systems, never with CHECK): blockIdx.y = replica
   const size_t off = CHECK ? 0 : (size_t)blockIdx.y * 3 * s.n;
@@ -1017,7 +1068,7 @@ __global__ void md_step_kernel(MdStepArgs<R> s, PairConsts<R> c) {
 template <typename R, bool LANGEVIN, bool CHECK>
 __global__ __launch_bounds__(256) void md_step_bonded_kernel(MdStepArgs<R> s, PairConsts<R> c, BondedArgs<R> A,
                                                              const R *__restrict__ boxes) {
-  if (CHECK && blockIdx.x == 0 && threadIdx.x == 0) s.flags[s.parity ^ 1] = 0;
+  if (CHECK && blockIdx.x == 0 && threadIdx.x == 0) list_check_clear(s.chk.flags, s.chk.parity);
   const int rep = CHECK ? 0 : (int)blockIdx.y;
   const size_t off = (size_t)rep * 3 * s.n;
   const uint64_t row0 = s.row0 + (uint64_t)rep * (uint64_t)s.n;
@@ -1083,7 +1134,7 @@ struct Replica {
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
   DevBuf pos_alt;  // second position buffer of tmdhip_md_run's double-buffered integrator kernel
-  DevBuf flags;  // int[4]: flags[0..1] rebuild parity, [2] overflow, [3] rebuild counter
+  DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf paircount;  // unsigned long long
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref,
@@ -1098,8 +1149,13 @@ struct tmdhip_ctx {
   tmdhip_nonbonded_desc d{};
   int real_size = 4;
   int algorithm = TMDHIP_ALGO_ALLPAIRS;
-  double skin = 1.0;
-  double rlist = 0;
+  double skin = 1.0;        // Verlet skin
+  double rlist = 0;         // cutoff + skin
+  int rebuild_every = 1;    // E: the MD loop enqueues the rebuild chain on steps with step % E == 0
+  double early_margin = 0;  // a rebuild is requested at displacement skin/2 - early_margin
+  bool safe_mode = false;   // chain on every step (replay after a violation)
+  DevBuf snap;              // pos, vel, forces at the entry of the last tmdhip_md_run (replay)
+  size_t snap_bytes = 0;
   DevBuf types, qs, tab, excl_off, excl_idx;
   DevBuf escratch;  // nreplicas x kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
   DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
@@ -1211,7 +1267,7 @@ PairConsts<R> make_consts(const tmdhip_ctx *ctx, const double *box) {
 int pick_lpa(int n, int capacity) {
   if (const char *e = std::getenv("TMDHIP_LPA")) {  // tuning override: lanes per atom (power of two, 1..64)
     const int v = std::atoi(e);
-    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) return v;
+    if (v >= 4 && v <= 64 && (v & (v - 1)) == 0) return v;
   }
   // (1) enough waves to hide list/gather latency: >= 8192 waves (32 per CU)
   int lpa = 1;
@@ -1336,6 +1392,26 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
   return 0;
 }
 
+// thresholds of the displacement test for the step that `rp.step` counts (see ListCheck)
+template <typename R>
+ListCheck<R> make_check(const tmdhip_ctx *ctx, Replica &rp, bool eligible) {
+  ListCheck<R> k;
+  k.ref = rp.ref.as<R>();
+  const double hard = 0.5 * ctx->skin;
+  // with the chain on every step a rebuild can wait until the list is about to become invalid
+  const double early = (ctx->rebuild_every > 1 && !ctx->safe_mode) ? std::max(hard - ctx->early_margin, 0.25 * hard) : hard;
+  k.early2 = (R)(early * early);
+  k.hard2 = (R)(hard * hard);
+  k.flags = rp.flags.as<int>();
+  k.parity = (int)(rp.step & 1);
+  k.eligible = eligible ? 1 : 0;
+  return k;
+}
+
+bool step_eligible(const tmdhip_ctx *ctx, const Replica &rp) {
+  return ctx->safe_mode || ctx->rebuild_every <= 1 || (rp.step % ctx->rebuild_every) == 0;
+}
+
 template <typename R, bool ENERGY>
 int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, int overwrite, double *energies,
                      unsigned long long *paircount, hipStream_t st) {
@@ -1346,13 +1422,13 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const int waves = (n + apw - 1) / apw;
   const int blocks = (waves + 3) / 4;
   const size_t shmem = (size_t)ctx->d.ntypes * ctx->d.ntypes * sizeof(R2);
-  // packed-fp32 kernel covers LJ (with or without switching) and/or electrostatics (reaction field or plain Coulomb)
+  // the lean fp32 kernel covers LJ (with or without switching) and/or electrostatics (reaction field or plain Coulomb)
   const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
   const bool fast = only_lj_el;  // (switching, if any, acts on the LJ term and is a kernel variant)
   if constexpr (std::is_same<R, float>::value) {
-    // packed-fp32 kernel: needs 32-bit byte offsets into sorted_xyzq and the 7-bit type field
-    if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= 128 && n < (1 << 24)) {
-      const size_t shfast = shmem + 2048;  // garbage type fields of padding entries stay inside the allocation
+    // lean fp32 kernel: the entry's type field holds 16 LJ classes; the unmasked table offset needs j < 2^20
+    if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= kEntryTypes && n <= (1 << 20)) {
+      const size_t shfast = 0;
       const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
 #define TMD_LAUNCH_FAST_T(L, A, B)       \
   if (c.switch_on && A) {               \
@@ -1373,9 +1449,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   } else {                                  \
     TMD_LAUNCH_FAST_T(L, false, true);      \
   }
-      switch (rp.lg.lpa) {
-        case 1: TMD_LAUNCH_FAST(1); break;
-        case 2: TMD_LAUNCH_FAST(2); break;
+      switch (rp.lg.lpa) {  // (pick_lpa never returns less than 4)
         case 4: TMD_LAUNCH_FAST(4); break;
         case 8: TMD_LAUNCH_FAST(8); break;
         case 16: TMD_LAUNCH_FAST(16); break;
@@ -1437,30 +1511,39 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   rp.lg.apw = 64 / rp.lg.lpa;
   rp.lg.lpa_shift = 0;
   while ((1 << rp.lg.lpa_shift) < rp.lg.lpa) rp.lg.lpa_shift++;
-  maxn = (maxn + rp.lg.lpa - 1) / rp.lg.lpa * rp.lg.lpa;
+  maxn = (maxn + 4 * rp.lg.lpa - 1) / (4 * rp.lg.lpa) * (4 * rp.lg.lpa);  // whole 16-byte words per lane
   rp.lg.maxn = maxn;
   const size_t groups = (n + rp.lg.apw - 1) / rp.lg.apw;
-  if (groups * maxn * rp.lg.apw + 8 * 64 >= (size_t)1 << 30)
+  if (groups * maxn * rp.lg.apw + 16 * 64 >= (size_t)1 << 30)
     return fail("neighbour list would exceed 2^30 entries per replica (32-bit row offsets)");
-  // + 8 wave-rows of padding: the unrolled pair kernels read up to 7 iterations past a group's rows
-  TMD_TRY(rp.nlist.ensure(sizeof(unsigned) * (groups * maxn * rp.lg.apw + 8 * 64)));
+  // + 16 wave-rows of padding: the pair kernels prefetch up to three 4-iteration groups past a group's rows
+  TMD_TRY(rp.nlist.ensure(sizeof(unsigned) * (groups * maxn * rp.lg.apw + 16 * 64)));
   return 0;
 }
 
 // Enqueue: displacement check -> conditional rebuild chain -> gather.  `force` forces a rebuild.
+// `prechecked`: the fused MD-step kernel already ran the displacement test of this step (with the same
+// `eligible`); on steps that are not eligible for a rebuild nothing is enqueued then.
 template <typename R>
 int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force,
-                        hipStream_t st, bool prechecked = false) {
+                        hipStream_t st, bool prechecked = false, bool eligible = true) {
   using R4 = typename Vec<R>::T4;
   const int n = ctx->d.natoms;
   const int parity = (int)(rp.step & 1);
   int *flags = rp.flags.as<int>();
-  const int *flag = flags + parity;
+  const int *flag = flags + F_REBUILD0 + parity;
   const int nb = (n + 255) / 256;
-  const R half_skin = (R)(0.5 * ctx->skin);
-  if (!prechecked)  // (the fused MD-step kernel already ran the displacement test for this parity)
-    hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.ref.as<R>(), c,
-                       half_skin * half_skin, flags, parity, force);
+  if (force) eligible = true;
+  if (!prechecked)
+    hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, make_check<R>(ctx, rp, eligible),
+                       c, force);
+  if (!eligible) {
+    if (!prechecked)  // (only the MD loop skips the chain today, and it always pre-checks)
+      hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.order.as<int>(),
+                         rp.sorted.as<R4>(), (const int *)nullptr);
+    TMD_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, rp.cell_of.as<int>(),
                      rp.slot.as<int>(), rp.count.as<int>(), flag);
   hipLaunchKernelGGL(scan_cells_kernel, dim3(1), dim3(1024), 0, st, rp.ncell, rp.count.as<int>(),
@@ -1469,8 +1552,7 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
                      rp.cell_start.as<int>(), rp.order_tmp.as<int>(), flag);
   hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(),
                      rp.cell_start.as<int>(), rp.order_tmp.as<int>(), pos, ctx->qs.as<R>(), ctx->types.as<int>(),
-                     rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(),
-                     flag);
+                     rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(), flag);
   if (!prechecked)
     hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.order.as<int>(),
                        rp.sorted.as<R4>(), flag);
@@ -1480,17 +1562,18 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
     hipLaunchKernelGGL((build_list_kernel<R, false>), dim3(rp.ncell), dim3(64), 0, st, n, rp.sorted.as<R4>(),
                        rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
                        ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
-                       rp.nneigh.as<int>(), flags + 2, flag, rp.ncell, ctx->nactive);
+                       rp.nneigh.as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes);
   else
     hipLaunchKernelGGL((build_list_kernel<R, true>), dim3(kMaxBuildBlocks), dim3(64), 0, st, n, rp.sorted.as<R4>(),
                        rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
                        ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
-                       rp.nneigh.as<int>(), flags + 2, flag, rp.ncell, ctx->nactive);
+                       rp.nneigh.as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes);
   TMD_HIP(hipGetLastError());
   return 0;
 }
 
 constexpr int kPrechecked = 1 << 16;  // internal compute flag: displacement test already enqueued
+constexpr int kNotEligible = 1 << 18;  // internal compute flag: this step does not enqueue the rebuild chain
 constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
 
 template <typename R>
@@ -1541,17 +1624,18 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     force = 1;
   }
   for (int attempt = 0; attempt < 8; ++attempt) {
-    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked)));
+    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked),
+                                   !(flags & kNotEligible)));
     rp.step++;
     if (!force) break;
     // forced builds are host-visible: size the list from the observed maximum so that later
     // device-side rebuilds have headroom (density fluctuations) without host involvement
-    int h[4];
+    int h[F_COUNT];
     TMD_HIP(hipMemcpyAsync(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
     TMD_HIP(hipStreamSynchronize(st));
     rp.host_rebuilds++;
-    const int want = (int)(h[2] * 1.2) + 8;
-    if (h[2] <= rp.lg.maxn && (rp.have_list || want <= rp.lg.maxn)) {
+    const int want = (int)(h[F_MAXN] * 1.2) + 8;
+    if (h[F_MAXN] <= rp.lg.maxn && (rp.have_list || want <= rp.lg.maxn)) {
       rp.have_list = true;
       break;
     }
@@ -1644,7 +1728,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   const int n = ctx->d.natoms;
   const int nrep = (int)ctx->rep.size();
   const bool langevin = d->vcoeff_dev != nullptr;
-  const R half_skin = (R)(0.5 * ctx->skin);
   const size_t stride = (size_t)n * 3;
   MdStepArgs<R> a{};
   a.n = n;
@@ -1654,7 +1737,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   a.half_dt = (R)(0.5 * d->dt);
   a.gamma = (R)d->gamma;
   a.seed = d->seed;
-  a.thresh2 = half_skin * half_skin;
   a.qs = ctx->qs.as<R>();
   // where each replica's positions currently live (caller's tensor, or the context's second buffer while
   // the bonded force is evaluated inside the integrator kernel) and whether the bonded force of the
@@ -1757,9 +1839,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       a.f_zero = (first && !list && ctx->d.terms != 0) ? f : nullptr;
       const bool zeroed = a.f_zero != nullptr;
       a.row0 = (uint64_t)r * (uint64_t)n;
-      a.ref = rp.ref.as<R>();
-      a.flags = rp.flags.as<int>();
-      a.parity = (int)(rp.step & 1);
+      const bool eligible = step_eligible(ctx, rp);
+      a.chk = make_check<R>(ctx, rp, eligible);
       a.sorted = rp.sorted.as<R4>();
       a.inv = rp.inv.as<int>();
       a.pos_in = a.pos_out = cur[r];
@@ -1796,7 +1877,9 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         rp.n_compute++;
         if (list) {
           const int rc = compute_list<R>(ctx, rp, pos, box, f, en,
-                                         flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0), st);
+                                         flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0) |
+                                             ((check && !eligible) ? kNotEligible : 0),
+                                         st);
           if (rc == kFallbackAllPairs) {
             ctx->algorithm = TMDHIP_ALGO_ALLPAIRS;
             list = false;
@@ -1872,7 +1955,18 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
   tmdhip_ctx *ctx = new tmdhip_ctx();
   ctx->d = *desc;
   ctx->real_size = desc->dtype == TMDHIP_F32 ? 4 : 8;
+  auto env_double = [](const char *name, double dflt) {
+    const char *e = std::getenv(name);
+    return e ? std::atof(e) : dflt;
+  };
   ctx->skin = desc->skin > 0 ? desc->skin : 1.2;  // measured optimum for the C3 water box (tools/time_kernels.py)
+  // E > 1: the MD loop enqueues the rebuild chain on every E-th step only and asks for the rebuild (E - 1)
+  // steps' worth of motion of the fastest atoms early (a miss is caught by F_VIOLATION and replayed).
+  // Measured on the C3 water box (skin 1.2 A, natural interval 9 steps): E = 2 +1.7 %, E = 4 -10 % (the early
+  // threshold costs more rebuilds than the skipped early-exit launches save) -> default 1.
+  ctx->rebuild_every = desc->rebuild_every > 0 ? desc->rebuild_every : (int)env_double("TMDHIP_REBUILD_EVERY", 1);
+  if (ctx->rebuild_every < 1) ctx->rebuild_every = 1;
+  ctx->early_margin = env_double("TMDHIP_EARLY_MARGIN", 0.1) * (ctx->rebuild_every - 1);
   ctx->rlist = desc->cutoff > 0 ? desc->cutoff + ctx->skin : 0;
   const int n = desc->natoms;
   auto cleanup = [&](int rc) {
@@ -1919,8 +2013,8 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
   (void)hipMemset(ctx->escratch.p, 0, esbytes);
   ctx->rep.resize(desc->nreplicas);
   for (auto &rp : ctx->rep) {
-    if (rp.flags.ensure(sizeof(int) * 4)) return cleanup(-1);
-    (void)hipMemset(rp.flags.p, 0, sizeof(int) * 4);
+    if (rp.flags.ensure(sizeof(int) * F_COUNT)) return cleanup(-1);
+    (void)hipMemset(rp.flags.p, 0, sizeof(int) * F_COUNT);
     if (rp.paircount.ensure(sizeof(unsigned long long))) return cleanup(-1);
     (void)hipMemset(rp.paircount.p, 0, sizeof(unsigned long long));
   }
@@ -1935,7 +2029,7 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
 void tmdhip_destroy(tmdhip_ctx *ctx) {
   if (!ctx) return;
   for (auto &rp : ctx->rep) rp.release();
-  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all})
+  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all, &ctx->snap})
     b->release();
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
@@ -2029,16 +2123,19 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   Replica &rp = ctx->rep[replica];
   std::memset(out, 0, sizeof(*out));
   TMD_HIP(hipDeviceSynchronize());
-  int h[4] = {0, 0, 0, 0};
+  int h[F_COUNT] = {0};
   TMD_HIP(hipMemcpy(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost));
   unsigned long long pc = 0;
   TMD_HIP(hipMemcpy(&pc, rp.paircount.p, sizeof(pc), hipMemcpyDeviceToHost));
   out->n_compute = rp.n_compute;
-  out->n_rebuilds = h[3];
+  out->n_rebuilds = h[F_NREBUILD];
+  out->violation = h[F_VIOLATION];
+  out->skin = ctx->skin;
+  out->rebuild_every = ctx->rebuild_every;
   out->pairs_in_cutoff = (int64_t)pc;
   out->algorithm = ctx->algorithm;
   out->max_neighbours = rp.lg.maxn;
-  out->overflow = (rp.have_list && h[2] > rp.lg.maxn) ? h[2] : 0;
+  out->overflow = (rp.have_list && h[F_MAXN] > rp.lg.maxn) ? h[F_MAXN] : 0;
   for (int k = 0; k < 3; ++k) out->ncell[k] = rp.grid.nc[k];
   if (rp.have_list) {
     std::vector<int> nn(ctx->d.natoms);
@@ -2056,12 +2153,20 @@ int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream) {
   Replica &rp = ctx->rep[replica];
   if (ctx->algorithm != TMDHIP_ALGO_CELLLIST || !rp.have_list) return 0;
   hipStream_t st = (hipStream_t)stream;
-  int h[4];
+  int h[F_COUNT];
   TMD_HIP(hipMemcpyAsync(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
   TMD_HIP(hipStreamSynchronize(st));
-  if (h[2] <= rp.lg.maxn) return 0;
+  if (h[F_VIOLATION]) {
+    // an atom moved further than skin/2 on a step that did not enqueue the rebuild chain: forces since then
+    // may miss pairs.  Clear the flag, rebuild on the next call; the caller repeats the work (tmdhip_md_restore).
+    TMD_HIP(hipMemsetAsync(rp.flags.as<int>() + F_VIOLATION, 0, sizeof(int), st));
+    rp.box[0] = -1;
+    last_error() = "neighbour list outlived its skin between two scheduled rebuilds (results since the last check are invalid)";
+    return 1;
+  }
+  if (h[F_MAXN] <= rp.lg.maxn) return 0;
   // a device-side rebuild truncated a list: grow the capacity and force a rebuild on the next call
-  const int want = (int)(h[2] * 1.25) + 16;
+  const int want = (int)(h[F_MAXN] * 1.25) + 16;
   const int rc = ctx->d.dtype == TMDHIP_F32 ? alloc_replica<float>(ctx, rp, want) : alloc_replica<double>(ctx, rp, want);
   if (rc) return rc;
   rp.box[0] = -1;  // forces the re-plan + rebuild path
@@ -2077,7 +2182,35 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     return fail("tmdhip_md_run: null buffer");
   if (desc->niter == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  return ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
+  if (ctx->algorithm == TMDHIP_ALGO_CELLLIST) {
+    // state at entry, for tmdhip_md_restore (a truncated list or a scheduled-rebuild violation is only
+    // detected after the batch): three device copies of N x 3 reals per call
+    const size_t bytes = (size_t)ctx->real_size * 3 * ctx->d.natoms * ctx->rep.size();
+    TMD_TRY(ctx->snap.ensure(3 * bytes));
+    char *sn = ctx->snap.as<char>();
+    TMD_HIP(hipMemcpyAsync(sn, desc->pos_dev, bytes, hipMemcpyDeviceToDevice, st));
+    TMD_HIP(hipMemcpyAsync(sn + bytes, desc->vel_dev, bytes, hipMemcpyDeviceToDevice, st));
+    TMD_HIP(hipMemcpyAsync(sn + 2 * bytes, desc->forces_dev, bytes, hipMemcpyDeviceToDevice, st));
+    ctx->snap_bytes = bytes;
+  }
+  const int rc = ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
+  ctx->safe_mode = false;  // (a replayed batch ran with the chain on every step)
+  return rc;
+}
+
+int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
+  if (!ctx || !desc) return fail("tmdhip_md_restore: null argument");
+  if (!desc->pos_dev || !desc->vel_dev || !desc->forces_dev) return fail("tmdhip_md_restore: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bytes = (size_t)ctx->real_size * 3 * ctx->d.natoms * ctx->rep.size();
+  if (ctx->snap_bytes != bytes || !ctx->snap.p) return fail("tmdhip_md_restore: no saved state of a matching tmdhip_md_run");
+  const char *sn = ctx->snap.as<char>();
+  TMD_HIP(hipMemcpyAsync(desc->pos_dev, sn, bytes, hipMemcpyDeviceToDevice, st));
+  TMD_HIP(hipMemcpyAsync(desc->vel_dev, sn + bytes, bytes, hipMemcpyDeviceToDevice, st));
+  TMD_HIP(hipMemcpyAsync(desc->forces_dev, sn + 2 * bytes, bytes, hipMemcpyDeviceToDevice, st));
+  for (auto &rp : ctx->rep) rp.box[0] = -1;  // re-plan + rebuild from the restored positions
+  ctx->safe_mode = true;
+  return 0;
 }
 
 int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica) {

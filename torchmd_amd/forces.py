@@ -127,6 +127,7 @@ class _Engine:
         d.switch_mode = L.SWITCH_EXACT if exact else L.SWITCH_REFERENCE
         d.algorithm = {"auto": L.ALGO_AUTO, "allpairs": L.ALGO_ALLPAIRS, "celllist": L.ALGO_CELLLIST}[owner.algorithm]
         d.skin = float(owner.skin) if owner.skin else 0.0
+        d.rebuild_every = int(owner.rebuild_every) if owner.rebuild_every else 0
         L.check(lib.tmdhip_create(C.byref(self.ctx), C.byref(d)), "tmdhip_create")
 
         b = L.BondedDesc()
@@ -230,7 +231,8 @@ class Forces:
 
     Extra keyword-only knobs of this implementation
     ----------
-    skin : float          Verlet-list skin in Angstrom (default 1.0)
+    skin : float          Verlet-list skin in Angstrom (default 1.2)
+    rebuild_every : int   the MD loop enqueues the list-rebuild chain on every E-th step only (default 1)
     algorithm : str       "auto" | "allpairs" | "celllist"
     switch_mode : str     "reference" (upstream's explicit switching force, extra 1/r,
                           forces.py:410-412) | "exact" (-dE/dr)
@@ -252,6 +254,7 @@ class Forces:
         exclusions=("bonds", "angles", "1-4"),
         *,
         skin=None,
+        rebuild_every=None,
         algorithm="auto",
         switch_mode="reference",
     ):
@@ -285,7 +288,8 @@ class Forces:
         self.solventDielectric = solventDielectric
         self.switch_dist = switch_dist
         self.exclusions = tuple(exclusions)
-        self.skin = skin  # None -> library default (1.2 A, tools/time_kernels.py sweep)
+        self.skin = skin  # None -> library default
+        self.rebuild_every = rebuild_every
         self.algorithm = algorithm
         self.switch_mode = switch_mode
         self._excl_csr = build_exclusion_csr(
@@ -520,9 +524,10 @@ class Forces:
                 return ebuf, torch.as_tensor(ext_ene, device=pos.device).detach().to(torch.float64).reshape(-1)
         return (ebuf, None) if want_energy else (None, None)
 
-    def _md_run(self, system, masses, vcoeff, dt, gamma, seed, step0, niter):
+    def _md_run(self, system, masses, vcoeff, dt, gamma, seed, step0, niter, restore=False):
         """Integrator fast path: `niter` MD steps enqueued by one C call; returns the energy buffer of the
-        last step (device, [R, NENERGY])."""
+        last step (device, [R, NENERGY]).  `restore`: first rewind to the state at the entry of the previous
+        call (tmdhip_md_restore) — the replay after a neighbour-list validity failure."""
         pos = system.pos
         L.require_device_tensor(pos, "systems.pos")
         if pos.shape[1] != self.natoms:
@@ -543,6 +548,8 @@ class Forces:
         eng.ebuf.zero_()
         d.energies_dev = eng.ebuf.data_ptr()
         stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+        if restore:
+            L.check(eng.lib.tmdhip_md_restore(eng.ctx, C.byref(d), stream), "tmdhip_md_restore")
         L.check(eng.lib.tmdhip_md_run(eng.ctx, C.byref(d), stream), "tmdhip_md_run")
         return eng.ebuf
 
@@ -575,6 +582,9 @@ class Forces:
             "max_neighbours": st.max_neighbours,
             "overflow": st.overflow,
             "ncell": tuple(st.ncell),
+            "violation": st.violation,
+            "rebuild_every": st.rebuild_every,
+            "skin": st.skin,
         }
 
     def enable_timing(self, pos, on=True, every=1):

@@ -146,14 +146,24 @@ class Integrator:
         ebuf = ext = None
         fused = fast and not self.forces.external and niter > 0
         with torch.cuda.device(dev):
+            return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=False)
+
+    def _step_body(self, lib, s, dev, code, R, N, fast, fused, niter, replay):
+        from .forces import Forces  # noqa: F401
+
+        pot = None
+        ebuf = ext = None
+        if True:
             if fused:
                 # whole loop enqueued from C (tmdhip_md_run): fused half-kick/drift/displacement-test
                 # kernels, no Python or ctypes work per step
+                step0 = self._nstep - niter if replay else self._nstep
                 ebuf = self.forces._md_run(
                     s, self.masses, self.vcoeff if self.T else None, self.dt,
-                    float(self.gamma) if self.T else 0.0, self._seed, self._nstep, niter,
+                    float(self.gamma) if self.T else 0.0, self._seed, step0, niter, restore=replay,
                 )
-                self._nstep += niter
+                if not replay:
+                    self._nstep += niter
             for it in range(0 if not fused else niter, niter):
                 st = _stream(dev)
                 L.check(
@@ -211,6 +221,11 @@ class Integrator:
                     host = torch.cat([ke.flatten(), tot]).cpu().numpy()
                     Ekin, pot = host[: ke.numel()], [float(v) for v in host[ke.numel():]]
                 if not self.forces._verify(eng, s.pos):
+                    # a neighbour list was truncated, or outlived its skin between two scheduled rebuilds
+                    if fused and not replay:
+                        # rewind to the entry state (saved by tmdhip_md_run) and repeat the batch with the
+                        # rebuild chain on every step; the noise stream is counter based: same trajectory
+                        return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
                     raise RuntimeError(
                         "a neighbour list overflowed during Integrator.step(); the trajectory since the previous "
                         "step() call is invalid (capacity has been grown — restart from the last saved state)"
