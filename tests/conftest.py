@@ -16,6 +16,14 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     have_ref = os.path.isdir("/root/reference/torchmd")
     skip_ref = pytest.mark.skip(reason="/root/reference not present (GPU box)")
+    have_gpu = None
     for item in items:
         if "needs_reference" in item.keywords and not have_ref:
             item.add_marker(skip_ref)
+        if "gpu" in item.keywords:
+            if have_gpu is None:
+                import torch
+
+                have_gpu = torch.cuda.is_available()
+            if not have_gpu:
+                item.add_marker(pytest.mark.skip(reason="needs a ROCm device (run through gpurun)"))

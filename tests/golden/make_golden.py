@@ -171,8 +171,47 @@ def thrombin():
     print("thrombin:", {k: float(v) for k, v in out.items() if "_E0_" in k and k.startswith("f64_nb")})
 
 
+def wrap():
+    """Reference `Wrapper.wrap` (torchmd/wrapper.py:8-30) on the tests/water topology (97 bonded TIP3P groups),
+    every molecule translated by random whole box vectors and then jittered, fp32 and fp64.  Case "r2": two
+    replicas with different boxes, bonded groups only.  Case "ions": one replica with three free ions appended
+    (the reference's free-atom branch, wrapper.py:28-30, only broadcasts for a single replica).  Inputs and the
+    reference's wrapped positions are stored."""
+    from torchmd.wrapper import Wrapper as RefWrapper
+
+    d = os.path.join(REF, "tests", "water")
+    mol = tio.read_psf(os.path.join(d, "structure.psf"))
+    xyz, box, _, _ = tio.read_pdb(os.path.join(d, "structure.pdb"))
+    rng = np.random.default_rng(11)
+    nw = mol.numAtoms
+    out = {"bonds": mol.bonds.astype(np.int64)}
+    for case, R, nfree in (("r2", 2, 0), ("ions", 1, 3)):
+        natoms = nw + nfree
+        boxes = np.stack([box * (1.0 + 0.1 * r) * np.array([1.0, 0.93, 1.21]) for r in range(R)], axis=1)  # [3, R]
+        pos0 = np.concatenate([xyz.astype(np.float64), rng.uniform(0, 1, (nfree, 3)) * box], axis=0)
+        pos = np.repeat(pos0[None], R, axis=0)  # [R, N, 3]
+        for r in range(R):
+            shift_mol = rng.integers(-3, 4, size=(nw // 3, 3)).astype(np.float64) * boxes[:, r]
+            pos[r, :nw] += np.repeat(shift_mol, 3, axis=0)
+            pos[r, nw:] += rng.integers(-3, 4, size=(nfree, 3)).astype(np.float64) * boxes[:, r]
+            pos[r] += rng.uniform(-0.4, 0.4, size=(natoms, 3)) * boxes[:, r]
+        out[f"{case}_natoms"] = np.int64(natoms)
+        out[f"{case}_boxes"] = boxes
+        for prec in ("f64", "f32"):
+            system = RefSystem(natoms, R, PREC[prec], "cpu")
+            system.set_box(boxes)
+            p = torch.tensor(pos, dtype=PREC[prec])
+            out[f"{case}_{prec}_pos_in"] = p.numpy().copy()
+            w = RefWrapper(natoms, mol.bonds, "cpu")
+            w.wrap(p, system.box)
+            out[f"{case}_{prec}_pos_out"] = p.numpy().copy()
+            moved = np.abs(out[f"{case}_{prec}_pos_out"] - out[f"{case}_{prec}_pos_in"]).max()
+            print(f"wrap {case} {prec}: {len(w.groups)} groups, {len(w.nongrouped)} free atoms, max translation {moved:.1f} A")
+    np.savez_compressed(os.path.join(HERE, "wrap.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["water291", "ala2", "thrombin"]
+    which = sys.argv[1:] or ["water291", "ala2", "thrombin", "wrap"]
     for w in which:
         globals()[w]()

@@ -234,6 +234,28 @@ def test_wrapper_vs_oracle(prec):
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["r2", "ions"])
+def test_wrapper_vs_reference_golden(prec, case):
+    """tmdhip_wrap equals the reference `Wrapper.wrap` (torchmd/wrapper.py:8-30) on the golden produced by the
+    reference itself (tests/golden/wrap.npz): bit for bit in fp64 and fp32 (translations are whole box
+    vectors; a group whose centre sits within rounding of a face could legitimately differ, none does here)."""
+    from _golden import load
+    from torchmd_amd.wrapper import Wrapper
+
+    dev, dt = _dev(), PREC[prec]
+    g = load("wrap")
+    natoms = int(g[f"{case}_natoms"])
+    pos = torch.tensor(g[f"{case}_{prec}_pos_in"], dtype=dt, device=dev)
+    R = pos.shape[0]
+    box = torch.zeros(R, 3, 3, dtype=dt, device=dev)
+    for r in range(R):
+        box[r] = torch.diag(torch.tensor(g[f"{case}_boxes"][:, r], dtype=dt))
+    w = Wrapper(natoms, g["bonds"], dev)
+    w.wrap(pos, box)
+    assert np.array_equal(pos.cpu().numpy(), g[f"{case}_{prec}_pos_out"])
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_fused_md_run_equals_stepwise_loop(prec):
     """tmdhip_md_run (fused half-kick / drift / displacement-test kernels, whole loop in C) reproduces the
     step-by-step Python loop (first_vv -> compute -> langevin_second_vv) bit for bit, incl. the noise."""

@@ -115,3 +115,24 @@ def test_thrombin_nocut():
     par = GoldenParameters(g, torch.float64)
     pos, box0 = pos_tensor(g["pos"], 1, torch.float64), box_tensor(np.zeros(3), 1, torch.float64)
     _check(g, "f64_nb_nocut", par, pos, box0, ["electrostatics", "lj"], etol=1e-12, ftol=1e-9)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["r2", "ions"])
+def test_wrap_bitexact(prec, case):
+    """oracle.wrap_molecules reproduces the reference `Wrapper.wrap` (torchmd/wrapper.py:8-30) bit for bit on
+    the golden produced by the reference itself (tests/golden/make_golden.py::wrap)."""
+    from torchmd_amd.wrapper import calculate_molecule_groups
+
+    g = load("wrap")
+    natoms = int(g[f"{case}_natoms"])
+    off, mem = calculate_molecule_groups(natoms, g["bonds"])
+    groups = [torch.as_tensor(mem[off[k]:off[k + 1]].astype(np.int64)) for k in range(len(off) - 1) if off[k + 1] - off[k] > 1]
+    free = torch.as_tensor(np.array([mem[off[k]] for k in range(len(off) - 1) if off[k + 1] - off[k] == 1], dtype=np.int64))
+    pos = torch.tensor(g[f"{case}_{prec}_pos_in"])
+    R = pos.shape[0]
+    box = torch.zeros(R, 3, 3, dtype=pos.dtype)
+    for r in range(R):
+        box[r] = torch.diag(torch.tensor(g[f"{case}_boxes"][:, r], dtype=pos.dtype))
+    orc.wrap_molecules(pos, box, groups, free)
+    assert np.array_equal(pos.numpy(), g[f"{case}_{prec}_pos_out"])

@@ -279,6 +279,14 @@ class Forces:
             raise ValueError("switch_mode must be 'reference' or 'exact'")
         if rfa and cutoff is None:
             raise RuntimeError("rfa=True needs a cutoff")
+        # the library encodes "no cutoff" / "no switching" as 0: reject the values that would be mistaken for
+        # "unset" (the reference would filter out every pair with cutoff = 0 and switch from r = 0)
+        if cutoff is not None and not cutoff > 0:
+            raise ValueError("cutoff must be positive (use None for no cutoff)")
+        if switch_dist is not None and not switch_dist > 0:
+            raise ValueError("switch_dist must be positive (use None for no switching)")
+        if switch_dist is not None and cutoff is not None and not switch_dist < cutoff:
+            raise ValueError("switch_dist must be smaller than cutoff")
 
         self.natoms = len(parameters.masses)
         self.require_distances = any(f in self.nonbonded for f in self.energies)
@@ -374,11 +382,16 @@ class Forces:
     def _host_box(self, box):
         """Box diagonals on the host, [R,3] float64.  Re-read only when the tensor changed (a read is a
         device sync; the reference syncs on `torch.all(box == 0)` every call, forces.py:361)."""
-        tag = (box.data_ptr(), box._version, tuple(box.shape))
-        if self._box_cache is None or self._box_cache[0] != tag:
-            diag = torch.diagonal(box.detach(), dim1=-2, dim2=-1).to("cpu", torch.float64).contiguous().numpy()
-            self._box_cache = (tag, np.ascontiguousarray(diag.reshape(-1, 3)))
-        return self._box_cache[1]
+        # keyed on the tensor OBJECT (weak reference) and its version counter: a temporary freed and
+        # re-allocated at the same address is a different object, so it can never hit a stale entry.
+        # (In-place edits through `.data` do not bump the version: pass a new tensor or use set_box.)
+        cache = self._box_cache
+        if cache is not None and cache[0]() is box and cache[1] == box._version:
+            return cache[2]
+        diag = torch.diagonal(box.detach(), dim1=-2, dim2=-1).to("cpu", torch.float64).contiguous().numpy()
+        host = np.ascontiguousarray(diag.reshape(-1, 3))
+        self._box_cache = (weakref.ref(box), box._version, host)
+        return host
 
     def _launch(self, eng, pos, box, forces, want_energy, want_forces, count_pairs=False):
         """Enqueue bonded + nonbonded kernels of every replica on the current stream."""
@@ -487,6 +500,10 @@ class Forces:
             if want_forces and explicit_forces:
                 forces += ext_force
             elif want_forces and not explicit_forces:
+                # Deviation from upstream, on purpose: with explicit_forces=False the reference overwrites
+                # `forces` with -grad of the summed potential (forces.py:328-336), so an external force only
+                # survives there if `ext_ene` carries an autograd graph back to `pos`.  Here the external
+                # force the plugin returns is always added, exactly as on the explicit path.
                 forces += ext_force.detach() if ext_force is not None else 0
 
         # per-term energies in the order of the reference dict: self.energies ..., then "external"

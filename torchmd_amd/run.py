@@ -183,9 +183,9 @@ class FrameStager:
         self.count = 0
 
     def push(self, pos):
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(pos.device))
         snap = pos.detach().clone()  # the integrator keeps mutating pos
+        ready = torch.cuda.Event()   # recorded AFTER the clone: the side stream's copy must see the snapshot
+        ready.record(torch.cuda.current_stream(pos.device))
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
             self.buf[self.count].copy_(snap, non_blocking=True)
