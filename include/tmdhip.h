@@ -164,6 +164,14 @@ int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, 
 int tmdhip_compute_bonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, const double *box_host,
                           void *forces_dev, double *energies_dev, int flags, void *stream);
 
+/* Forces.compute (forces.py:83-346) for every replica in ONE call with ONE host synchronisation: bonded +
+ * nonbonded forces stored into forces_dev (real [R,N,3]; NULL: energies only, `calculateForces=False`) and the
+ * per-term energies returned on the host (energies_host: double [R][TMDHIP_NENERGY]).  The neighbour-list
+ * validity check rides on the same read-back.  Returns 0 = valid; 1 = a list was truncated (capacity grown):
+ * call again; negative = error. */
+int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host, void *forces_dev,
+                   double *energies_host, void *stream);
+
 /* Synchronises `stream` and verifies that the neighbour lists used since the last check were valid: no
  * device-side rebuild ran out of list capacity, and no atom moved further than skin/2 on an MD step that
  * did not enqueue the rebuild chain (tmdhip_nonbonded_desc.rebuild_every).  Returns 0 = results valid; 1 = not valid: capacity has been grown /
@@ -190,6 +198,12 @@ typedef struct tmdhip_md_desc {
   double *energies_dev;                 /* [R*TMDHIP_NENERGY]: += energies of the LAST iteration, or NULL */
 } tmdhip_md_desc;
 int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
+/* What Integrator.step returns after its loop (integrator.py:121-125), with ONE read-back and ONE host
+ * synchronisation: kinetic energy per replica (integrator.py:8-31), the per-term energies of the last step
+ * (energies_dev = the buffer given to tmdhip_md_run; NULL: zeros) and the neighbour-list validity check.
+ * out_host: double [R][TMDHIP_NENERGY + 1] = per-term energies, then Ekin.  Returns as tmdhip_check. */
+int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev, const double *energies_dev,
+                      double *out_host, void *stream);
 /* Rewind: copy the state tmdhip_md_run saved at its entry (positions, velocities, forces of every replica)
  * back into desc's buffers and make the next tmdhip_md_run enqueue the rebuild chain on every step (no
  * scheduled-rebuild violation possible).  Used after tmdhip_check returned 1 for an MD batch; the noise

@@ -144,9 +144,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     ),
+    "tmdhip_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "tmdhip_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "tmdhip_md_run": (C.c_int, [C.c_void_p, C.POINTER(MdDesc), C.c_void_p]),
     "tmdhip_md_restore": (C.c_int, [C.c_void_p, C.POINTER(MdDesc), C.c_void_p]),
+    "tmdhip_md_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "tmdhip_invalidate_list": (C.c_int, [C.c_void_p, C.c_int]),
     "tmdhip_update_atoms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "tmdhip_get_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Stats)]),

@@ -1091,6 +1091,16 @@ __global__ __launch_bounds__(256) void md_step_bonded_kernel(MdStepArgs<R> s, Pa
 
 __global__ void halve_count_kernel(unsigned long long *c) { *c >>= 1; }
 
+// state at the entry of an MD batch (positions, velocities, forces) in one launch; n4 = 16-byte words per array
+__global__ void snapshot3_kernel(size_t n4, const uint4 *__restrict__ a, const uint4 *__restrict__ b,
+                                 const uint4 *__restrict__ c, uint4 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  out[i] = a[i];
+  out[n4 + i] = b[i];
+  out[2 * n4 + i] = c[i];
+}
+
 }  // namespace tmd
 
 // =============================================================================================
@@ -1156,6 +1166,10 @@ struct tmdhip_ctx {
   bool safe_mode = false;   // chain on every step (replay after a violation)
   DevBuf snap;              // pos, vel, forces at the entry of the last tmdhip_md_run (replay)
   size_t snap_bytes = 0;
+  DevBuf sync_e;            // tmdhip_compute: per-term energies [R][NENERGY] on the device ...
+  void *sync_host = nullptr;  // ... and their pinned host landing zone (+ the list flags of every replica)
+  DevBuf obs_ke;              // tmdhip_md_observe: kinetic energies [R] ...
+  void *obs_host = nullptr;   // ... and the pinned landing zone of energies, kinetic energies and list flags
   DevBuf types, qs, tab, excl_off, excl_idx;
   DevBuf escratch;  // nreplicas x kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
   DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
@@ -2035,6 +2049,10 @@ void tmdhip_destroy(tmdhip_ctx *ctx) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
   }
+  if (ctx->sync_host) (void)hipHostFree(ctx->sync_host);
+  if (ctx->obs_host) (void)hipHostFree(ctx->obs_host);
+  ctx->sync_e.release();
+  ctx->obs_ke.release();
   tmd::bonded_release(ctx);
   delete ctx;
 }
@@ -2147,15 +2165,8 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   return 0;
 }
 
-int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream) {
-  if (!ctx) return fail("tmdhip_check: null ctx");
-  if (replica < 0 || replica >= (int)ctx->rep.size()) return fail("tmdhip_check: bad replica index");
-  Replica &rp = ctx->rep[replica];
-  if (ctx->algorithm != TMDHIP_ALGO_CELLLIST || !rp.have_list) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  int h[F_COUNT];
-  TMD_HIP(hipMemcpyAsync(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
-  TMD_HIP(hipStreamSynchronize(st));
+// verdict on the list flags of one replica (already on the host): 0 valid, 1 repeat the work, < 0 error
+static int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
   if (h[F_VIOLATION]) {
     // an atom moved further than skin/2 on a step that did not enqueue the rebuild chain: forces since then
     // may miss pairs.  Clear the flag, rebuild on the next call; the caller repeats the work (tmdhip_md_restore).
@@ -2174,6 +2185,57 @@ int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream) {
   return 1;
 }
 
+int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream) {
+  if (!ctx) return fail("tmdhip_check: null ctx");
+  if (replica < 0 || replica >= (int)ctx->rep.size()) return fail("tmdhip_check: bad replica index");
+  Replica &rp = ctx->rep[replica];
+  if (ctx->algorithm != TMDHIP_ALGO_CELLLIST || !rp.have_list) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int h[F_COUNT];
+  TMD_HIP(hipMemcpyAsync(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  TMD_HIP(hipStreamSynchronize(st));
+  return judge_flags(ctx, rp, h, st);
+}
+
+int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host, void *forces_dev,
+                   double *energies_host, void *stream) {
+  if (!ctx || !pos_dev || !box_host || !energies_host) return fail("tmdhip_compute: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nrep = ctx->rep.size();
+  const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, fbytes = sizeof(int) * F_COUNT * nrep;
+  TMD_TRY(ctx->sync_e.ensure(ebytes));
+  if (!ctx->sync_host) TMD_HIP(hipHostMalloc(&ctx->sync_host, ebytes + fbytes, hipHostMallocDefault));
+  double *he = (double *)ctx->sync_host;
+  int *hf = (int *)((char *)ctx->sync_host + ebytes);
+  double *e = ctx->sync_e.as<double>();
+  TMD_HIP(hipMemsetAsync(e, 0, ebytes, st));
+  int flags = TMDHIP_WANT_ENERGY;
+  if (forces_dev) {
+    flags |= TMDHIP_WANT_FORCES;
+    if (ctx->d.terms == 0)  // no nonbonded kernel to store the forces: the bonded kernels add into zeros
+      TMD_HIP(hipMemsetAsync(forces_dev, 0, (size_t)ctx->real_size * 3 * ctx->d.natoms * nrep, st));
+  }
+  TMD_TRY(tmdhip_compute_nonbonded(ctx, TMDHIP_ALL_REPLICAS, pos_dev, box_host, forces_dev, e,
+                                   flags | (forces_dev ? TMDHIP_OVERWRITE_FORCES : 0), stream));
+  TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos_dev, box_host, forces_dev, e, flags, stream));
+  TMD_HIP(hipMemcpyAsync(he, e, ebytes, hipMemcpyDeviceToHost, st));
+  const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
+  if (lists)
+    for (size_t r = 0; r < nrep; ++r)
+      TMD_HIP(hipMemcpyAsync(hf + r * F_COUNT, ctx->rep[r].flags.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st));
+  TMD_HIP(hipStreamSynchronize(st));  // the one host synchronisation of an energy evaluation
+  int verdict = 0;
+  if (lists && ctx->algorithm == TMDHIP_ALGO_CELLLIST)
+    for (size_t r = 0; r < nrep; ++r)
+      if (ctx->rep[r].have_list) {
+        const int rc = judge_flags(ctx, ctx->rep[r], hf + r * F_COUNT, st);
+        if (rc < 0) return rc;
+        verdict |= rc;
+      }
+  std::memcpy(energies_host, he, ebytes);
+  return verdict;
+}
+
 int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
   if (!ctx || !desc) return fail("tmdhip_md_run: null argument");
   if (desc->struct_size != (int32_t)sizeof(tmdhip_md_desc)) return fail("tmdhip_md_run: tmdhip_md_desc size mismatch (ABI)");
@@ -2186,16 +2248,61 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     // state at entry, for tmdhip_md_restore (a truncated list or a scheduled-rebuild violation is only
     // detected after the batch): three device copies of N x 3 reals per call
     const size_t bytes = (size_t)ctx->real_size * 3 * ctx->d.natoms * ctx->rep.size();
-    TMD_TRY(ctx->snap.ensure(3 * bytes));
+    const size_t padded = (bytes + 15) / 16 * 16;
+    TMD_TRY(ctx->snap.ensure(3 * padded));
     char *sn = ctx->snap.as<char>();
-    TMD_HIP(hipMemcpyAsync(sn, desc->pos_dev, bytes, hipMemcpyDeviceToDevice, st));
-    TMD_HIP(hipMemcpyAsync(sn + bytes, desc->vel_dev, bytes, hipMemcpyDeviceToDevice, st));
-    TMD_HIP(hipMemcpyAsync(sn + 2 * bytes, desc->forces_dev, bytes, hipMemcpyDeviceToDevice, st));
+    const bool aligned = ((uintptr_t)desc->pos_dev | (uintptr_t)desc->vel_dev | (uintptr_t)desc->forces_dev) % 16 == 0 &&
+                         bytes % 16 == 0;
+    if (aligned) {
+      const size_t n4 = bytes / 16;
+      hipLaunchKernelGGL(snapshot3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4,
+                         (const uint4 *)desc->pos_dev, (const uint4 *)desc->vel_dev, (const uint4 *)desc->forces_dev,
+                         (uint4 *)sn);
+      TMD_HIP(hipGetLastError());
+    } else {
+      TMD_HIP(hipMemcpyAsync(sn, desc->pos_dev, bytes, hipMemcpyDeviceToDevice, st));
+      TMD_HIP(hipMemcpyAsync(sn + padded, desc->vel_dev, bytes, hipMemcpyDeviceToDevice, st));
+      TMD_HIP(hipMemcpyAsync(sn + 2 * padded, desc->forces_dev, bytes, hipMemcpyDeviceToDevice, st));
+    }
     ctx->snap_bytes = bytes;
   }
   const int rc = ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
   ctx->safe_mode = false;  // (a replayed batch ran with the chain on every step)
   return rc;
+}
+
+int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev, const double *energies_dev,
+                      double *out_host, void *stream) {
+  if (!ctx || !vel_dev || !mass_dev || !out_host) return fail("tmdhip_md_observe: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nrep = ctx->rep.size();
+  const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, kbytes = sizeof(double) * nrep;
+  const size_t fbytes = sizeof(int) * F_COUNT * nrep;
+  TMD_TRY(ctx->obs_ke.ensure(kbytes));
+  if (!ctx->obs_host) TMD_HIP(hipHostMalloc(&ctx->obs_host, ebytes + kbytes + fbytes, hipHostMallocDefault));
+  double *he = (double *)ctx->obs_host, *hk = he + TMDHIP_NENERGY * nrep;
+  int *hf = (int *)((char *)ctx->obs_host + ebytes + kbytes);
+  TMD_TRY(tmdhip_kinetic_energy(ctx->d.dtype, (int64_t)nrep, ctx->d.natoms, vel_dev, mass_dev, ctx->obs_ke.as<double>(), stream));
+  if (energies_dev) TMD_HIP(hipMemcpyAsync(he, energies_dev, ebytes, hipMemcpyDeviceToHost, st));
+  TMD_HIP(hipMemcpyAsync(hk, ctx->obs_ke.p, kbytes, hipMemcpyDeviceToHost, st));
+  const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
+  if (lists)
+    for (size_t r = 0; r < nrep; ++r)
+      TMD_HIP(hipMemcpyAsync(hf + r * F_COUNT, ctx->rep[r].flags.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st));
+  TMD_HIP(hipStreamSynchronize(st));
+  int verdict = 0;
+  if (lists && ctx->algorithm == TMDHIP_ALGO_CELLLIST)
+    for (size_t r = 0; r < nrep; ++r)
+      if (ctx->rep[r].have_list) {
+        const int rc = judge_flags(ctx, ctx->rep[r], hf + r * F_COUNT, st);
+        if (rc < 0) return rc;
+        verdict |= rc;
+      }
+  for (size_t r = 0; r < nrep; ++r) {
+    for (int k = 0; k < TMDHIP_NENERGY; ++k) out_host[r * (TMDHIP_NENERGY + 1) + k] = energies_dev ? he[r * TMDHIP_NENERGY + k] : 0.0;
+    out_host[r * (TMDHIP_NENERGY + 1) + TMDHIP_NENERGY] = hk[r];
+  }
+  return verdict;
 }
 
 int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
@@ -2205,9 +2312,10 @@ int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream)
   const size_t bytes = (size_t)ctx->real_size * 3 * ctx->d.natoms * ctx->rep.size();
   if (ctx->snap_bytes != bytes || !ctx->snap.p) return fail("tmdhip_md_restore: no saved state of a matching tmdhip_md_run");
   const char *sn = ctx->snap.as<char>();
+  const size_t padded = (bytes + 15) / 16 * 16;
   TMD_HIP(hipMemcpyAsync(desc->pos_dev, sn, bytes, hipMemcpyDeviceToDevice, st));
-  TMD_HIP(hipMemcpyAsync(desc->vel_dev, sn + bytes, bytes, hipMemcpyDeviceToDevice, st));
-  TMD_HIP(hipMemcpyAsync(desc->forces_dev, sn + 2 * bytes, bytes, hipMemcpyDeviceToDevice, st));
+  TMD_HIP(hipMemcpyAsync(desc->vel_dev, sn + padded, bytes, hipMemcpyDeviceToDevice, st));
+  TMD_HIP(hipMemcpyAsync(desc->forces_dev, sn + 2 * padded, bytes, hipMemcpyDeviceToDevice, st));
   for (auto &rp : ctx->rep) rp.box[0] = -1;  // re-plan + rebuild from the restored positions
   ctx->safe_mode = true;
   return 0;

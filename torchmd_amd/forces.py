@@ -465,6 +465,48 @@ class Forces:
             target.copy_(forces)
         return eng.ebuf
 
+    def _evaluate_sync(self, pos, box, forces, exact=None):
+        """One energy (+ force) evaluation through `tmdhip_compute`: a single C call and a single host
+        synchronisation.  Fills `forces` (None: energies only) and returns the per-term energies as a host
+        array [R, NENERGY] (float64)."""
+        L.require_device_tensor(pos, "pos")
+        L.require_device_tensor(box, "box")
+        if pos.dim() != 3 or pos.shape[2] != 3 or pos.shape[1] != self.natoms:
+            raise RuntimeError(f"pos must have shape (nreplicas, {self.natoms}, 3), got {tuple(pos.shape)}")
+        p = pos.detach()
+        if not p.is_contiguous():
+            p = p.contiguous()
+        target = None
+        if forces is not None:
+            L.require_device_tensor(forces, "forces")
+            if forces.dtype != pos.dtype or forces.shape != pos.shape:
+                raise RuntimeError("forces must have the dtype and shape of pos")
+            if not forces.is_contiguous():
+                target, forces = forces, torch.empty_like(p)
+        eng = self._engine(p, exact)
+        hbox = self._host_box(box)
+        R = p.shape[0]
+        boxes = hbox if len(hbox) == R else np.ascontiguousarray(np.stack([hbox[min(r, len(hbox) - 1)] for r in range(R)]))
+        out = np.empty((R, L.NENERGY), dtype=np.float64)
+        with torch.cuda.device(p.device):
+            stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+            for _ in range(4):
+                rc = L.check(
+                    eng.lib.tmdhip_compute(
+                        eng.ctx, C.c_void_p(p.data_ptr()), boxes.ctypes.data_as(C.POINTER(C.c_double)),
+                        C.c_void_p(forces.data_ptr()) if forces is not None else C.c_void_p(),
+                        out.ctypes.data_as(C.POINTER(C.c_double)), stream,
+                    ),
+                    "tmdhip_compute",
+                )
+                if rc == 0:
+                    break
+            else:
+                raise RuntimeError("neighbour list kept overflowing; increase `skin` capacity")
+        if target is not None:
+            target.copy_(forces)
+        return out
+
     # ------------------------------------------------------------------ public API
     def compute(
         self,
@@ -490,9 +532,7 @@ class Forces:
         if calculateForces and not explicit_forces and pos.requires_grad and forces is None:
             scratch = torch.zeros_like(pos.detach())
         exact = True if (calculateForces and not explicit_forces) else None
-        ebuf = self._evaluate(
-            pos, box, forces if want_forces else scratch, True, want_forces or scratch is not None, exact=exact
-        )
+        ehost = self._evaluate_sync(pos, box, forces if want_forces else scratch, exact=exact)
 
         ext_ene = None
         if self.external:
@@ -508,28 +548,27 @@ class Forces:
 
         # per-term energies in the order of the reference dict: self.energies ..., then "external"
         names = list(self.energies) + ["external"]
-        cols = torch.zeros(nsystems, len(names), dtype=torch.float64, device=pos.device)
+        cols = np.zeros((nsystems, len(names)), dtype=np.float64)
         for k, name in enumerate(self.energies):
             slot = L.ENERGY_SLOT.get(name)
             if slot is not None:  # "1-4" has no slot: it accumulates into lj/electrostatics (forces.py:216,232)
-                cols[:, k] = ebuf[:, slot]
+                cols[:, k] = ehost[:, slot]
         if ext_ene is not None:
-            cols[:, -1] = torch.as_tensor(ext_ene, device=pos.device).detach().to(torch.float64).reshape(nsystems)
+            cols[:, -1] = torch.as_tensor(ext_ene).detach().to("cpu", torch.float64).reshape(nsystems).numpy()
 
         if not returnDetails:
-            tot = cols.sum(dim=1)
+            tot = cols.sum(axis=1)
             if toNumpy:
-                return [float(v) for v in tot.cpu().tolist()]
-            tot = tot.to(pos.dtype)
+                return [float(v) for v in tot]
+            tot = torch.as_tensor(tot, device=pos.device).to(pos.dtype)
             if not explicit_forces and calculateForces and pos.requires_grad:
                 fsrc = forces if want_forces else scratch
                 tot = _PotentialWithGrad.apply(pos, tot, fsrc.detach().clone())
             return tot
         if toNumpy:
-            host = cols.cpu().tolist()
-            return [{n: float(v) for n, v in zip(names, row)} for row in host]
-        cols = cols.to(pos.dtype)
-        return [{n: cols[s, k : k + 1].clone() for k, n in enumerate(names)} for s in range(nsystems)]
+            return [{n: float(v) for n, v in zip(names, row)} for row in cols]
+        tcols = torch.as_tensor(cols, device=pos.device).to(pos.dtype)
+        return [{n: tcols[s, k : k + 1].clone() for k, n in enumerate(names)} for s in range(nsystems)]
 
     # used by Integrator: no host synchronisation unless energies are requested
     def _compute_async(self, pos, box, forces, want_energy):

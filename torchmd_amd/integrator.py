@@ -191,6 +191,31 @@ class Integrator:
                 self._nstep += 1
 
             eng = self.forces._engine(s.pos) if (fast and niter > 0) else None
+            if fused and self.batch is None:
+                # kinetic energy + energies of the last step + neighbour-list validity: ONE C call, ONE read-back,
+                # ONE host synchronisation (tmdhip_md_observe)
+                obs = np.empty((R, L.NENERGY + 1), dtype=np.float64)
+                rc = L.check(
+                    lib.tmdhip_md_observe(eng.ctx, s.vel.data_ptr(), self.masses.data_ptr(), ebuf.data_ptr(),
+                                          obs.ctypes.data_as(C.POINTER(C.c_double)), _stream(dev)),
+                    "tmdhip_md_observe",
+                )
+                if rc != 0:
+                    # a neighbour list was truncated, or outlived its skin between two scheduled rebuilds: rewind
+                    # to the entry state (saved by tmdhip_md_run) and repeat the batch with the rebuild chain on
+                    # every step; the noise stream is counter based, so it is the same trajectory
+                    if not replay:
+                        return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
+                    raise RuntimeError(
+                        "a neighbour list overflowed during Integrator.step(); the trajectory since the previous "
+                        "step() call is invalid (capacity has been grown — restart from the last saved state)"
+                    )
+                cols = self.forces.energy_columns()
+                tot = obs[:, cols].sum(axis=1) if cols else np.zeros(R)
+                pot = [float(v) for v in tot]
+                Ekin = obs[:, L.NENERGY].copy()
+                Ekin = Ekin.astype(np.dtype("float32") if s.pos.dtype == torch.float32 else np.float64)
+                return Ekin, pot, kinetic_to_temp(Ekin, self.natoms)
             if self.batch is None:
                 if eng is not None:
                     kebuf = eng.kebuf  # shares one buffer with the energies: a single read-back below
@@ -221,10 +246,7 @@ class Integrator:
                     host = torch.cat([ke.flatten(), tot]).cpu().numpy()
                     Ekin, pot = host[: ke.numel()], [float(v) for v in host[ke.numel():]]
                 if not self.forces._verify(eng, s.pos):
-                    # a neighbour list was truncated, or outlived its skin between two scheduled rebuilds
-                    if fused and not replay:
-                        # rewind to the entry state (saved by tmdhip_md_run) and repeat the batch with the
-                        # rebuild chain on every step; the noise stream is counter based: same trajectory
+                    if fused and not replay:  # (batch mode of the fused loop: same rewind as above)
                         return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
                     raise RuntimeError(
                         "a neighbour list overflowed during Integrator.step(); the trajectory since the previous "
