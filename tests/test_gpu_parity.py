@@ -131,6 +131,37 @@ def test_switch_modes():
     assert torch.allclose(-grad, F_auto, atol=1e-12)
 
 
+def test_vmap_over_compute_like_the_reference_test():
+    """Reference tests/test_torchmd.py:552-605: `torch.vmap(forces.compute)` over a batch of positions with
+    explicit_forces=False, calculateForces=False, toNumpy=False, then backward() — alanine dipeptide, all
+    terms, no cutoff, fp64.  Epot per batch entry = the reference's own value (-1768.8915 for its ingestion of
+    the fixture; the golden holds the value for these exact inputs) and -grad = the golden forces."""
+    from torchmd_amd.forces import Forces
+
+    g = load("ala2")
+    dev = _dev()
+    terms = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+    par = GoldenParameters(g, torch.float64)
+    f = Forces(par, terms=terms, cutoff=None, switch_dist=7.5, rfa=False)
+    pos = pos_tensor(g["pos"], 1, torch.float64, dev)  # [1, N, 3]
+    box = box_tensor(np.zeros(3), 1, torch.float64, dev)
+    batch = 4
+    positions = torch.stack([pos] * batch, dim=0)  # [B, 1, N, 3]
+    positions[2, 0, 7, 1] += 0.05  # one entry differs: results must not be broadcast copies
+    positions.requires_grad = True
+    epot = torch.vmap(f.compute, in_dims=(0,))(positions, box=box, forces=None, returnDetails=False,
+                                               explicit_forces=False, calculateForces=False, toNumpy=False)
+    epot.sum().backward()
+    forces = -positions.grad
+    assert epot.shape == (batch, 1) and forces.shape == positions.shape
+    ref = sum(energies(g, "f64_full_nocut", 0).values())
+    assert abs(ref + 1768.8915) < 1e-3  # the literal of the reference test, for its float32-ingested inputs
+    assert abs(epot[0].item() - ref) < 1e-8 and abs(epot[1].item() - ref) < 1e-8 and abs(epot[3].item() - ref) < 1e-8
+    assert abs(epot[2].item() - ref) > 1e-6
+    assert np.abs(forces[0, 0].cpu().numpy() - g["f64_full_nocut_forces"][0]).max() < 1e-8
+    assert np.abs(forces[2, 0].cpu().numpy() - g["f64_full_nocut_forces"][0]).max() > 1e-4
+
+
 def test_thrombin_nocut_and_celllist():
     """4 676-atom non-periodic complex: no-cutoff all-pairs vs the reference golden, then the same
     system with a 9 A cutoff through the cell-list path vs the all-pairs kernel and the oracle."""

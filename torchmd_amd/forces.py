@@ -518,6 +518,8 @@ class Forces:
         toNumpy=True,
         calculateForces=True,
     ):
+        if _is_batched(pos):  # called under torch.vmap (reference tests/test_torchmd.py:590-598)
+            return self._compute_vmapped(pos, box, forces, returnDetails, explicit_forces, toNumpy, calculateForces)
         if calculateForces:
             if not explicit_forces and not pos.requires_grad:
                 raise RuntimeError(
@@ -528,10 +530,14 @@ class Forces:
         want_forces = calculateForces and forces is not None
         if forces is not None and not want_forces:
             forces.zero_()  # the reference zeroes `forces` whenever it is given (forces.py:113-114)
+        # The reference's potential is a torch expression of `pos`, so a tensor result can always be
+        # back-propagated, also with calculateForces=False (its vmap test does exactly that).  Here the
+        # gradient is -F from the kernels: evaluate the forces whenever a differentiable result is due.
+        differentiable = (not toNumpy) and (not returnDetails) and pos.requires_grad and torch.is_grad_enabled()
         scratch = None
-        if calculateForces and not explicit_forces and pos.requires_grad and forces is None:
+        if forces is None and ((calculateForces and not explicit_forces and pos.requires_grad) or differentiable):
             scratch = torch.zeros_like(pos.detach())
-        exact = True if (calculateForces and not explicit_forces) else None
+        exact = True if ((calculateForces and not explicit_forces) or (differentiable and not want_forces)) else None
         ehost = self._evaluate_sync(pos, box, forces if want_forces else scratch, exact=exact)
 
         ext_ene = None
@@ -561,7 +567,7 @@ class Forces:
             if toNumpy:
                 return [float(v) for v in tot]
             tot = torch.as_tensor(tot, device=pos.device).to(pos.dtype)
-            if not explicit_forces and calculateForces and pos.requires_grad:
+            if differentiable and (want_forces or scratch is not None) and (not explicit_forces or not want_forces):
                 fsrc = forces if want_forces else scratch
                 tot = _PotentialWithGrad.apply(pos, tot, fsrc.detach().clone())
             return tot
@@ -569,6 +575,31 @@ class Forces:
             return [{n: float(v) for n, v in zip(names, row)} for row in cols]
         tcols = torch.as_tensor(cols, device=pos.device).to(pos.dtype)
         return [{n: tcols[s, k : k + 1].clone() for k, n in enumerate(names)} for s in range(nsystems)]
+
+    def _compute_vmapped(self, pos, box, forces, returnDetails, explicit_forces, toNumpy, calculateForces):
+        """`torch.vmap(forces.compute)`: the batch dimension becomes extra replicas of ONE evaluation (the
+        kernels serve [R,N,3] anyway), and the result is handed back to vmap as a batched tensor.  Supports what
+        the reference's use needs: a tensor result (toNumpy=False, returnDetails=False), `forces=None`."""
+        F = torch._C._functorch
+        if toNumpy or returnDetails:
+            raise RuntimeError("compute() under torch.vmap returns tensors: pass toNumpy=False, returnDetails=False")
+        if forces is not None:
+            raise RuntimeError("compute() under torch.vmap does not fill a `forces` tensor: pass forces=None and "
+                               "differentiate the returned potential")
+        level, bdim = F.maybe_get_level(pos), F.maybe_get_bdim(pos)
+        p = F.get_unwrapped(pos)
+        if _is_batched(p):
+            raise RuntimeError("nested torch.vmap over compute() is not supported")
+        p = p.movedim(bdim, 0)  # [B, R, N, 3]
+        B, R = p.shape[0], p.shape[1]
+        flat = p.reshape(B * R, p.shape[2], 3)
+        if _is_batched(box):
+            b = F.get_unwrapped(box).movedim(F.maybe_get_bdim(box), 0)
+        else:
+            b = box.unsqueeze(0).expand(B, *box.shape)
+        bflat = b.reshape(B * R, 3, 3).contiguous()
+        tot = self.compute(flat, bflat, None, False, explicit_forces, False, calculateForces)  # [B * R]
+        return F._add_batch_dim(tot.reshape(B, R), 0, level)
 
     # used by Integrator: no host synchronisation unless energies are requested
     def _compute_async(self, pos, box, forces, want_energy):
@@ -656,14 +687,25 @@ class Forces:
         return ms.value, n.value
 
 
+def _is_batched(t) -> bool:
+    return torch.is_tensor(t) and torch._C._functorch.is_batchedtensor(t)
+
+
 class _PotentialWithGrad(torch.autograd.Function):
     """Makes the returned potential differentiable w.r.t. `pos` for `explicit_forces=False` callers
-    (reference forces.py:328-336 derives forces with autograd; here dE/dpos = -F from the kernels)."""
+    (reference forces.py:328-336 derives forces with autograd; here dE/dpos = -F from the kernels).
+    Written in the functorch-compatible style (setup_context) so that it can be applied while a
+    `torch.vmap` level is active."""
+
+    generate_vmap_rule = True
 
     @staticmethod
-    def forward(ctx, pos, energy, forces):
-        ctx.save_for_backward(forces)
+    def forward(pos, energy, forces):
         return energy.clone()
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(inputs[2])
 
     @staticmethod
     def backward(ctx, grad_out):
