@@ -270,7 +270,6 @@ def main():
             "steps_per_rebuild": (args.steps / rebuilds) if rebuilds else None,
             "entries": int(st2["list_entries"]),
             "skin": st2["skin"],
-            "rebuild_every": st2["rebuild_every"],
             "capacity_per_atom": int(st2["max_neighbours"]),
             "ncell": list(st2["ncell"]),
         },

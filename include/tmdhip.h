@@ -93,10 +93,6 @@ typedef struct tmdhip_nonbonded_desc {
   int32_t switch_mode;         /* TMDHIP_SWITCH_*                                          */
   int32_t algorithm;           /* TMDHIP_ALGO_*                                            */
   double skin;                 /* Verlet skin in Angstrom; <= 0: library default (1.2)     */
-  int32_t rebuild_every;       /* tmdhip_md_run enqueues the list-rebuild chain (5 launches that return at once
-                                  unless the device-side displacement test asked for a rebuild) on every E-th
-                                  step only; <= 0 or 1: every step (default)                   */
-  int32_t reserved0;
 } tmdhip_nonbonded_desc;
 
 /* Bonded topology (already expanded: one parameter row per instance).  Replaces the per-call
@@ -135,9 +131,7 @@ typedef struct tmdhip_stats {
   int32_t max_neighbours;   /* list capacity per atom                                       */
   int32_t overflow;         /* != 0: a list is currently truncated (see tmdhip_check)       */
   int32_t ncell[3];
-  int32_t violation;        /* != 0: the list outlived its skin between two scheduled rebuilds (see tmdhip_check) */
-  int32_t rebuild_every;
-  double skin;
+  double skin;              /* Verlet skin in use (Angstrom)                                */
 } tmdhip_stats;
 
 int tmdhip_abi_version(void);
@@ -173,9 +167,8 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
                    double *energies_host, void *stream);
 
 /* Synchronises `stream` and verifies that the neighbour lists used since the last check were valid: no
- * device-side rebuild ran out of list capacity, and no atom moved further than skin/2 on an MD step that
- * did not enqueue the rebuild chain (tmdhip_nonbonded_desc.rebuild_every).  Returns 0 = results valid; 1 = not valid: capacity has been grown /
- * the next compute rebuilds, and the caller must repeat the work (a plain evaluation is simply repeated; an
+ * device-side rebuild ran out of list capacity.  Returns 0 = results valid; 1 = not valid: the capacity has
+ * been grown, the next compute rebuilds, and the caller must repeat the work (a plain evaluation is simply repeated; an
  * MD batch is rewound with tmdhip_md_restore and run again); negative = error. */
 int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream);
 
@@ -205,9 +198,9 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
 int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev, const double *energies_dev,
                       double *out_host, void *stream);
 /* Rewind: copy the state tmdhip_md_run saved at its entry (positions, velocities, forces of every replica)
- * back into desc's buffers and make the next tmdhip_md_run enqueue the rebuild chain on every step (no
- * scheduled-rebuild violation possible).  Used after tmdhip_check returned 1 for an MD batch; the noise
- * stream is counter based, so the repeated batch is the same trajectory. */
+ * back into desc's buffers.  Used after tmdhip_md_observe / tmdhip_check returned 1 for an MD batch (a list was
+ * truncated: the capacity has been grown); the noise stream is counter based, so running the batch again gives
+ * the trajectory the truncated run should have produced. */
 int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
 
 /* Atomic systems only (no exclusions, no bonded terms): replace the atom set of the context — new count,

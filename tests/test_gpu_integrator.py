@@ -380,3 +380,61 @@ def test_replica_batched_langevin_equals_stepwise_loop():
     for a, b in zip(r0, r1):
         assert np.allclose(a[0], b[0], rtol=1e-9) and np.allclose(a[1], b[1], rtol=1e-9)
     assert (p0[0] - p0[2]).abs().max().item() > 1e-3
+
+
+def test_list_overflow_is_replayed_not_raised(monkeypatch):
+    """A neighbour list that overflows during an Integrator.step() batch (a device-side rebuild finds more
+    neighbours than the capacity sized at the first build) no longer invalidates the trajectory: the batch is
+    rewound to its entry state (tmdhip_md_restore), the capacity grown, and the batch repeated with the same
+    noise stream.  (Not bit-identical to a run with ample capacity: the replay rebuilds its list at the entry
+    positions, i.e. at other steps, and the fp32 summation order follows the list.)  Checked: no exception, the
+    lists grew, nothing is truncated at the end, the forces of the final state are those of a fresh evaluation,
+    and the thermodynamic state matches the untroubled run."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(14, seed=4)  # 8 232 atoms on a lattice: uniform neighbour counts at the start
+    # expanded by 15 % (each molecule moved as a whole): ~290 neighbours per atom, after melting the largest
+    # count exceeds the tight capacity (observed maximum rounded up to the list granule) by tens of entries
+    com = pos.reshape(-1, 3, 3).mean(axis=1, keepdims=True)
+    pos = (pos.reshape(-1, 3, 3) + 0.15 * com).reshape(-1, 3)
+    box = box * 1.15
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+
+    monkeypatch.setenv("TMDHIP_LPA", "8")  # list granule of 32 entries per atom (a small system would get 256)
+
+    def run(tight):
+        if tight:
+            monkeypatch.setenv("TMDHIP_DEBUG_LIST_SLACK", "0")
+        else:
+            monkeypatch.delenv("TMDHIP_DEBUG_LIST_SLACK", raising=False)
+        s = System(mol.numAtoms, 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        torch.manual_seed(5)
+        s.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        f.compute(s.pos, s.box, s.forces)
+        cap0 = f.stats(s.pos)["max_neighbours"]
+        torch.manual_seed(6)
+        integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+        out = integ.step(400)  # the lattice melts: the largest neighbour count grows by far more than 32
+        st = f.stats(s.pos)
+        fresh = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        F2 = torch.zeros_like(s.pos)
+        fresh.compute(s.pos, s.box, F2)
+        ferr = (F2 - s.forces).abs().max().item()
+        return out, cap0, st, ferr
+
+    out_ref, cap_ref, st_ref, ferr_ref = run(False)
+    out_t, cap_t, st_t, ferr_t = run(True)
+    assert cap_t < cap_ref and st_t["max_neighbours"] > cap_t  # the tight run had to grow its lists
+    assert st_t["overflow"] == 0 and st_ref["overflow"] == 0
+    assert ferr_t < 2e-3 and ferr_ref < 2e-3
+    assert abs(out_t[2][0] - out_ref[2][0]) < 15.0  # temperature (K)
+    assert abs(out_t[1][0] - out_ref[1][0]) < 0.01 * abs(out_ref[1][0])  # potential energy

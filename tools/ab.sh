@@ -6,5 +6,5 @@ for lib in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.readline())
 l=d['list']
-print('ms/step %.4f  ns/day %.1f  pair_us %.2f  rebuilds %s  entries %s  E %s  T %.1f Epot %.1f' % (d['ms_per_step'], d['value'], d['roofline']['avg_kernel_us'], l['rebuilds_in_timed_region'], l['entries'], l['rebuild_every'], d['temperature_K'][0], d['epot_kcal_mol'][0]))"
+print('ms/step %.4f  ns/day %.1f  pair_us %.2f  rebuilds %s  entries %s  T %.1f Epot %.1f' % (d['ms_per_step'], d['value'], d['roofline']['avg_kernel_us'], l['rebuilds_in_timed_region'], l['entries'], d['temperature_K'][0], d['epot_kcal_mol'][0]))"
 done

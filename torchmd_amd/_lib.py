@@ -63,8 +63,6 @@ class NonbondedDesc(C.Structure):
         ("switch_mode", C.c_int32),
         ("algorithm", C.c_int32),
         ("skin", C.c_double),
-        ("rebuild_every", C.c_int32),
-        ("reserved0", C.c_int32),
     ]
 
 
@@ -123,8 +121,6 @@ class Stats(C.Structure):
         ("max_neighbours", C.c_int32),
         ("overflow", C.c_int32),
         ("ncell", C.c_int32 * 3),
-        ("violation", C.c_int32),
-        ("rebuild_every", C.c_int32),
         ("skin", C.c_double),
     ]
 

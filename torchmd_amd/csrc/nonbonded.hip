@@ -219,22 +219,18 @@ __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
 //                 SET flags[p] and CLEAR flags[p^1]; every other kernel of that step only reads flags[p].
 //   F_MAXN        largest neighbour count seen by a build (> capacity: a list was truncated)
 //   F_NREBUILD    rebuild counter
-//   F_VIOLATION   sticky: the list outlived its skin on a step that did not enqueue the rebuild chain
-enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_COUNT = 8 };
+enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_COUNT = 4 };
 
-// Displacement test that drives the rebuilds (thresholds are squared distances).  The list (cutoff + skin) is
-// valid while no atom has moved further than skin/2 from `ref`.  The rebuild chain (5 launches that return at
-// once unless the flag is set: ~8 us per step at C3) is only enqueued on "eligible" steps — every E-th MD step,
-// decided on the host — so a rebuild is requested early, at `early2` < `hard2` = (skin/2)^2, and a
-// displacement beyond hard2 on a step without chain sets the sticky F_VIOLATION flag: the caller rewinds the
-// batch (tmdhip_md_restore) and repeats it with the chain on every step.
+// Displacement test that drives the rebuilds: the list (cutoff + skin) is valid while no atom has moved
+// further than skin/2 from `ref`; the test runs on the device (in the fused integrator kernel, or in
+// check_displacement_kernel for plain evaluations) and every kernel of the rebuild chain returns at once unless
+// the flag of its step is set, so the host never has to look.
 template <typename R>
 struct ListCheck {
-  const R *ref;     // positions at the last list build, original atom order [3N]
-  R early2, hard2;
+  const R *ref;  // positions at the last list build, original atom order [3N]
+  R hard2;       // (skin/2)^2
   int *flags;
   int parity;
-  int eligible;     // the rebuild chain is enqueued in this step
 };
 
 template <typename R>
@@ -243,8 +239,7 @@ __device__ __forceinline__ void list_check_atom(const ListCheck<R> &k, const Pai
   const R dy = min_image(py - k.ref[3 * i + 1], c.box[1], c.invbox[1]);
   const R dz = min_image(pz - k.ref[3 * i + 2], c.box[2], c.invbox[2]);
   const R d2 = dx * dx + dy * dy + dz * dz;
-  if (!(d2 <= k.early2)) k.flags[F_REBUILD0 + k.parity] = 1;  // NaN positions also force a rebuild
-  if (!k.eligible && !(d2 <= k.hard2)) k.flags[F_VIOLATION] = 1;
+  if (!(d2 <= k.hard2)) k.flags[F_REBUILD0 + k.parity] = 1;  // NaN positions also force a rebuild
 }
 
 // thread 0 of the check of a step: the other parity's request is history
@@ -355,7 +350,7 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
 template <typename R>
 __global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const int *__restrict__ order,
                                      typename Vec<R>::T4 *__restrict__ sorted, const int *flag) {
-  if (flag && *flag) return;  // place_sorted_kernel has just written everything
+  if (*flag) return;  // place_sorted_kernel has just written everything
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
   const int i = order[a];
@@ -1161,9 +1156,6 @@ struct tmdhip_ctx {
   int algorithm = TMDHIP_ALGO_ALLPAIRS;
   double skin = 1.0;        // Verlet skin
   double rlist = 0;         // cutoff + skin
-  int rebuild_every = 1;    // E: the MD loop enqueues the rebuild chain on steps with step % E == 0
-  double early_margin = 0;  // a rebuild is requested at displacement skin/2 - early_margin
-  bool safe_mode = false;   // chain on every step (replay after a violation)
   DevBuf snap;              // pos, vel, forces at the entry of the last tmdhip_md_run (replay)
   size_t snap_bytes = 0;
   DevBuf sync_e;            // tmdhip_compute: per-term energies [R][NENERGY] on the device ...
@@ -1406,24 +1398,15 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
   return 0;
 }
 
-// thresholds of the displacement test for the step that `rp.step` counts (see ListCheck)
+// displacement test for the step that `rp.step` counts (see ListCheck)
 template <typename R>
-ListCheck<R> make_check(const tmdhip_ctx *ctx, Replica &rp, bool eligible) {
+ListCheck<R> make_check(const tmdhip_ctx *ctx, Replica &rp) {
   ListCheck<R> k;
   k.ref = rp.ref.as<R>();
-  const double hard = 0.5 * ctx->skin;
-  // with the chain on every step a rebuild can wait until the list is about to become invalid
-  const double early = (ctx->rebuild_every > 1 && !ctx->safe_mode) ? std::max(hard - ctx->early_margin, 0.25 * hard) : hard;
-  k.early2 = (R)(early * early);
-  k.hard2 = (R)(hard * hard);
+  k.hard2 = (R)(0.25 * ctx->skin * ctx->skin);
   k.flags = rp.flags.as<int>();
   k.parity = (int)(rp.step & 1);
-  k.eligible = eligible ? 1 : 0;
   return k;
-}
-
-bool step_eligible(const tmdhip_ctx *ctx, const Replica &rp) {
-  return ctx->safe_mode || ctx->rebuild_every <= 1 || (rp.step % ctx->rebuild_every) == 0;
 }
 
 template <typename R, bool ENERGY>
@@ -1536,28 +1519,19 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
 }
 
 // Enqueue: displacement check -> conditional rebuild chain -> gather.  `force` forces a rebuild.
-// `prechecked`: the fused MD-step kernel already ran the displacement test of this step (with the same
-// `eligible`); on steps that are not eligible for a rebuild nothing is enqueued then.
+// `prechecked`: the fused MD-step kernel already ran the displacement test of this step.
 template <typename R>
 int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force,
-                        hipStream_t st, bool prechecked = false, bool eligible = true) {
+                        hipStream_t st, bool prechecked = false) {
   using R4 = typename Vec<R>::T4;
   const int n = ctx->d.natoms;
   const int parity = (int)(rp.step & 1);
   int *flags = rp.flags.as<int>();
   const int *flag = flags + F_REBUILD0 + parity;
   const int nb = (n + 255) / 256;
-  if (force) eligible = true;
   if (!prechecked)
-    hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, make_check<R>(ctx, rp, eligible),
-                       c, force);
-  if (!eligible) {
-    if (!prechecked)  // (only the MD loop skips the chain today, and it always pre-checks)
-      hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.order.as<int>(),
-                         rp.sorted.as<R4>(), (const int *)nullptr);
-    TMD_HIP(hipGetLastError());
-    return 0;
-  }
+    hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, make_check<R>(ctx, rp), c,
+                       force);
   hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, rp.cell_of.as<int>(),
                      rp.slot.as<int>(), rp.count.as<int>(), flag);
   hipLaunchKernelGGL(scan_cells_kernel, dim3(1), dim3(1024), 0, st, rp.ncell, rp.count.as<int>(),
@@ -1587,7 +1561,6 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
 }
 
 constexpr int kPrechecked = 1 << 16;  // internal compute flag: displacement test already enqueued
-constexpr int kNotEligible = 1 << 18;  // internal compute flag: this step does not enqueue the rebuild chain
 constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
 
 template <typename R>
@@ -1638,8 +1611,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     force = 1;
   }
   for (int attempt = 0; attempt < 8; ++attempt) {
-    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked),
-                                   !(flags & kNotEligible)));
+    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked)));
     rp.step++;
     if (!force) break;
     // forced builds are host-visible: size the list from the observed maximum so that later
@@ -1648,7 +1620,17 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     TMD_HIP(hipMemcpyAsync(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
     TMD_HIP(hipStreamSynchronize(st));
     rp.host_rebuilds++;
-    const int want = (int)(h[F_MAXN] * 1.2) + 8;
+    int want = (int)(h[F_MAXN] * 1.2) + 8;
+    if (const char *e = std::getenv("TMDHIP_DEBUG_LIST_SLACK")) {
+      // test knob: size the list for the observed maximum + N entries only, so that a later device-side
+      // rebuild overflows and the replay path (tmdhip_md_restore) gets exercised
+      want = h[F_MAXN] + std::max(std::atoi(e), 0);
+      const int tight = (want + 4 * rp.lg.lpa - 1) / (4 * rp.lg.lpa) * (4 * rp.lg.lpa);
+      if (!rp.have_list && h[F_MAXN] <= rp.lg.maxn && rp.lg.maxn > tight) {
+        TMD_TRY(alloc_replica<R>(ctx, rp, tight));
+        continue;  // rebuild in the tighter geometry
+      }
+    }
     if (h[F_MAXN] <= rp.lg.maxn && (rp.have_list || want <= rp.lg.maxn)) {
       rp.have_list = true;
       break;
@@ -1853,8 +1835,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       a.f_zero = (first && !list && ctx->d.terms != 0) ? f : nullptr;
       const bool zeroed = a.f_zero != nullptr;
       a.row0 = (uint64_t)r * (uint64_t)n;
-      const bool eligible = step_eligible(ctx, rp);
-      a.chk = make_check<R>(ctx, rp, eligible);
+      a.chk = make_check<R>(ctx, rp);
       a.sorted = rp.sorted.as<R4>();
       a.inv = rp.inv.as<int>();
       a.pos_in = a.pos_out = cur[r];
@@ -1891,9 +1872,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         rp.n_compute++;
         if (list) {
           const int rc = compute_list<R>(ctx, rp, pos, box, f, en,
-                                         flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0) |
-                                             ((check && !eligible) ? kNotEligible : 0),
-                                         st);
+                                         flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0), st);
           if (rc == kFallbackAllPairs) {
             ctx->algorithm = TMDHIP_ALGO_ALLPAIRS;
             list = false;
@@ -1969,18 +1948,7 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
   tmdhip_ctx *ctx = new tmdhip_ctx();
   ctx->d = *desc;
   ctx->real_size = desc->dtype == TMDHIP_F32 ? 4 : 8;
-  auto env_double = [](const char *name, double dflt) {
-    const char *e = std::getenv(name);
-    return e ? std::atof(e) : dflt;
-  };
   ctx->skin = desc->skin > 0 ? desc->skin : 1.2;  // measured optimum for the C3 water box (tools/time_kernels.py)
-  // E > 1: the MD loop enqueues the rebuild chain on every E-th step only and asks for the rebuild (E - 1)
-  // steps' worth of motion of the fastest atoms early (a miss is caught by F_VIOLATION and replayed).
-  // Measured on the C3 water box (skin 1.2 A, natural interval 9 steps): E = 2 +1.7 %, E = 4 -10 % (the early
-  // threshold costs more rebuilds than the skipped early-exit launches save) -> default 1.
-  ctx->rebuild_every = desc->rebuild_every > 0 ? desc->rebuild_every : (int)env_double("TMDHIP_REBUILD_EVERY", 1);
-  if (ctx->rebuild_every < 1) ctx->rebuild_every = 1;
-  ctx->early_margin = env_double("TMDHIP_EARLY_MARGIN", 0.1) * (ctx->rebuild_every - 1);
   ctx->rlist = desc->cutoff > 0 ? desc->cutoff + ctx->skin : 0;
   const int n = desc->natoms;
   auto cleanup = [&](int rc) {
@@ -2147,9 +2115,7 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   TMD_HIP(hipMemcpy(&pc, rp.paircount.p, sizeof(pc), hipMemcpyDeviceToHost));
   out->n_compute = rp.n_compute;
   out->n_rebuilds = h[F_NREBUILD];
-  out->violation = h[F_VIOLATION];
   out->skin = ctx->skin;
-  out->rebuild_every = ctx->rebuild_every;
   out->pairs_in_cutoff = (int64_t)pc;
   out->algorithm = ctx->algorithm;
   out->max_neighbours = rp.lg.maxn;
@@ -2167,14 +2133,6 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
 
 // verdict on the list flags of one replica (already on the host): 0 valid, 1 repeat the work, < 0 error
 static int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
-  if (h[F_VIOLATION]) {
-    // an atom moved further than skin/2 on a step that did not enqueue the rebuild chain: forces since then
-    // may miss pairs.  Clear the flag, rebuild on the next call; the caller repeats the work (tmdhip_md_restore).
-    TMD_HIP(hipMemsetAsync(rp.flags.as<int>() + F_VIOLATION, 0, sizeof(int), st));
-    rp.box[0] = -1;
-    last_error() = "neighbour list outlived its skin between two scheduled rebuilds (results since the last check are invalid)";
-    return 1;
-  }
   if (h[F_MAXN] <= rp.lg.maxn) return 0;
   // a device-side rebuild truncated a list: grow the capacity and force a rebuild on the next call
   const int want = (int)(h[F_MAXN] * 1.25) + 16;
@@ -2245,8 +2203,7 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
   if (desc->niter == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (ctx->algorithm == TMDHIP_ALGO_CELLLIST) {
-    // state at entry, for tmdhip_md_restore (a truncated list or a scheduled-rebuild violation is only
-    // detected after the batch): three device copies of N x 3 reals per call
+    // state at entry, for tmdhip_md_restore (a truncated list is only detected after the batch)
     const size_t bytes = (size_t)ctx->real_size * 3 * ctx->d.natoms * ctx->rep.size();
     const size_t padded = (bytes + 15) / 16 * 16;
     TMD_TRY(ctx->snap.ensure(3 * padded));
@@ -2266,9 +2223,7 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     }
     ctx->snap_bytes = bytes;
   }
-  const int rc = ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
-  ctx->safe_mode = false;  // (a replayed batch ran with the chain on every step)
-  return rc;
+  return ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
 }
 
 int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev, const double *energies_dev,
@@ -2317,7 +2272,6 @@ int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream)
   TMD_HIP(hipMemcpyAsync(desc->vel_dev, sn + padded, bytes, hipMemcpyDeviceToDevice, st));
   TMD_HIP(hipMemcpyAsync(desc->forces_dev, sn + 2 * padded, bytes, hipMemcpyDeviceToDevice, st));
   for (auto &rp : ctx->rep) rp.box[0] = -1;  // re-plan + rebuild from the restored positions
-  ctx->safe_mode = true;
   return 0;
 }
 

@@ -127,7 +127,6 @@ class _Engine:
         d.switch_mode = L.SWITCH_EXACT if exact else L.SWITCH_REFERENCE
         d.algorithm = {"auto": L.ALGO_AUTO, "allpairs": L.ALGO_ALLPAIRS, "celllist": L.ALGO_CELLLIST}[owner.algorithm]
         d.skin = float(owner.skin) if owner.skin else 0.0
-        d.rebuild_every = int(owner.rebuild_every) if owner.rebuild_every else 0
         L.check(lib.tmdhip_create(C.byref(self.ctx), C.byref(d)), "tmdhip_create")
 
         b = L.BondedDesc()
@@ -232,7 +231,6 @@ class Forces:
     Extra keyword-only knobs of this implementation
     ----------
     skin : float          Verlet-list skin in Angstrom (default 1.2)
-    rebuild_every : int   the MD loop enqueues the list-rebuild chain on every E-th step only (default 1)
     algorithm : str       "auto" | "allpairs" | "celllist"
     switch_mode : str     "reference" (upstream's explicit switching force, extra 1/r,
                           forces.py:410-412) | "exact" (-dE/dr)
@@ -254,7 +252,6 @@ class Forces:
         exclusions=("bonds", "angles", "1-4"),
         *,
         skin=None,
-        rebuild_every=None,
         algorithm="auto",
         switch_mode="reference",
     ):
@@ -297,7 +294,6 @@ class Forces:
         self.switch_dist = switch_dist
         self.exclusions = tuple(exclusions)
         self.skin = skin  # None -> library default
-        self.rebuild_every = rebuild_every
         self.algorithm = algorithm
         self.switch_mode = switch_mode
         self._excl_csr = build_exclusion_csr(
@@ -669,8 +665,6 @@ class Forces:
             "max_neighbours": st.max_neighbours,
             "overflow": st.overflow,
             "ncell": tuple(st.ncell),
-            "violation": st.violation,
-            "rebuild_every": st.rebuild_every,
             "skin": st.skin,
         }
 
