@@ -85,22 +85,21 @@ __device__ __forceinline__ void replica_view(BondedArgs<R> &A, const R *__restri
   }
 }
 
-// (1) light topologies (every atom in a handful of terms: water, ions): thread = atom, one launch
+// (1) light topologies (every atom in a handful of terms: water, ions): four lanes per atom, one launch
 template <typename R>
 __global__ __launch_bounds__(256) void bonded_atom_kernel(int natoms, BondedArgs<R> A, const R *__restrict__ pos,
                                                           R *__restrict__ forces, double *__restrict__ energies,
                                                           int want_e, const R *__restrict__ boxes) {
   replica_view(A, pos, forces, energies, boxes, natoms);
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = t / kQuad, sub = t % kQuad;
   R fx = 0, fy = 0, fz = 0;
   double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (a < natoms) {
-    eval_atom<R>(A, pos, a, fx, fy, fz, e);
-    if (forces) {
-      forces[3 * a + 0] += fx;
-      forces[3 * a + 1] += fy;
-      forces[3 * a + 2] += fz;
-    }
+  eval_atom_quad<R>(A, pos, a, sub, a < natoms, fx, fy, fz, e);
+  if (a < natoms && sub == 0 && forces) {
+    forces[3 * a + 0] += fx;
+    forces[3 * a + 1] += fy;
+    forces[3 * a + 2] += fz;
   }
   if (want_e) flush_energies(e, energies);
 }
@@ -326,7 +325,7 @@ int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box,
   const int we = (flags & TMDHIP_WANT_ENERGY) ? 1 : 0;
   const int n = b->natoms;
   if (b->max_entries_per_atom <= kAtomCentricLimit) {
-    hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((n + 255) / 256, nrep), dim3(256), 0, st, n, A,
+    hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((kQuad * n + 255) / 256, nrep), dim3(256), 0, st, n, A,
                        (const R *)pos_v, forces, ctx_energy_scratch(ctx), we, boxes);
   } else {
     hipLaunchKernelGGL((bonded_wave_kernel<R>), dim3((n + 3) / 4, nrep), dim3(256), 0, st, n, A, (const R *)pos_v,

@@ -273,15 +273,28 @@ __device__ __forceinline__ void eval_rec(const BondedArgs<R> &A, const R *__rest
   }
 }
 
-// all bonded terms of atom `self` (atom-centric scheme)
+// All bonded terms of atom `self` (atom-centric scheme), evaluated by the FOUR adjacent lanes of the atom:
+// lane `sub` takes records sub, sub + 4, ... (a record = load, then dependent partner-position loads: one
+// thread walking an atom's records is a chain of 2 x records memory round trips — 9.9 us for the kernel at C3 —
+// four lanes make it 2), then the three force components are added with a fixed butterfly:
+// (r0 + r1) + (r2 + r3).  Must be called by all four lanes (active = the atom exists); every lane returns the sum.
+constexpr int kQuad = 4;
 template <typename R>
-__device__ __forceinline__ void eval_atom(const BondedArgs<R> &A, const R *__restrict__ pos, int self, R &fx, R &fy,
-                                          R &fz, double *e) {
-  const AtomRec<R> *rec = A.arec + (size_t)self * A.arec_stride;
-  for (int k = 0; k < A.arec_stride; ++k) {
-    const AtomRec<R> r = rec[k];
-    if (r.ent == kNoRec) break;
-    eval_rec<R>(A, pos, self, r, fx, fy, fz, e);
+__device__ __forceinline__ void eval_atom_quad(const BondedArgs<R> &A, const R *__restrict__ pos, int self, int sub,
+                                               bool active, R &fx, R &fy, R &fz, double *e) {
+  if (active) {
+    const AtomRec<R> *rec = A.arec + (size_t)self * A.arec_stride;
+    for (int k = sub; k < A.arec_stride; k += kQuad) {
+      const AtomRec<R> r = rec[k];
+      if (r.ent == kNoRec) break;  // records are packed from the front
+      eval_rec<R>(A, pos, self, r, fx, fy, fz, e);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < kQuad; o <<= 1) {
+    fx += __shfl_xor(fx, o, 64);
+    fy += __shfl_xor(fy, o, 64);
+    fz += __shfl_xor(fz, o, 64);
   }
 }
 

@@ -233,13 +233,18 @@ struct ListCheck {
   int parity;
 };
 
+// (rx, ry, rz) = position - reference position of one atom
 template <typename R>
-__device__ __forceinline__ void list_check_atom(const ListCheck<R> &k, const PairConsts<R> &c, int i, R px, R py, R pz) {
-  const R dx = min_image(px - k.ref[3 * i + 0], c.box[0], c.invbox[0]);
-  const R dy = min_image(py - k.ref[3 * i + 1], c.box[1], c.invbox[1]);
-  const R dz = min_image(pz - k.ref[3 * i + 2], c.box[2], c.invbox[2]);
+__device__ __forceinline__ void list_check_point(const ListCheck<R> &k, const PairConsts<R> &c, R rx, R ry, R rz) {
+  const R dx = min_image(rx, c.box[0], c.invbox[0]);
+  const R dy = min_image(ry, c.box[1], c.invbox[1]);
+  const R dz = min_image(rz, c.box[2], c.invbox[2]);
   const R d2 = dx * dx + dy * dy + dz * dz;
   if (!(d2 <= k.hard2)) k.flags[F_REBUILD0 + k.parity] = 1;  // NaN positions also force a rebuild
+}
+template <typename R>
+__device__ __forceinline__ void list_check_atom(const ListCheck<R> &k, const PairConsts<R> &c, int i, R px, R py, R pz) {
+  list_check_point<R>(k, c, px - k.ref[3 * i + 0], py - k.ref[3 * i + 1], pz - k.ref[3 * i + 2]);
 }
 
 // thread 0 of the check of a step: the other parity's request is history
@@ -982,21 +987,47 @@ struct MdStepArgs {
   const R *qs;
 };
 
+// Everything the update of one atom reads, loaded in ONE batch before any arithmetic or store: the kernel is
+// a chain of memory round trips per wave (every wave of the launch is resident at once), and stores to the
+// position buffers would otherwise order the later loads (inv, ref, qs) behind them.
+template <typename R>
+struct AtomIn {
+  R m, vc, q;
+  R v[3], f[3], p[3], r[3];
+  int slot;
+};
+
+template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
+__device__ __forceinline__ AtomIn<R> md_load_atom(const MdStepArgs<R> &s, int i, size_t off) {
+  AtomIn<R> x;
+  const R *vel = s.vel + off, *f = s.f + off, *pos_in = s.pos_in + off;
+  x.m = s.mass[i];
+  x.vc = (SECOND && LANGEVIN) ? s.vcoeff[i] : R(0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    x.v[k] = vel[3 * i + k];
+    x.f[k] = f[3 * i + k];
+    x.p[k] = FIRST ? pos_in[3 * i + k] : R(0);
+    x.r[k] = (FIRST && CHECK) ? s.chk.ref[3 * i + k] : R(0);
+  }
+  x.q = (FIRST && CHECK) ? s.qs[i] : R(0);
+  x.slot = (FIRST && CHECK) ? s.inv[i] : 0;
+  return x;
+}
+
 // fb = extra force on atom i that is not in `f` (the inline bonded force), added before the division
 // by the mass exactly like the separate bonded kernel's `forces[i] += fb`
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
 __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairConsts<R> &c, int i, size_t off,
-                                             uint64_t row0, const R (&fb)[3], bool add_fb) {
+                                             uint64_t row0, const AtomIn<R> &x, const R (&fb)[3], bool add_fb) {
 #pragma clang fp contract(off)
-  const R *pos_in = s.pos_in + off;
   R *pos_out = s.pos_out + off, *vel = s.vel + off;
-  const R *f = s.f + off;
-  const R m = s.mass[i];
+  const R m = x.m;
   R v[3], a[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    v[k] = vel[3 * i + k];
-    R fk = f[3 * i + k];
+    v[k] = x.v[k];
+    R fk = x.f[k];
     if (add_fb) fk += fb[k];
     a[k] = fk / m;
   }
@@ -1007,7 +1038,7 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
   }
   if (SECOND) {
     if (LANGEVIN) {
-      const R vc = s.vcoeff[i];
+      const R vc = x.vc;
       R g[3];
       normal3<R>(s.seed, s.noise_step, row0 + (uint64_t)i, g[0], g[1], g[2]);
 #pragma unroll
@@ -1020,7 +1051,7 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
     R p[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      p[k] = pos_in[3 * i + k] + (v[k] * s.dt + R(0.5) * a[k] * s.dt * s.dt);
+      p[k] = x.p[k] + (v[k] * s.dt + R(0.5) * a[k] * s.dt * s.dt);
       v[k] = v[k] + s.half_dt * a[k];
       pos_out[3 * i + k] = p[k];
     }
@@ -1031,9 +1062,9 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
       sv.x = p[0];
       sv.y = p[1];
       sv.z = p[2];
-      sv.w = s.qs[i];
-      s.sorted[s.inv[i]] = sv;
-      list_check_atom<R>(s.chk, c, i, p[0], p[1], p[2]);
+      sv.w = x.q;
+      s.sorted[x.slot] = sv;
+      list_check_point<R>(s.chk, c, p[0] - x.r[0], p[1] - x.r[1], p[2] - x.r[2]);
     }
   }
 #pragma unroll
@@ -1049,7 +1080,8 @@ __global__ void md_step_kernel(MdStepArgs<R> s, PairConsts<R> c) {
   const size_t off = CHECK ? 0 : (size_t)blockIdx.y * 3 * s.n;
   const uint64_t row0 = s.row0 + (CHECK ? 0 : (uint64_t)blockIdx.y * (uint64_t)s.n);
   const R none[3] = {0, 0, 0};
-  md_step_atom<R, SECOND, LANGEVIN, FIRST, CHECK>(s, c, i, off, row0, none, false);
+  const AtomIn<R> x = md_load_atom<R, SECOND, LANGEVIN, FIRST, CHECK>(s, i, off);
+  md_step_atom<R, SECOND, LANGEVIN, FIRST, CHECK>(s, c, i, off, row0, x, none, false);
 }
 
 // Interior steps of an MD run: the bonded force of the previous step's positions is evaluated HERE
@@ -1077,11 +1109,28 @@ __global__ __launch_bounds__(256) void md_step_bonded_kernel(MdStepArgs<R> s, Pa
   const R *pos = s.pos_in + off;
   R fx = 0, fy = 0, fz = 0;
   double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= s.n) return;
-  eval_atom<R>(A, pos, i, fx, fy, fz, e);
-  const R fb[3] = {fx, fy, fz};
-  md_step_atom<R, true, LANGEVIN, true, CHECK>(s, c, i, off, row0, fb, true);
+  // Two thread mappings in one block of 256 threads = 64 atoms: the bonded records are evaluated by four
+  // lanes per atom (eval_atom_quad: short dependent-load chains, every lane busy), the result goes through
+  // LDS, and the update itself (noise, kicks, drift: ~400 instructions per atom) runs one atom per lane on
+  // the block's first wave — with one lane in four active it cost 4x the VALU time.  The first wave issues
+  // the loads of its 64 atoms before the bonded part so that they are in flight meanwhile.
+  __shared__ R s_fb[3][64];
+  const int a0 = blockIdx.x * 64;
+  const int i = a0 + (int)threadIdx.x / kQuad, sub = (int)threadIdx.x % kQuad;
+  const int mine = a0 + (int)threadIdx.x;  // atom this thread integrates (first wave only)
+  const bool integrates = threadIdx.x < 64 && mine < s.n;
+  AtomIn<R> x{};
+  if (integrates) x = md_load_atom<R, true, LANGEVIN, true, CHECK>(s, mine, off);
+  eval_atom_quad<R>(A, pos, i, sub, i < s.n, fx, fy, fz, e);
+  if (sub == 0) {
+    s_fb[0][threadIdx.x / kQuad] = fx;
+    s_fb[1][threadIdx.x / kQuad] = fy;
+    s_fb[2][threadIdx.x / kQuad] = fz;
+  }
+  __syncthreads();
+  if (!integrates) return;
+  const R fb[3] = {s_fb[0][threadIdx.x], s_fb[1][threadIdx.x], s_fb[2][threadIdx.x]};
+  md_step_atom<R, true, LANGEVIN, true, CHECK>(s, c, mine, off, row0, x, fb, true);
 }
 
 __global__ void halve_count_kernel(unsigned long long *c) { *c >>= 1; }
@@ -1709,7 +1758,7 @@ void launch_md_step(const MdStepArgs<R> &a, const PairConsts<R> &c, bool check, 
 template <typename R>
 void launch_md_step_bonded(const MdStepArgs<R> &a, const PairConsts<R> &c, const BondedArgs<R> &A, bool langevin,
                            bool check, const R *boxes, int nrep, hipStream_t st) {
-  const dim3 grid((a.n + 255) / 256, check ? 1 : nrep), block(256);
+  const dim3 grid((kQuad * a.n + 255) / 256, check ? 1 : nrep), block(256);
 #define TMD_MSB(L, C) hipLaunchKernelGGL((md_step_bonded_kernel<R, L, C>), grid, block, 0, st, a, c, A, boxes)
   if (langevin && check) TMD_MSB(true, true);
   else if (langevin) TMD_MSB(true, false);
