@@ -34,9 +34,9 @@ PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
 
 
 def timing_stride(steps):
-    """HIP events bracket every launch of the pair kernel for short runs and every 16th for long ones (an
-    event pair costs ~3 us of stream time), so that any --steps >= 8 yields >= 8 timed launches."""
-    return 1 if steps < 128 else 16
+    """HIP events bracket every n-th launch of the pair kernel (an event pair costs ~3 us of stream time):
+    n chosen so that any --steps >= 8 yields >= 8 timed launches (20 steps: every 2nd; >= 128: every 16th)."""
+    return max(1, min(16, steps // 8))
 
 
 def pmc_traffic():
@@ -94,6 +94,107 @@ def dry_run(args, rank, world):
                           "dry": True, "ranks_seen": [int(x) for x in obs[:, 0]]}), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_c5(args, rank, world, local_rank, device, launched):
+    """Config C5 of BASELINE.json: synthetic 10^6-atom Lennard-Jones (argon) box, cutoff 9 A, Langevin 85 K,
+    1 fs.  One GPU: the whole box on the single-domain engine.  N > 1: spatial domain decomposition, one brick
+    per rank, positions of the halo atoms exchanged over RCCL every step (torchmd_amd/domain.py); strong
+    scaling (the box is fixed)."""
+    import torch.distributed as dist
+
+    from torchmd_amd.builders import argon_forcefield, lj_box
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.replicas import ReplicaFanout
+    from torchmd_amd.systems import System
+
+    nside = args.nside if args.nside != 32 else 100
+    mol, pos, box = lj_box(nside, seed=0)
+    par = Parameters(argon_forcefield(mol), mol, ["lj"], precision=torch.float32)
+    natoms = mol.numAtoms
+    torch.manual_seed(1)
+    vel0 = maxwell_boltzmann(par.masses, 85.0, 1)
+    fan = ReplicaFanout(total_replicas=world, device=device)
+    extra = {}
+    if world == 1:
+        from torchmd_amd.forces import Forces
+
+        s = System(natoms, 1, torch.float32, device)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        s.set_velocities(vel0)
+        f = Forces(par, terms=["lj"], cutoff=CUTOFF, **({} if args.skin is None else {"skin": args.skin}))
+        f.compute(s.pos, s.box, s.forces)
+        integ = Integrator(s, f, TIMESTEP_FS, device, gamma=1.0, T=85.0)
+        integ.step(max(args.warmup, 1))
+        stride = timing_stride(args.steps)
+        f.enable_timing(s.pos, True, every=stride)
+        f.read_timing(s.pos, reset=True)
+        st0 = f.stats(s.pos)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ekin, epot, temp = integ.step(args.steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        pair_ms, pair_launches = f.read_timing(s.pos, reset=True)
+        st1 = f.stats(s.pos)
+        pcut = f.count_pairs(s.pos, s.box)[0]
+        alg_bytes = 4.0 * pcut + 28.0 * natoms
+        pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
+        achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
+        extra["roofline"] = {
+            "kernel": "list_pair_fast_f32_kernel (fp32, LJ)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_kernel_us": pair_avg_s * 1e6, "launches_timed": int(pair_launches),
+        }
+        extra["list"] = {"rebuilds_in_timed_region": int(st1["n_rebuilds"] - st0["n_rebuilds"]),
+                         "entries": int(st1["list_entries"]), "ncell": list(st1["ncell"]), "skin": st1["skin"]}
+        extra["temperature_K"] = [float(temp[0])]
+        f.close()
+    else:
+        from torchmd_amd.domain import DistTransport, DomainSet
+
+        A, B = par.get_AB()
+        ds = DomainSet(box, world, device, torch.float32, ["lj"], CUTOFF, A=A, B=B, skin=args.skin or 1.5,
+                       transport=DistTransport())
+        ds.scatter(pos, vel0[0].numpy(), par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
+        ds.compute_forces()
+        ds.step(max(args.warmup, 1), timestep_fs=TIMESTEP_FS, gamma_ps=1.0, T=85.0, seed=3)
+        m0 = ds.migrations
+        fan.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ds.step(args.steps, timestep_fs=TIMESTEP_FS, gamma_ps=1.0, T=85.0, seed=3)
+        torch.cuda.synchronize()
+        fan.barrier()
+        elapsed = fan.max_over_ranks(time.perf_counter() - t0)
+        d = next(iter(ds.domains.values()))
+        info = torch.tensor([d.nown, d.local_pos.shape[1] - d.nown], dtype=torch.float64, device=device)
+        allinfo = [torch.empty_like(info) for _ in range(world)]
+        dist.all_gather(allinfo, info)
+        extra["domains"] = {"grid": list(ds.grid.dims), "own_atoms": [int(x[0]) for x in allinfo],
+                            "halo_atoms": [int(x[1]) for x in allinfo], "migrations_in_timed_region": ds.migrations - m0}
+        pcut = None
+        for dom in ds.domains.values():
+            dom.forces_engine.close()
+    out = {
+        "metric": "ns/day, 1M-atom Lennard-Jones box, 9 A cutoff" + (", spatial domain decomposition" if world > 1 else ""),
+        "value": ns_per_day(args.steps, elapsed), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C5 synthetic argon box: {natoms} atoms, L={box[0]:.1f} A, cutoff 9 A, LJ only, "
+                   "Langevin 85 K gamma 1/ps, timestep 1 fs" + ("; one brick per GPU, halo exchange over RCCL" if world > 1 else ""),
+                   "natoms": natoms, "timestep_fs": TIMESTEP_FS},
+        "pairs_in_cutoff": pcut,
+        "pair_interactions_per_s": (pcut * args.steps / elapsed) if pcut else None,
+    }
+    out.update(extra)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if launched:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
@@ -164,6 +265,9 @@ def main():
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin in A (default: the library's)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --dry)")
     ap.add_argument("--dry", action="store_true", help="launcher/collective plumbing only, no GPU work (CPU test)")
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"],
+                    help="c3 (default, the headline): 98 304-atom TIP3P box, one replica per GPU; c5: 10^6-atom LJ box, "
+                    "spatial domain decomposition for --gpus > 1")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -189,6 +293,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=device)  # nccl = RCCL on ROCm
+    if args.config == "c5":
+        return run_c5(args, rank, world, local_rank, device, launched)
     fan = ReplicaFanout(total_replicas=world, device=device)
 
     dtype = torch.float32
