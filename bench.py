@@ -380,7 +380,7 @@ def main():
             "ncell": list(st2["ncell"]),
         },
         "roofline": {
-            "kernel": "list_pair_fast_f32_kernel<8> (packed fp32, LJ + reaction field)",
+            "kernel": "list_pair_fast_f32_kernel<8> (lean scalar fp32, LJ + reaction field)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

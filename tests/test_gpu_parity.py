@@ -428,17 +428,17 @@ def test_auto_falls_back_to_allpairs_in_small_boxes():
 @pytest.mark.parametrize(
     "terms,kw",
     [
-        (["lj"], dict(cutoff=9.0)),  # packed kernel, LJ only
-        (["electrostatics"], dict(cutoff=9.0)),  # packed kernel, plain Coulomb
-        (["electrostatics"], dict(cutoff=9.0, rfa=True)),  # packed kernel, reaction field only
-        (["lj", "electrostatics"], dict(cutoff=9.0)),  # packed kernel, LJ + plain Coulomb
+        (["lj"], dict(cutoff=9.0)),  # lean fp32 kernel, LJ only
+        (["electrostatics"], dict(cutoff=9.0)),  # lean fp32 kernel, plain Coulomb
+        (["electrostatics"], dict(cutoff=9.0, rfa=True)),  # lean fp32 kernel, reaction field only
+        (["lj", "electrostatics"], dict(cutoff=9.0)),  # lean fp32 kernel, LJ + plain Coulomb
         (["lj", "electrostatics"], dict(cutoff=9.0, rfa=True, switch_dist=7.5)),  # generic kernel (switch)
         (["repulsion"], dict(cutoff=9.0)),
         (["repulsioncg", "electrostatics"], dict(cutoff=8.0, rfa=True, solventDielectric=60.0)),
     ],
 )
 def test_celllist_term_variants_vs_oracle(prec, terms, kw):
-    """Every term combination on the cell-list path (packed fp32 kernel variants and the generic kernel)
+    """Every term combination on the cell-list path (lean fp32 kernel variants and the generic kernel)
     against the oracle on the 5 184-atom water box: forces, per-term energies, in-cutoff pair count."""
     from oracle import torchmd_oracle as orc
     from torchmd_amd.builders import tip3p_box, water_forcefield
@@ -455,7 +455,7 @@ def test_celllist_term_variants_vs_oracle(prec, terms, kw):
     f = Forces(par, terms=terms, algorithm="celllist", **kw)
     pd, bd = p.to(dev), box_tensor(box, 1, dt, dev)
     F = torch.zeros_like(pd)
-    f.compute(pd, bd, F)  # forces-only path first (this is what the packed kernel serves) ...
+    f.compute(pd, bd, F)  # forces-only path first (this is what the lean fp32 kernel serves) ...
     F_noenergy = torch.zeros_like(pd)
     f._evaluate(pd, bd, F_noenergy, False, True)
     pots = f.compute(pd, bd, F, returnDetails=True)  # ... then with energies (generic kernel)
@@ -472,7 +472,7 @@ def test_celllist_term_variants_vs_oracle(prec, terms, kw):
 @pytest.mark.parametrize("lpa", [1, 2, 4, 16, 32, 64])
 def test_every_lanes_per_atom_variant(lpa, monkeypatch):
     """The list layout / pair kernels are templated on LPA (lanes per atom); the heuristic picks 4-64
-    depending on N.  Force every instantiation on the same box (fp32 packed kernel and fp64 generic)."""
+    depending on N.  Force every instantiation on the same box (lean fp32 kernel and fp64 generic)."""
     from oracle import torchmd_oracle as orc
     from torchmd_amd.builders import tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
@@ -542,8 +542,50 @@ def test_box_change_and_capacity_growth():
     assert ((F - Fr).abs() / (1 + Fr.abs())).max().item() < 1e-9
 
 
-def test_thrombin_fp32_open_boundaries_packed_kernel():
-    """fp32 packed kernel on a non-periodic system with 15 atom types (LDS table, clamp-to-grid cells)."""
+@pytest.mark.parametrize("ntypes", [24, 32, 40])
+def test_many_lj_classes_on_the_list_path(ntypes):
+    """The lean fp32 list kernel keeps the LJ class of atom j in 5 bits of the list entry (<= 32 classes, LDS
+    table rows of 32 x 8 B); more classes leave the field empty and the generic kernel reads the type array.
+    Water box with the atoms re-labelled into `ntypes` artificial classes (random sigma/epsilon), LJ +
+    reaction field, vs the oracle: forces, energies and the in-cutoff pair count."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(10, seed=2)  # 3 000 atoms
+    terms = ["lj", "electrostatics"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    rng = np.random.default_rng(ntypes)
+    types = rng.integers(0, ntypes, size=mol.numAtoms)
+    types[:ntypes] = np.arange(ntypes)  # every class occurs
+    par.mapped_atom_types = torch.tensor(types, dtype=torch.int64)
+    sig = rng.uniform(0.6, 1.7, size=ntypes)  # small: the re-labelled hydrogens sit 1.5-2 A from other molecules
+    eps = rng.uniform(0.02, 0.2, size=ntypes)
+    par.nonbonded_params = {"idx": [], "map": torch.tensor(np.stack([np.arange(mol.numAtoms), types], axis=1)),
+                            "params": torch.tensor(np.stack([sig, eps], axis=1), dtype=par.nonbonded_params["params"].dtype)}
+    kw = dict(cutoff=9.0, rfa=True)
+    p32 = pos_tensor(pos, 1, dt)
+    pairs = orc.candidate_pairs(pos, box, 9.6, orc.exclusion_pairs(par))
+    po, Fo, npairs = orc.compute(par, p32, box_tensor(box, 1, dt), terms, pairs=pairs, **kw)
+    f = Forces(par, terms=terms, algorithm="celllist", **kw)
+    p, b = p32.to(dev), box_tensor(box, 1, dt, dev)
+    F = torch.zeros_like(p)
+    f._evaluate(p, b, F, False, True)  # forces only: the hot variant
+    # the artificial classes put hydrogens with sizeable radii next to other molecules: forces reach 1e3-1e4,
+    # so the fp32 comparison is relative to |F|
+    scale = 1.0 + Fo.abs()
+    assert ((F.cpu() - Fo).abs() / scale).max().item() < 2.5e-4
+    pots = f.compute(p, b, F, returnDetails=True)
+    assert ((F.cpu() - Fo).abs() / scale).max().item() < 2.5e-4
+    for t in terms:
+        assert abs(pots[0][t] - po[0][t]) <= ERTOL["f32"] * EFAC * max(1, abs(po[0][t])), t
+    assert f.count_pairs(p, b) == npairs
+
+
+def test_thrombin_fp32_open_boundaries_lean_kernel():
+    """lean fp32 kernel on a non-periodic system with 15 atom types (LDS table, clamp-to-grid cells)."""
     g = load("thrombin")
     par = GoldenParameters(g, torch.float32)
     zero = np.zeros(3)
@@ -552,7 +594,7 @@ def test_thrombin_fp32_open_boundaries_packed_kernel():
     _, F_c, fc, p, b = _run(par, g["pos"], zero, terms, prec="f32", algorithm="celllist", **kw)
     _, F_a, fa, _, _ = _run(par, g["pos"], zero, terms, prec="f32", algorithm="allpairs", **kw)
     Fn = torch.zeros_like(p)
-    fc._evaluate(p, b, Fn, False, True)  # forces only -> packed kernel
+    fc._evaluate(p, b, Fn, False, True)  # forces only -> lean fp32 kernel
     assert np.abs(F_c - F_a).max() < 2e-3 and np.abs(Fn.cpu().numpy() - F_a).max() < 2e-3
     assert fc.count_pairs(p, b) == fa.count_pairs(p, b)
 
@@ -596,8 +638,8 @@ def test_replica_batch_matches_single_replica_calls(which):
 
 
 @pytest.mark.parametrize("mode", ["reference", "exact"])
-def test_packed_kernel_switching_variants(mode):
-    """LJ switching in the packed fp32 list kernel (both force flavours, with and without energies)
+def test_lean_kernel_switching_variants(mode):
+    """LJ switching in the lean fp32 list kernel (both force flavours, with and without energies)
     against the generic fp64 list kernel on the 5 184-atom water box.  LJ only: the switched LJ force
     vanishes at the cutoff, so the handful of pairs whose cutoff decision differs between fp32 and fp64
     coordinates does not matter (with the reaction field each such pair is a 0.05 kcal/mol/A jump); the

@@ -364,11 +364,12 @@ __global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const int
   sorted[a].z = pos[3 * i + 2];
 }
 
-// list entry = type_j << 28 | j << 4 (j = cell-sorted slot, 24 bits): `entry & kEntryOffMask` is the byte offset
-// of atom j's float4 record, `entry >> 24` the byte offset of type j in a 16-byte-stride LDS table row (for
+// list entry = type_j << 27 | j << 4 (j = cell-sorted slot, 23 bits): `entry & kEntryOffMask` is the byte offset
+// of atom j's float4 record, `entry >> 24` the byte offset of type j in an 8-byte-stride LDS table row (for
 // n <= 2^20).  Contexts with more than kEntryTypes LJ classes leave the type field 0 (kernels read stype[j]).
-constexpr unsigned kEntryOffMask = 0x0FFFFFF0u;  // byte offset of atom j's float4 record
-constexpr int kEntryTypes = 16;                  // LJ classes that fit the entry's type field
+constexpr unsigned kEntryOffMask = 0x07FFFFF0u;  // byte offset of atom j's float4 record
+constexpr int kEntryTypes = 32;                  // LJ classes that fit the entry's type field
+constexpr int kEntryTypeShift = 27;
 constexpr float kR2Floor = 1.0e-2f;  // (0.1 A)^2: keeps 1/r^14 finite for the self entries that pad a column
 
 struct ListGeom {
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       const int j = nx_j, code = nx_code;
       const bool valid = nx_valid;
       const unsigned oj = (unsigned)nx_order;
-      const unsigned entry = ((unsigned)j << 4) | (type_in_entry ? (unsigned)nx_type << 28 : 0u);
+      const unsigned entry = ((unsigned)j << 4) | (type_in_entry ? (unsigned)nx_type << kEntryTypeShift : 0u);
       if (q0 + 64 < ncand) fetch(q0 + 64);
       // candidate position as the periodic image that lies next to this cell: the i loop then needs
       // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
@@ -701,9 +702,9 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       valid[u] = (kk0 + u) * LPA + sub < nn;
-      jdx[u] = valid[u] ? (int)((entry[u] >> 4) & 0xFFFFFFu) : aself;
+      jdx[u] = valid[u] ? (int)((entry[u] & kEntryOffMask) >> 4) : aself;
       pj[u] = sorted[jdx[u]];
-      tj[u] = !valid[u] ? 0 : (ntypes <= kEntryTypes ? (int)(entry[u] >> 28) : stype[jdx[u]]);
+      tj[u] = !valid[u] ? 0 : (ntypes <= kEntryTypes ? (int)(entry[u] >> kEntryTypeShift) : stype[jdx[u]]);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -772,8 +773,8 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
 // (transposes of {pj[u].x, pj[u+1].x} into register pairs) per 4 entries = ~155 cycles per entry.  This
 // version is plain scalar code on the natural float4 record: ~32 full-rate ops + 1 v_cmp + 1 v_rsq per
 // entry (~85 cycles), no transposes, no shifts:
-//   entry = type << 28 | j << 4      -> gather offset = entry & 0x0FFFFFF0 (one v_and), LDS table address
-//                                       = (type_i << 8) | entry >> 24 (one SDWA v_or; table rows of 16 x 16 B)
+//   entry = type << 27 | j << 4      -> gather offset = entry & 0x07FFFFF0 (one v_and), LDS table address
+//                                       = (type_i << 8) | entry >> 24 (one SDWA v_or; table rows of 32 x 8 B)
 //   minimum image by the magic-number trick (3 ops per component, bit-exact, see min_image_magic)
 //   force scale factored as  rinv2 * ((a12 rinv6 + b6) rinv6 - qq rinv) + qq 2 krf   (9 ops)
 // Same decision arithmetic (bit-exact) as pair_math.h.  Terms: LJ and/or electrostatics (plain Coulomb or
@@ -804,12 +805,12 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     double *__restrict__ energies) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
-  __shared__ __align__(16) float4 stab[kEntryTypes * kEntryTypes];  // row of type i: 16 x {-12 A, 6 B, A, B}
+  __shared__ __align__(16) float2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
   for (int t = threadIdx.x; t < kEntryTypes * kEntryTypes; t += blockDim.x) {
-    const int ti = t >> 4, tj = t & 15;
+    const int ti = t >> 5, tj = t & 31;
     float2 ab = make_float2(0.f, 0.f);
     if (ti < ntypes && tj < ntypes) ab = tab[ti * ntypes + tj];
-    stab[t] = make_float4(-12.0f * ab.x, 6.0f * ab.y, ab.x, ab.y);
+    stab[t] = make_float2(-12.0f * ab.x, 6.0f * ab.y);
   }
   __syncthreads();
 
@@ -871,14 +872,16 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     const float rinv2 = rinv * rinv;
     const float rinv6 = rinv2 * rinv2 * rinv2;
     float fs;  // (dE/dr) / r; rejected entries may produce inf/NaN here, the select below discards them
-    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (LJ) ab = *reinterpret_cast<const float4 *>(tbase + (trow | tofs));
+    float2 ab = make_float2(0.f, 0.f);  // (-12 A, 6 B)
+    if (LJ) ab = *reinterpret_cast<const float2 *>(tbase + (trow | tofs));
+    // E_lj = (A r^-6 - B) r^-6 from the force coefficients (energy / switching variants only)
+    auto elj_of = [&](float r6) { return __builtin_fmaf(ab.x * (-1.0f / 12.0f), r6, ab.y * (-1.0f / 6.0f)) * r6; };
     if (LJ && !SWITCH && ELEC) {
       const float qq = pi.w * pjw;
       const float p = __builtin_fmaf(ab.x, rinv6, ab.y) * rinv6;  // (a12 rinv6 + b6) rinv6
       const float g = __builtin_fmaf(-qq, rinv, p);
       fs = __builtin_fmaf(rinv2, g, qi2k * pjw);
-      if (ENERGY) e_lj += hit ? (__builtin_fmaf(ab.z, rinv6, -ab.w) * rinv6) : 0.f;
+      if (ENERGY) e_lj += hit ? elj_of(rinv6) : 0.f;
     } else {
       fs = 0.f;
       float sw = 1.f;  // switching function S(r) of the LJ term (forces.py:402-412), 1 below switch_dist
@@ -894,11 +897,11 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
           const float pp = __builtin_fmaf(t, __builtin_fmaf(t, -6.f, 15.f), -10.f);
           sw = __builtin_fmaf(t2 * t, pp, 1.f);
           const float dq = __builtin_fmaf(t, __builtin_fmaf(t, -30.f * sw_ir, 60.f * sw_ir), -30.f * sw_ir);
-          const float elj = __builtin_fmaf(ab.z, rinv6, -ab.w) * rinv6;
+          const float elj = elj_of(rinv6);
           const float x = c.switch_reference_mode ? rinv2 : rinv;
           fs = __builtin_fmaf(sw, fs, elj * (t2 * dq) * x);
         }
-        if (ENERGY) e_lj += hit ? sw * (__builtin_fmaf(ab.z, rinv6, -ab.w) * rinv6) : 0.f;
+        if (ENERGY) e_lj += hit ? sw * elj_of(rinv6) : 0.f;
       }
       if (ELEC) fs += (pi.w * pjw) * (two_krf - rinv2 * rinv);
     }
@@ -933,7 +936,7 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) body((entry[u] >> 24) & 0xF0u, raw[u], kk0 + u < myiters);  // padding words are garbage
+    for (int u = 0; u < UNROLL; ++u) body((entry[u] >> 24) & 0xF8u, raw[u], kk0 + u < myiters);  // padding words are garbage
   }
   float sx = fx, sy = fy, sz = fz;
 #pragma unroll
@@ -1472,7 +1475,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
   const bool fast = only_lj_el;  // (switching, if any, acts on the LJ term and is a kernel variant)
   if constexpr (std::is_same<R, float>::value) {
-    // lean fp32 kernel: the entry's type field holds 16 LJ classes; the unmasked table offset needs j < 2^20
+    // lean fp32 kernel: the entry's type field holds 32 LJ classes; the unmasked table offset needs j < 2^20
     if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= kEntryTypes && n <= (1 << 20)) {
       const size_t shfast = 0;
       const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
