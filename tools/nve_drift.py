@@ -19,11 +19,11 @@ Integrator(system, forces, 0.5, dev, gamma=1.0, T=300.0).step(2000)
 nve = Integrator(system, forces, 0.5, dev)
 e = []
 r0 = forces.stats(system.pos)["n_rebuilds"]
-for _ in range(20):
+for _ in range(int(os.environ.get("NVE_BLOCKS", "20"))):
     ek, ep, T = nve.step(200)
     e.append((ek[0] + ep[0], T[0]))
 e = np.array(e)
 n = mol.numAtoms
-print(f"NVE 4000 steps x 0.5 fs, N={n}: Etot/N first {e[0,0]/n:.5f} last {e[-1,0]/n:.5f} kcal/mol, "
-      f"drift {(e[-1,0]-e[0,0])/n/2.0:.2e} kcal/mol/atom/ps, rms fluct {e[:,0].std()/n:.2e}, T {e[0,1]:.1f} -> {e[-1,1]:.1f} K, "
+print(f"NVE {len(e)*200} steps x 0.5 fs, N={n}: Etot/N first {e[0,0]/n:.5f} last {e[-1,0]/n:.5f} kcal/mol, "
+      f"drift {(e[-1,0]-e[0,0])/n/(len(e)*0.1):.2e} kcal/mol/atom/ps, rms fluct {e[:,0].std()/n:.2e}, T {e[0,1]:.1f} -> {e[-1,1]:.1f} K, "
       f"rebuilds {forces.stats(system.pos)['n_rebuilds'] - r0}")

@@ -17,7 +17,11 @@
 //                entry k of the a-th atom of group g belongs to lane l = a*LPA + k%LPA, iteration kk = k/LPA,
 //                and lives at  g*maxn*APW + ((kk/4)*64 + l)*4 + kk%4 : a lane's entries of four consecutive
 //                iterations are one 16-byte word, so one wave-wide dwordx4 load reads 1 KB of contiguous list.
-//                entry = type_j << 28 | j << 4 (j = sorted slot)
+//                (Consecutive entries in ADJACENT LANES matter: candidates arrive in cell-sorted order, so the
+//                lanes of an atom gather runs of consecutive records, which the texture path serves faster —
+//                tools/ubench/gather_rate.hip.  Giving each lane four consecutive entries instead would make
+//                the build's store address three instructions but costs the pair kernel 46 -> 52 us.)
+//                entry = type_j << 27 | j << 4 (j = sorted slot)
 //   nneigh       int32[N]
 #include <hip/hip_runtime.h>
 
