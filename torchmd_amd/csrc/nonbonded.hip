@@ -2343,6 +2343,14 @@ int tmdhip_timing_enable(tmdhip_ctx *ctx, int on) {
   ctx->timing = on != 0;
   ctx->timing_stride = on > 1 ? on : 1;
   ctx->timing_seen = 0;
+  // the events of the first launches are created here, not inside the region being timed (a hipEventCreate
+  // costs ~10 us of host time: twenty of them in a 20-step run made the loop enqueue-bound)
+  while (ctx->timing && ctx->events.size() < 192) {
+    hipEvent_t a, b;
+    TMD_HIP(hipEventCreate(&a));
+    TMD_HIP(hipEventCreate(&b));
+    ctx->events.emplace_back(a, b);
+  }
   return 0;
 }
 
