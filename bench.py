@@ -157,7 +157,7 @@ def run_c5(args, rank, world, local_rank, device, launched):
         from torchmd_amd.domain import DistTransport, DomainSet
 
         A, B = par.get_AB()
-        ds = DomainSet(box, world, device, torch.float32, ["lj"], CUTOFF, A=A, B=B, skin=args.skin or 1.5,
+        ds = DomainSet(box, world, device, torch.float32, ["lj"], CUTOFF, A=A, B=B, skin=args.skin or 2.5,
                        transport=DistTransport())
         ds.scatter(pos, vel0[0].numpy(), par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
         ds.compute_forces()

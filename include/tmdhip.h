@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TMDHIP_ABI_VERSION 2
+#define TMDHIP_ABI_VERSION 3
 
 /* dtype */
 #define TMDHIP_F32 0
@@ -249,6 +249,81 @@ int tmdhip_wrap(int dtype, int64_t nreplicas, int64_t natoms, void *pos_dev, con
                 void *stream);
 /* Fill `out_dev` (real [n]) with the N(0,1) stream used by tmdhip_langevin_second_vv (for tests). */
 int tmdhip_normal_fill(int dtype, int64_t n, void *out_dev, uint64_t seed, uint64_t step, void *stream);
+
+
+/* ---- spatial domain decomposition (no reference counterpart: torchmd is single-device) ----
+ * One brick = one rank.  pos_dev is the position buffer of the brick's force engine, real [nown + nhalo, 3]:
+ * the owned atoms first (integrated in place), then the halo rows the exchange writes.
+ *
+ * tmdhip_dd_step: on the owned atoms, phases bit 0 = second half kick of the previous step (preceded by the
+ * Langevin update when vcoeff_dev != NULL; integrator.py:72-74, 67-69), bit 1 = first half step of this step
+ * (integrator.py:61-64); same expressions and rounding as the separate kernels above.  With ref_dev (positions
+ * at the last migration, real [nown, 3]) and disp2_dev, phase bit 1 also folds max_i |pos_i - ref_i|^2 into
+ * *disp2_dev (float bits, atomic max; the caller zeroes it at a migration). */
+int tmdhip_dd_step(int dtype, int64_t nown, void *pos_dev, void *vel_dev, const void *forces_dev,
+                   const void *mass_dev, const void *vcoeff_dev, double dt, double gamma, uint64_t seed,
+                   uint64_t step, int phases, const void *ref_dev, uint32_t *disp2_dev, void *stream);
+/* out_dev[k, :] = pos_dev[index_dev[k], :] + shift_dev[k, :] for the `count` rows of all outgoing halo
+ * messages (message order; shift = the periodic image the receiver sees). */
+int tmdhip_halo_pack(int dtype, int64_t count, const void *pos_dev, const int32_t *index_dev,
+                     const void *shift_dev, void *out_dev, void *stream);
+
+/* Halo-exchange communicator: RCCL point-to-point among the `world` ranks of the brick grid (one process and
+ * one GPU per rank).  librccl is opened at run time from `librccl_path` (NULL/"" = default search; pass the copy
+ * the process has already mapped, e.g. PyTorch's torch/lib/librccl.so).  Rank 0 draws the id, the caller
+ * distributes its TMDHIP_COMM_ID_BYTES bytes to the other ranks by any means (torch.distributed broadcast),
+ * every rank then calls tmdhip_comm_create with its HIP device current. */
+#define TMDHIP_COMM_ID_BYTES 128
+typedef struct tmdhip_comm tmdhip_comm;
+int tmdhip_comm_unique_id(const char *librccl_path, void *id_out);
+int tmdhip_comm_create(tmdhip_comm **out, const char *librccl_path, const void *id, int rank, int world);
+void tmdhip_comm_destroy(tmdhip_comm *comm);
+/* One grouped exchange on `stream`: rows of `width` reals; the first send_counts_host[0] rows of send_dev go to
+ * rank 0, the next send_counts_host[1] to rank 1, ...; recv_dev receives recv_counts_host[p] rows from rank p
+ * in rank order (the layout of an all-to-all with split sizes, as ncclSend/ncclRecv pairs between the
+ * ranks that actually exchange rows — messages to oneself across the periodic boundary included). */
+int tmdhip_comm_exchange(tmdhip_comm *comm, int dtype, const void *send_dev, const int64_t *send_counts_host,
+                         void *recv_dev, const int64_t *recv_counts_host, int width, void *stream);
+
+/* The step loop of one brick enqueued from C (velocity Verlet + optional Langevin over the decomposed system):
+ *   per iteration: tmdhip_dd_step (kick of the previous iteration + drift of this one) -> tmdhip_halo_pack ->
+ *   tmdhip_comm_exchange into the halo rows of pos_dev -> nonbonded forces on the owned atoms (ctx: open
+ *   boundaries, atoms >= nown passive, see tmdhip_update_atoms);  after the last iteration the owed kick.
+ * Every `check_every` iterations the maximum squared displacement since the last migration is max-reduced over
+ * the ranks and copied to the host asynchronously; it is examined one check later, so the loop never waits for
+ * the device.  When the projected displacement exceeds skin/2 the call returns 1 with *iters_done = the number
+ * of complete iterations: the next one has drifted but has neither halo nor forces yet — the caller migrates
+ * atoms, evaluates the forces, counts that iteration as done and calls again with first_phases = 3 (a kick is
+ * owed; niter may then be 0).  Returns 0 when all niter iterations are done, negative on error. */
+typedef struct tmdhip_dd_desc {
+  int32_t struct_size;
+  int32_t dtype;
+  int32_t niter;
+  int32_t first_phases;      /* 2: velocities complete on entry; 3: the second half kick of the last step is owed */
+  int32_t check_every;       /* iterations between displacement checks                                        */
+  int32_t reserved;
+  int64_t nown, nhalo;
+  void *pos_dev;             /* real [nown + nhalo, 3]                                                        */
+  void *vel_dev;             /* real [nown, 3]                                                                */
+  void *forces_dev;          /* real [nown + nhalo, 3] (halo rows stay zero)                                  */
+  const void *mass_dev;      /* real [nown]                                                                   */
+  const void *vcoeff_dev;    /* real [nown] or NULL: no thermostat                                            */
+  const void *ref_dev;       /* real [nown, 3]: positions at the last migration                               */
+  uint32_t *disp2_dev;       /* running maximum of |pos - ref|^2 (float bits); zero at a migration            */
+  double dt, gamma;
+  uint64_t seed, step0;      /* noise stream key; iteration i kicks with counter step0 + i                    */
+  int64_t nsend;             /* rows of all outgoing messages                                                 */
+  const int32_t *send_index_dev;
+  const void *send_shift_dev; /* real [nsend, 3]                                                              */
+  void *send_buf_dev;        /* real [nsend, 3]                                                               */
+  const int64_t *send_counts_host, *recv_counts_host; /* [world] rows per peer; sum(recv) = nhalo             */
+  double skin;               /* halo skin: migration when the projected displacement exceeds skin / 2         */
+  int64_t since_migration;   /* iterations started since the last migration, on entry                         */
+} tmdhip_dd_desc;
+int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *comm, const tmdhip_dd_desc *desc, int32_t *iters_done,
+                  void *stream);
+/* Forget the pending displacement read-back (call after every migration). */
+int tmdhip_dd_reset(tmdhip_comm *comm);
 
 #ifdef __cplusplus
 }

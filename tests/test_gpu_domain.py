@@ -84,3 +84,73 @@ def test_trajectory_equal_single_domain():
     assert (P - s.pos[0]).abs().max().item() < 1e-7
     assert (V - s.vel[0]).abs().max().item() < 1e-7
     assert (F - s.forces[0]).abs().max().item() < 1e-6
+
+
+@pytest.mark.timeout(300)
+def test_native_exchange_and_step_loop_single_rank():
+    """The C-driven path (`tmdhip_dd_run`: fused kick/drift kernel, device-side halo pack, grouped RCCL
+    send/recv into the halo rows, forces — all enqueued from C) on a 1-rank RCCL communicator, where the brick
+    exchanges its periodic images with itself: (i) `tmdhip_comm_exchange` reproduces the torch all-to-all,
+    (ii) a 40-step NVE trajectory with migrations equals the single-domain integrator, (iii) and equals the
+    Python-driven loop over torch.distributed bit for bit."""
+    import os
+
+    import torch.distributed as dist
+
+    from torchmd_amd import _lib as L
+    from torchmd_amd.domain import DistTransport, DomainSet
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.systems import System
+
+    dev, dt = torch.device("cuda:0"), torch.float64
+    mol, pos, box, par = _system(22, dt)
+    n = mol.numAtoms
+    torch.manual_seed(3)
+    vel = maxwell_boltzmann(par.masses, 4000.0, 1)[0].numpy()
+    A, B = par.get_AB()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=dev)
+    try:
+        results = {}
+        for native in ("1", "0"):
+            os.environ["TMDHIP_DD_NATIVE"] = native
+            tr = DistTransport()
+            ds = DomainSet(box, 1, dev, dt, ["lj"], 9.0, A=A, B=B, skin=1.0, transport=tr)
+            ds.scatter(pos, vel, par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
+            assert (tr.native() is not None) == (native == "1")
+            d = ds.domains[0]
+            if native == "1":  # (i) one grouped exchange against torch's all_to_all_single
+                import ctypes as C
+
+                sent = d.pack_halo().clone()
+                want = tr.all_to_all(sent, d.plan.send_counts, ds._recv_counts["halo"])
+                got = torch.zeros_like(want)
+                sc = (C.c_int64 * 1)(*d.plan.send_counts)
+                rc = (C.c_int64 * 1)(*ds._recv_counts["halo"])
+                L.check(L.load().tmdhip_comm_exchange(tr.native(), L.dtype_code(dt), sent.data_ptr(), sc, got.data_ptr(), rc, 3,
+                                                      torch.cuda.current_stream(dev).cuda_stream))
+                torch.cuda.synchronize()
+                assert got.shape[0] > 0 and torch.equal(got, want)
+            ds.compute_forces()
+            ds.step(25, timestep_fs=2.0)
+            ds.step(15, timestep_fs=2.0)
+            results[native] = ds.gather(n) + (ds.migrations,)
+            d.forces_engine.close()
+            tr.close()
+    finally:
+        os.environ.pop("TMDHIP_DD_NATIVE", None)
+        dist.destroy_process_group()
+    P, V, F, mig = results["1"]
+    assert mig >= 1
+    s = System(n, 1, dt, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    s.set_velocities(torch.tensor(vel)[None])
+    f = Forces(par, terms=["lj"], cutoff=9.0)
+    f.compute(s.pos, s.box, s.forces)
+    Integrator(s, f, 2.0, dev).step(40)
+    assert (P - s.pos[0]).abs().max().item() < 1e-7
+    assert (V - s.vel[0]).abs().max().item() < 1e-7
+    assert (F - s.forces[0]).abs().max().item() < 1e-6
+    P0, V0, F0, mig0 = results["0"]
+    assert mig0 == mig and torch.equal(P, P0) and torch.equal(V, V0) and torch.equal(F, F0)

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--nside", type=int, default=100)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--skin", type=float, default=1.5)
+    ap.add_argument("--skin", type=float, default=2.5, help="halo skin in A (migration when an atom has moved skin/2)")
     args = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
@@ -50,6 +50,19 @@ def main():
     torch.cuda.synchronize()
     dist.barrier(device_ids=[local])
     m0 = ds.migrations
+    mig_t = [0.0]
+    plain_migrate = ds.migrate
+
+    def timed_migrate():  # wall time of a migration incl. everything still queued in front of it
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        plain_migrate()
+        ds.compute_forces()
+        torch.cuda.synchronize()
+        mig_t[0] += time.perf_counter() - t
+
+    if os.environ.get("DD_TIME_MIGRATIONS"):
+        ds.migrate = timed_migrate
     t0 = time.perf_counter()
     ds.step(args.steps, timestep_fs=1.0, gamma_ps=1.0, T=85.0, seed=3)
     torch.cuda.synchronize()
@@ -65,6 +78,7 @@ def main():
             "n_gpus": world, "us_per_step": el / args.steps * 1e6, "ns_per_day": args.steps / el * 1e-6 * 86400,
             "own_atoms": [int(x[0]) for x in allinfo], "halo_atoms": [int(x[1]) for x in allinfo],
             "migrations_in_timed_region": ds.migrations - m0, "steps": args.steps,
+            "migration_ms_total": mig_t[0] * 1e3,
         }), flush=True)
     for dom in ds.domains.values():
         dom.forces_engine.close()

@@ -47,26 +47,34 @@ def timed(name, fn):
 
 N = 100
 st = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
+counts = d.plan.send_counts
+
+
+def dd_step(phases):
+    L.check(lib.tmdhip_dd_step(code, d.nown, d.pos.data_ptr(), d.vel.data_ptr(), d.forces.data_ptr(), d.masses.data_ptr(),
+                               0, dt, 0.0, 0, 0, phases, d.ref.data_ptr(), d.disp2.data_ptr(), st()))
+
+
 for it in range(N):
-    timed("first_vv", lambda: L.check(lib.tmdhip_first_vv(code, 1, d.nown, d.pos.data_ptr(), d.vel.data_ptr(),
-                                                          d.forces.contiguous().data_ptr(), d.masses.data_ptr(), dt, st())))
+    timed("dd_step (kick+drift+disp)", lambda: dd_step(3))
     due = timed("migration_check", ds._migration_due)
     if due:
         timed("migrate", ds.migrate)
+        counts = d.plan.send_counts
     else:
-        payload = timed("pack", lambda: d.halo_payload(False))
-        got = timed("all_to_all", lambda: ds._all_to_all("halo", {0: payload}, {0: d.plan.send_counts}))
-        timed("unpack", lambda: d.set_halo(got[0], False))
+        timed("pack", d.pack_halo)
+        timed("all_to_all (in place)", lambda: ds.transport.all_to_all_into(d.halo_rows, d.send_buf, counts,
+                                                                           ds._recv_counts["halo"]))
     timed("compute", ds.compute_forces)
-    timed("second_vv", lambda: L.check(lib.tmdhip_second_vv(code, 1, d.nown, d.vel.data_ptr(),
-                                                            d.forces.contiguous().data_ptr(), d.masses.data_ptr(), dt, st())))
 print(f"own {d.nown} halo {d.local_pos.shape[1] - d.nown} migrations {ds.migrations}")
 for k, v in acc.items():
-    print(f"{k:16s} {v / N * 1e6:9.1f} us/step")
+    print(f"{k:28s} {v / N * 1e6:9.1f} us/step")
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 ds.step(N, timestep_fs=1.0)
+t1 = time.perf_counter()
 torch.cuda.synchronize()
-print(f"unsynchronised loop: {(time.perf_counter() - t0) / N * 1e6:.1f} us/step")
+print(f"unsynchronised loop: {(time.perf_counter() - t0) / N * 1e6:.1f} us/step (host side of it: {(t1 - t0) / N * 1e6:.1f} us/step)")
 if len(sys.argv) > 2:  # profile of one forced migration
     import cProfile
     import pstats

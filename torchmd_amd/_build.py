@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libtmdhip.so")
-SOURCES = ["nonbonded.hip", "bonded.hip", "integrator.hip"]
+SOURCES = ["nonbonded.hip", "bonded.hip", "integrator.hip", "domain.hip"]
 HEADERS = ["common.h", "pair_math.h", "rng.h", "bonded_math.h", os.path.join("..", "..", "include", "tmdhip.h")]
 ARCH = "gfx950"
 FLAGS = ["-fno-slp-vectorize"]  # the SLP vectoriser packs the pair kernel into v_pk_* ops + v_mov transposes: measured slower

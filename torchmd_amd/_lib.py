@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # TMDHIP_LIB: developer knob for A/B runs of differently built libraries (kernel experiments)
 LIBPATH = os.environ.get("TMDHIP_LIB") or os.path.join(PKG, "lib", "libtmdhip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, F64 = 0, 1
 TERM_LJ, TERM_ELECTROSTATICS, TERM_REPULSION, TERM_REPULSIONCG = 1, 2, 4, 8
 E_LJ, E_ELECTROSTATICS, E_REPULSION, E_REPULSIONCG, E_BONDS, E_ANGLES, E_DIHEDRALS, E_IMPROPERS = range(8)
@@ -111,6 +111,41 @@ class MdDesc(C.Structure):
     ]
 
 
+class DdDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("dtype", C.c_int32),
+        ("niter", C.c_int32),
+        ("first_phases", C.c_int32),
+        ("check_every", C.c_int32),
+        ("reserved", C.c_int32),
+        ("nown", C.c_int64),
+        ("nhalo", C.c_int64),
+        ("pos_dev", C.c_void_p),
+        ("vel_dev", C.c_void_p),
+        ("forces_dev", C.c_void_p),
+        ("mass_dev", C.c_void_p),
+        ("vcoeff_dev", C.c_void_p),
+        ("ref_dev", C.c_void_p),
+        ("disp2_dev", C.c_void_p),
+        ("dt", C.c_double),
+        ("gamma", C.c_double),
+        ("seed", C.c_uint64),
+        ("step0", C.c_uint64),
+        ("nsend", C.c_int64),
+        ("send_index_dev", C.c_void_p),
+        ("send_shift_dev", C.c_void_p),
+        ("send_buf_dev", C.c_void_p),
+        ("send_counts_host", C.c_void_p),
+        ("recv_counts_host", C.c_void_p),
+        ("skin", C.c_double),
+        ("since_migration", C.c_int64),
+    ]
+
+
+COMM_ID_BYTES = 128
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("n_compute", C.c_int64),
@@ -184,6 +219,21 @@ SIGNATURES = {
         [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
     ),
     "tmdhip_normal_fill": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "tmdhip_dd_step": (
+        C.c_int,
+        [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+         C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "tmdhip_halo_pack": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tmdhip_comm_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "tmdhip_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
+    "tmdhip_comm_destroy": (None, [C.c_void_p]),
+    "tmdhip_comm_exchange": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    ),
+    "tmdhip_dd_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(DdDesc), C.POINTER(C.c_int32), C.c_void_p]),
+    "tmdhip_dd_reset": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,341 @@
+// Spatial domain decomposition support for gfx950: the per-step kernels of one brick.
+//
+// The reference has no counterpart (single process, single device).  A brick
+// integrates the atoms it owns in place inside the position buffer of its force engine ([own | halo] rows)
+// and sends the positions of the atoms that lie within `cutoff + skin` of a face to the neighbouring bricks,
+// already shifted to the periodic image the receiver sees (torchmd_amd/domain.py).  Per step this file
+// contributes two launches:
+//   dd_step_kernel    second half kick of step s-1 (+ Langevin) and first half step of step s on the owned
+//                     atoms (same expressions, same rounding as integrator.hip's separate kernels:
+//                     integrator.py:61-74), plus the running maximum of |x - x_ref|^2 that triggers the next
+//                     migration (wave maximum, then at most one atomic per wave);
+//   halo_pack_kernel  out[k] = pos[send_index[k]] + send_shift[k] for the rows of all outgoing messages, in
+//                     message order: the buffer the all-to-all sends.
+// The receiver needs no unpack kernel: the exchange writes straight into the halo rows of its engine's
+// position buffer.
+//
+// Exchange and step loop from C (tmdhip_comm_*, tmdhip_dd_run): RCCL point-to-point between the ranks of the
+// brick grid — a brick of a 2 x 2 x 2 grid has 7 distinct neighbour ranks, one per xGMI link — as ONE group of
+// ncclSend/ncclRecv per step, enqueued on the same stream as the kernels (no cross-stream events, no host
+// round trip).  librccl is opened at run time (the copy the process has already mapped: PyTorch's), so the
+// library carries no link-time dependency on it and loads without it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "pair_math.h"
+#include "rng.h"
+
+using namespace tmd;
+
+namespace {
+
+template <typename R, bool LANGEVIN>
+__global__ __launch_bounds__(256) void dd_step_kernel(int64_t nown, R *__restrict__ pos, R *__restrict__ vel,
+                                                      const R *__restrict__ f, const R *__restrict__ mass,
+                                                      const R *__restrict__ vcoeff, R dt, R half_dt, R gamma,
+                                                      uint64_t seed, uint64_t step, int phases,
+                                                      const R *__restrict__ ref, unsigned *__restrict__ disp2) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float d2 = 0.f;
+  if (i < nown) {
+    const R m = mass[i];
+    R g[3] = {0, 0, 0}, vc = 0;
+    if (LANGEVIN && (phases & 1)) {
+      vc = vcoeff[i];
+      normal3<R>(seed, step, (uint64_t)i, g[0], g[1], g[2]);
+    }
+    R dd = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const R a = f[3 * i + k] / m;
+      R v = vel[3 * i + k];
+      if (phases & 1) {  // integrator.py:72-74 (thermostat) then 67-69
+        if (LANGEVIN) v += -gamma * v * dt + g[k] * vc;
+        v += half_dt * a;
+      }
+      if (phases & 2) {  // integrator.py:61-64
+        const R p = pos[3 * i + k] + (v * dt + R(0.5) * a * dt * dt);
+        v = v + half_dt * a;
+        pos[3 * i + k] = p;
+        if (ref) {
+          const R d = p - ref[3 * i + k];
+          dd += d * d;
+        }
+      }
+      vel[3 * i + k] = v;
+    }
+    d2 = sizeof(R) == 4 ? (float)dd : __double2float_ru((double)dd);
+  }
+  if (disp2 && (phases & 2)) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o, 64));
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > *disp2) atomicMax(disp2, __float_as_uint(d2));
+  }
+}
+
+template <typename R>
+__global__ void halo_pack_kernel(int64_t n3, const R *__restrict__ pos, const int32_t *__restrict__ index,
+                                 const R *__restrict__ shift, R *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n3) return;
+  const int64_t row = t / 3;
+  const int k = (int)(t - 3 * row);
+  out[t] = pos[3 * (int64_t)index[row] + k] + shift[t];
+}
+
+inline dim3 blocks_for(int64_t n, int t) { return dim3((unsigned)((n + t - 1) / t)); }
+
+template <typename R>
+int launch_dd_step(int64_t nown, void *pos, void *vel, const void *forces, const void *mass, const void *vcoeff,
+                   double dt, double gamma, uint64_t seed, uint64_t step, int phases, const void *ref,
+                   uint32_t *disp2, hipStream_t st) {
+  if (vcoeff)
+    hipLaunchKernelGGL((dd_step_kernel<R, true>), blocks_for(nown, 256), dim3(256), 0, st, nown, (R *)pos, (R *)vel,
+                       (const R *)forces, (const R *)mass, (const R *)vcoeff, (R)dt, (R)(0.5 * dt), (R)gamma, seed,
+                       step, phases, (const R *)ref, disp2);
+  else
+    hipLaunchKernelGGL((dd_step_kernel<R, false>), blocks_for(nown, 256), dim3(256), 0, st, nown, (R *)pos, (R *)vel,
+                       (const R *)forces, (const R *)mass, (const R *)nullptr, (R)dt, (R)(0.5 * dt), (R)0, seed, step,
+                       phases, (const R *)ref, disp2);
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+struct RcclApi {
+  void *handle = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+};
+
+int load_rccl(const char *path, RcclApi &api) {
+  const char *names[] = {path, "librccl.so.1", "librccl.so"};
+  for (const char *nm : names) {
+    if (!nm || !*nm) continue;
+    api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (api.handle) break;
+  }
+  if (!api.handle) return fail(std::string("librccl could not be opened: ") + (dlerror() ? dlerror() : "?"));
+  bool ok = true;
+  auto sym = [&](const char *n) {
+    void *p = dlsym(api.handle, n);
+    ok = ok && p;
+    return p;
+  };
+  api.get_unique_id = (decltype(api.get_unique_id))sym("ncclGetUniqueId");
+  api.comm_init_rank = (decltype(api.comm_init_rank))sym("ncclCommInitRank");
+  api.comm_destroy = (decltype(api.comm_destroy))sym("ncclCommDestroy");
+  api.error_string = (decltype(api.error_string))sym("ncclGetErrorString");
+  api.group_start = (decltype(api.group_start))sym("ncclGroupStart");
+  api.group_end = (decltype(api.group_end))sym("ncclGroupEnd");
+  api.send = (decltype(api.send))sym("ncclSend");
+  api.recv = (decltype(api.recv))sym("ncclRecv");
+  api.all_reduce = (decltype(api.all_reduce))sym("ncclAllReduce");
+  if (!ok) return fail("librccl lacks a required symbol");
+  return 0;
+}
+
+}  // namespace
+
+// halo-exchange communicator of one rank + the state of the asynchronous migration trigger
+struct tmdhip_comm {
+  RcclApi api;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  // displacement read-back: two pinned slots / events used alternately; `pending` = slot `cur` holds the
+  // maximum squared displacement measured `at` steps after the last migration
+  float *host_flag = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int cur = 0;
+  bool pending = false;
+  int64_t at = 0;
+};
+
+#define TMD_NCCL(c, expr)                                                                                   \
+  do {                                                                                                      \
+    ncclResult_t _r = (expr);                                                                               \
+    if (_r != ncclSuccess) return ::tmd::fail(std::string(#expr) + ": " + (c)->api.error_string(_r));       \
+  } while (0)
+
+namespace {
+
+int exchange_rows(tmdhip_comm *c, int dtype, const void *send, const int64_t *send_counts, void *recv,
+                  const int64_t *recv_counts, int width, hipStream_t st) {
+  const ncclDataType_t dt = dtype == TMDHIP_F32 ? ncclFloat32 : ncclFloat64;
+  const size_t esz = dtype == TMDHIP_F32 ? 4 : 8;
+  TMD_NCCL(c, c->api.group_start());
+  size_t so = 0, ro = 0;
+  for (int p = 0; p < c->world; ++p) {
+    const size_t ns = (size_t)send_counts[p] * width, nr = (size_t)recv_counts[p] * width;
+    if (ns) TMD_NCCL(c, c->api.send((const char *)send + so * esz, ns, dt, p, c->comm, st));
+    if (nr) TMD_NCCL(c, c->api.recv((char *)recv + ro * esz, nr, dt, p, c->comm, st));
+    so += ns;
+    ro += nr;
+  }
+  TMD_NCCL(c, c->api.group_end());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tmdhip_comm_unique_id(const char *librccl_path, void *id_out) {
+  if (!id_out) return fail("tmdhip_comm_unique_id: null argument");
+  RcclApi api;
+  TMD_TRY(load_rccl(librccl_path, api));
+  ncclUniqueId id;
+  const ncclResult_t r = api.get_unique_id(&id);
+  if (r != ncclSuccess) return fail(std::string("ncclGetUniqueId: ") + api.error_string(r));
+  static_assert(sizeof(id) == TMDHIP_COMM_ID_BYTES, "unique id size");
+  std::memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+int tmdhip_comm_create(tmdhip_comm **out, const char *librccl_path, const void *id, int rank, int world) {
+  if (!out || !id) return fail("tmdhip_comm_create: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail("tmdhip_comm_create: bad rank / world size");
+  tmdhip_comm *c = new tmdhip_comm();
+  c->rank = rank;
+  c->world = world;
+  auto bail = [&](int rc) {
+    tmdhip_comm_destroy(c);
+    return rc;
+  };
+  if (load_rccl(librccl_path, c->api)) return bail(-1);
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  const ncclResult_t r = c->api.comm_init_rank(&c->comm, world, uid, rank);
+  if (r != ncclSuccess) return bail(fail(std::string("ncclCommInitRank: ") + c->api.error_string(r)));
+  if (hipHostMalloc((void **)&c->host_flag, 2 * sizeof(float), hipHostMallocDefault) != hipSuccess)
+    return bail(fail("tmdhip_comm_create: pinned allocation failed"));
+  for (auto &e : c->ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail("tmdhip_comm_create: event creation failed"));
+  *out = c;
+  return 0;
+}
+
+void tmdhip_comm_destroy(tmdhip_comm *c) {
+  if (!c) return;
+  if (c->comm && c->api.comm_destroy) c->api.comm_destroy(c->comm);
+  for (auto &e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->host_flag) (void)hipHostFree(c->host_flag);
+  delete c;
+}
+
+int tmdhip_comm_exchange(tmdhip_comm *c, int dtype, const void *send_dev, const int64_t *send_counts_host,
+                         void *recv_dev, const int64_t *recv_counts_host, int width, void *stream) {
+  if (!c || !send_counts_host || !recv_counts_host) return fail("tmdhip_comm_exchange: null argument");
+  if (dtype != TMDHIP_F32 && dtype != TMDHIP_F64) return fail("tmdhip_comm_exchange: bad dtype");
+  if (width < 1) return fail("tmdhip_comm_exchange: bad row width");
+  return exchange_rows(c, dtype, send_dev, send_counts_host, recv_dev, recv_counts_host, width, (hipStream_t)stream);
+}
+
+int tmdhip_dd_reset(tmdhip_comm *c) {
+  if (!c) return fail("tmdhip_dd_reset: null argument");
+  c->pending = false;
+  c->at = 0;
+  return 0;
+}
+
+int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int32_t *iters_done, void *stream) {
+  if (!ctx || !c || !d || !iters_done) return fail("tmdhip_dd_run: null argument");
+  if (d->struct_size != (int32_t)sizeof(tmdhip_dd_desc)) return fail("tmdhip_dd_run: struct_size mismatch");
+  if (d->dtype != TMDHIP_F32 && d->dtype != TMDHIP_F64) return fail("tmdhip_dd_run: bad dtype");
+  if (d->niter < 0 || d->nown < 0 || d->nhalo < 0 || d->nsend < 0 || d->check_every < 1 ||
+      (d->first_phases != 2 && d->first_phases != 3))
+    return fail("tmdhip_dd_run: bad arguments");
+  if (!d->pos_dev || !d->vel_dev || !d->forces_dev || !d->mass_dev || !d->ref_dev || !d->disp2_dev ||
+      !d->send_counts_host || !d->recv_counts_host)
+    return fail("tmdhip_dd_run: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const double box0[3] = {0, 0, 0};  // images are explicit halo atoms: open boundaries
+  const size_t esz = d->dtype == TMDHIP_F32 ? 4 : 8;
+  void *halo_rows = (char *)d->pos_dev + (size_t)d->nown * 3 * esz;
+  int64_t since = d->since_migration;
+  *iters_done = 0;
+  auto kick_drift = [&](int phases, uint64_t kick_step) {
+    return tmdhip_dd_step(d->dtype, d->nown, d->pos_dev, d->vel_dev, d->forces_dev, d->mass_dev, d->vcoeff_dev, d->dt,
+                          d->gamma, d->seed, kick_step, phases, d->ref_dev, d->disp2_dev, stream);
+  };
+  for (int it = 0; it < d->niter; ++it) {
+    // the kick belongs to the previous iteration (noise counter step0 + it - 1), the drift to this one
+    const uint64_t kick_step = d->step0 + (uint64_t)it > 0 ? d->step0 + (uint64_t)it - 1 : 0;
+    TMD_TRY(kick_drift(it == 0 ? d->first_phases : 3, kick_step));
+    ++since;
+    if (since % d->check_every == 0) {
+      if (c->pending) {
+        TMD_HIP(hipEventSynchronize(c->ev[c->cur]));  // recorded check_every steps ago
+        const double ahead = 1.0 + 2.0 * (double)(since + d->check_every - c->at) / (double)c->at;
+        if (std::sqrt((double)c->host_flag[c->cur]) * ahead > 0.5 * d->skin) {
+          c->pending = false;
+          *iters_done = it;
+          return 1;  // this iteration has drifted; the caller migrates, evaluates the forces and comes back
+        }
+      }
+      c->cur ^= 1;
+      if (c->world > 1) TMD_NCCL(c, c->api.all_reduce(d->disp2_dev, d->disp2_dev, 1, ncclFloat32, ncclMax, c->comm, st));
+      TMD_HIP(hipMemcpyAsync(&c->host_flag[c->cur], d->disp2_dev, sizeof(float), hipMemcpyDeviceToHost, st));
+      TMD_HIP(hipEventRecord(c->ev[c->cur], st));
+      c->pending = true;
+      c->at = since;
+    }
+    TMD_TRY(tmdhip_halo_pack(d->dtype, d->nsend, d->pos_dev, d->send_index_dev, d->send_shift_dev, d->send_buf_dev, stream));
+    TMD_TRY(exchange_rows(c, d->dtype, d->send_buf_dev, d->send_counts_host, halo_rows, d->recv_counts_host, 3, st));
+    TMD_TRY(tmdhip_compute_nonbonded(ctx, 0, d->pos_dev, box0, d->forces_dev, nullptr,
+                                     TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES, stream));
+    *iters_done = it + 1;
+  }
+  if (d->niter > 0 || d->first_phases == 3) {
+    const uint64_t last = d->step0 + (uint64_t)d->niter;
+    TMD_TRY(kick_drift(1, last > 0 ? last - 1 : 0));
+  }
+  return 0;
+}
+
+int tmdhip_dd_step(int dtype, int64_t nown, void *pos, void *vel, const void *forces, const void *mass,
+                   const void *vcoeff, double dt, double gamma, uint64_t seed, uint64_t step, int phases,
+                   const void *ref, uint32_t *disp2_dev, void *stream) {
+  if (dtype != TMDHIP_F32 && dtype != TMDHIP_F64) return fail("tmdhip_dd_step: bad dtype");
+  if (nown < 0 || (phases & ~3) || !(phases & 3)) return fail("tmdhip_dd_step: bad arguments");
+  if (nown == 0) return 0;
+  if (!pos || !vel || !forces || !mass) return fail("tmdhip_dd_step: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TMDHIP_F32
+             ? launch_dd_step<float>(nown, pos, vel, forces, mass, vcoeff, dt, gamma, seed, step, phases, ref, disp2_dev, st)
+             : launch_dd_step<double>(nown, pos, vel, forces, mass, vcoeff, dt, gamma, seed, step, phases, ref, disp2_dev, st);
+}
+
+int tmdhip_halo_pack(int dtype, int64_t count, const void *pos, const int32_t *index_dev, const void *shift_dev,
+                     void *out, void *stream) {
+  if (dtype != TMDHIP_F32 && dtype != TMDHIP_F64) return fail("tmdhip_halo_pack: bad dtype");
+  if (count < 0) return fail("tmdhip_halo_pack: negative count");
+  if (count == 0) return 0;
+  if (!pos || !index_dev || !shift_dev || !out) return fail("tmdhip_halo_pack: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n3 = 3 * count;
+  if (dtype == TMDHIP_F32)
+    hipLaunchKernelGGL((halo_pack_kernel<float>), blocks_for(n3, 256), dim3(256), 0, st, n3, (const float *)pos,
+                       index_dev, (const float *)shift_dev, (float *)out);
+  else
+    hipLaunchKernelGGL((halo_pack_kernel<double>), blocks_for(n3, 256), dim3(256), 0, st, n3, (const double *)pos,
+                       index_dev, (const double *)shift_dev, (double *)out);
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

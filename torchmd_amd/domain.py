@@ -15,8 +15,12 @@ Scheme ("full-list ownership": no force return path)
     (all-to-all of state), the halo plan is rebuilt and the engine re-created for the new local set.
 
 Per step: ONE all-to-all of positions (26 directed messages per rank, packed into one
-`all_to_all_single`) + one 4-byte all-reduce for the migration trigger.  Over RCCL the payload is
-~0.56 MB per rank and step at C5: latency-, not bandwidth-bound.
+`all_to_all_single` that writes straight into the halo rows of the engine's position buffer) + every
+`check_every` steps one 4-byte all-reduce for the migration trigger, read back asynchronously and acted on
+at the next check (no host synchronisation in the step loop).  Device work per step besides the force
+evaluation: `tmdhip_dd_step` (kick of the previous step + drift of this one + displacement maximum, one
+launch) and `tmdhip_halo_pack` (one launch) — `csrc/domain.hip`.  Over RCCL the payload is ~0.56 MB per
+rank and step at C5: latency-, not bandwidth-bound.
 
 Scope of this version: atomic systems (no bonded terms; types/charges travel with the atoms) — LJ,
 repulsion and electrostatic terms.  Molecules with bonds need molecule-aware ownership (next).
@@ -97,41 +101,35 @@ class HaloPlan:
             raise ValueError(f"bricks {grid.edge.tolist()} are thinner than the halo {halo}: use fewer ranks")
         dev, dt = wrapped_pos.device, wrapped_pos.dtype
         lo, hi = (t.to(dev, dt) for t in grid.bounds(rank))
-        box = grid.box.to(dev, dt)
         me = grid.coords(rank)
         near_lo = wrapped_pos < lo + halo  # [n,3]
         near_hi = wrapped_pos >= hi - halo
-        self.dest, self.index, self.shift = [], [], []
-        for d in DIRECTIONS:
-            m = torch.ones(wrapped_pos.shape[0], dtype=torch.bool, device=dev)
-            shift = torch.zeros(3, dtype=dt, device=dev)
+        # the 26 directed messages, ordered by destination rank so that one all-to-all carries them
+        order = sorted(range(len(DIRECTIONS)), key=lambda q: (grid.rank_of(tuple(me[k] + DIRECTIONS[q][k] for k in range(3))), q))
+        self.dest = [grid.rank_of(tuple(me[k] + DIRECTIONS[q][k] for k in range(3))) for q in order]
+        shifts = torch.zeros(len(order), 3, dtype=torch.float64)
+        for m_, q in enumerate(order):
             for k in range(3):
-                if d[k] == -1:
-                    m &= near_lo[:, k]
-                    if me[k] == 0:
-                        shift[k] = box[k]  # crossing the lower global face: receiver sees us at +L
-                elif d[k] == 1:
-                    m &= near_hi[:, k]
-                    if me[k] == grid.dims[k] - 1:
-                        shift[k] = -box[k]
-            self.dest.append(grid.rank_of((me[0] + d[0], me[1] + d[1], me[2] + d[2])))
-            self.index.append(torch.nonzero(m, as_tuple=False).flatten())
-            self.shift.append(shift)
-        # messages ordered by destination rank so that one all_to_all_single carries them
-        order = sorted(range(len(DIRECTIONS)), key=lambda q: (self.dest[q], q))
-        self.dest = [self.dest[q] for q in order]
-        self.index = [self.index[q] for q in order]
-        self.shift = [self.shift[q] for q in order]
-        self.send_index = torch.cat(self.index) if self.index else torch.zeros(0, dtype=torch.long, device=dev)
-        self.send_shift = (
-            torch.cat([s.expand(len(i), 3) for s, i in zip(self.shift, self.index)])
-            if len(self.send_index)
-            else torch.zeros(0, 3, dtype=dt, device=dev)
-        )
-        counts = torch.zeros(grid.world, dtype=torch.long)
-        for dst, idx in zip(self.dest, self.index):
-            counts[dst] += len(idx)
-        self.send_counts = counts.tolist()
+                if DIRECTIONS[q][k] == -1 and me[k] == 0:
+                    shifts[m_, k] = grid.box[k]  # crossing the lower global face: receiver sees us at +L
+                elif DIRECTIONS[q][k] == 1 and me[k] == grid.dims[k] - 1:
+                    shifts[m_, k] = -grid.box[k]
+        # membership of every atom in every message as ONE [26, n] mask and ONE nonzero (a single host
+        # synchronisation instead of 26): row m of the result lists, in atom order, the atoms of message m
+        true = torch.ones(wrapped_pos.shape[0], dtype=torch.bool, device=dev)
+        axis = [(near_lo[:, k], true, near_hi[:, k]) for k in range(3)]  # indexed by direction component + 1
+        masks = torch.stack([axis[0][DIRECTIONS[q][0] + 1] & axis[1][DIRECTIONS[q][1] + 1] & axis[2][DIRECTIONS[q][2] + 1]
+                             for q in order])
+        nz = torch.nonzero(masks)
+        self.send_index = nz[:, 1].contiguous()
+        per_message = torch.bincount(nz[:, 0], minlength=len(order)).tolist()
+        self.shift = [shifts[m_].to(dev, dt) for m_ in range(len(order))]
+        self.send_shift = shifts.to(dev, dt)[nz[:, 0]].contiguous()
+        self.index = list(torch.split(self.send_index, per_message))
+        counts = [0] * grid.world
+        for dst, cnt in zip(self.dest, per_message):
+            counts[dst] += cnt
+        self.send_counts = counts
 
     def pack(self, tensor):
         """Rows of `tensor` ([n_own, k]) in message order."""
@@ -165,11 +163,57 @@ class DistTransport:
         self._dev = device
         return self
 
+    def native(self):
+        """The library's own RCCL communicator over the same ranks (device tensors only): lets the halo exchange
+        and the whole step loop be enqueued from C (`tmdhip_dd_run`).  Rank 0 draws the id, this group's
+        broadcast distributes it.  None when it cannot be created (CPU tensors / gloo, TMDHIP_DD_NATIVE=0)."""
+        if getattr(self, "_native", False) is not False:
+            return self._native
+        self._native = None
+        import ctypes as C
+        import os
+
+        from . import _lib as L
+
+        if self._dev.type != "cuda" or os.environ.get("TMDHIP_DD_NATIVE", "1") == "0":
+            return None
+        lib = L.load()
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = (cand if os.path.exists(cand) else "").encode()
+        ident = (C.c_ubyte * L.COMM_ID_BYTES)()
+        if self.rank == 0:
+            L.check(lib.tmdhip_comm_unique_id(path, ident), "tmdhip_comm_unique_id")
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=self._dev)
+        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                            group=self.group)
+        ident = (C.c_ubyte * L.COMM_ID_BYTES)(*t.cpu().tolist())
+        handle = C.c_void_p()
+        with torch.cuda.device(self._dev):
+            L.check(lib.tmdhip_comm_create(C.byref(handle), path, ident, self.rank, self.world), "tmdhip_comm_create")
+        self._native = handle
+        return handle
+
+    def close(self):
+        if getattr(self, "_native", None):
+            from . import _lib as L
+
+            L.load().tmdhip_comm_destroy(self._native)
+        self._native = False
+
     def all_to_all(self, send, send_counts, recv_counts):
         out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         self.dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts),
                                     input_split_sizes=list(send_counts), group=self.group)
         return out
+
+    def all_to_all_into(self, out, send, send_counts, recv_counts):
+        """Rows of `send` (message order) -> rows of `out` (source-rank order), no intermediate tensor."""
+        self.dist.all_to_all_single(out, send, output_split_sizes=list(recv_counts),
+                                    input_split_sizes=list(send_counts), group=self.group)
+
+    def max_(self, t: torch.Tensor) -> torch.Tensor:
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t
 
     def any_true(self, flag: torch.Tensor) -> bool:
         t = flag.to(torch.int32).reshape(1).clone()
@@ -240,6 +284,10 @@ class Domain:
         self.pos = self._own_init  # re-pointed into local_pos once the halo size is known
         self.ref = w.clone()
         self.plan = HaloPlan(self.grid, self.rank, w, self.halo)
+        self.send_index32 = self.plan.send_index.to(torch.int32).contiguous()
+        self.send_shift = self.plan.send_shift.contiguous()
+        self.send_buf = torch.empty(len(self.send_index32), 3, dtype=self.dtype, device=self.device)
+        self.disp2 = torch.zeros(1, dtype=torch.float32, device=self.device)  # max |x - ref|^2 since this migration
         self.vcoeff_unit = torch.sqrt(1.0 / self.masses).contiguous()  # x sqrt(2 gamma kB T dt) at run time
 
     def state_rows(self):
@@ -258,11 +306,26 @@ class Domain:
         return torch.sqrt(d2.max()) if len(d2) else torch.zeros((), dtype=self.dtype, device=self.device)
 
     # -- halo -------------------------------------------------------------------------------
+    def pack_halo(self):
+        """Positions of all outgoing messages (wrapped frame + image shift) -> `send_buf`, one launch."""
+        from . import _lib as L
+
+        if len(self.send_index32):
+            L.check(L.load().tmdhip_halo_pack(L.dtype_code(self.dtype), len(self.send_index32), self.pos.data_ptr(),
+                                              self.send_index32.data_ptr(), self.send_shift.data_ptr(),
+                                              self.send_buf.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+        return self.send_buf
+
+    @property
+    def halo_rows(self):
+        """The halo part of the engine's position buffer (contiguous [nhalo, 3] view): the exchange writes here."""
+        return self.local_pos[0, self.nown:]
+
     def halo_payload(self, static: bool):
         """Rows to send: positions (wrapped frame + image shift), plus charge/type on (re)builds."""
-        p = self.plan.pack_positions(self.pos)
         if not static:
-            return p
+            return self.pack_halo()
+        p = self.plan.pack_positions(self.pos)
         extra = torch.stack([self.charges, self.types.to(self.dtype)], dim=1)
         return torch.cat([p, self.plan.pack(extra)], dim=1)
 
@@ -322,6 +385,8 @@ class DomainSet:
         self._nstep = 0
         self._since_migration = 0
         self.check_every = 4  # steps between migration-trigger collectives
+        self._pending = None  # (event, pinned host value, step since migration) of the last displacement read-back
+        self._host_ring, self._ring_pos = None, 0
 
     # -- setup: every rank holds the same global arrays and keeps its brick ---------------------
     def scatter(self, pos, vel, charges, types, masses):
@@ -352,13 +417,26 @@ class DomainSet:
         return out
 
     def _exchange(self, static):
-        if static:
-            self._recv_counts = {}
-        payloads = {r: d.halo_payload(static) for r, d in self.domains.items()}
         counts = {r: d.plan.send_counts for r, d in self.domains.items()}
-        got = self._all_to_all("halo", payloads, counts)
-        for r, d in self.domains.items():
-            d.set_halo(got[r], static)
+        if static:  # after a (re)distribution: positions + charge + type, engines re-created for the new atom sets
+            self._recv_counts = {}
+            payloads = {r: d.halo_payload(True) for r, d in self.domains.items()}
+            got = self._all_to_all("halo", payloads, counts)
+            for r, d in self.domains.items():
+                d.set_halo(got[r], True)
+            return
+        # every step: pack on the device, receive in place
+        if not self.local:
+            r, d = next(iter(self.domains.items()))
+            self.transport.all_to_all_into(d.halo_rows, d.pack_halo(), counts[r], self._recv_counts["halo"])
+            return
+        sent = {r: d.pack_halo() for r, d in self.domains.items()}
+        for dst, d in self.domains.items():
+            out, o = d.halo_rows, 0
+            for src in range(self.grid.world):
+                off, cnt = sum(counts[src][:dst]), counts[src][dst]
+                out[o: o + cnt] = sent[src][off: off + cnt]
+                o += cnt
 
     def _any(self, flags):
         if self.local:
@@ -366,14 +444,37 @@ class DomainSet:
         return self.transport.any_true(next(iter(flags.values())))
 
     def _migration_due(self):
-        """Checked every `check_every` steps (one 4-byte all-reduce + one host read).  A migration is
-        requested early enough that the halo stays complete until the next check: displacement so far
-        plus twice the average growth over `check_every` more steps must stay below skin/2."""
+        """Checked every `check_every` steps without stalling the step loop: the running maximum of the squared
+        displacement (kept on the device by `tmdhip_dd_step`) is max-reduced over the ranks and copied to pinned
+        host memory asynchronously; the value is looked at one check later.  A migration is requested early
+        enough that the halo stays complete until the decision after that one: the displacement measured at
+        step `at` (since the last migration) plus twice its average growth over the 2 x `check_every` steps
+        that pass until then must stay below skin/2."""
         self._since_migration += 1
-        if self._since_migration % self.check_every:
+        k = self.check_every
+        if self._since_migration % k:
             return False
-        ahead = 1.0 + 2.0 * self.check_every / self._since_migration
-        return self._any({r: d.max_displacement() * ahead > 0.5 * d.skin for r, d in self.domains.items()})
+        due = False
+        if self._pending is not None:
+            ev, host, at = self._pending
+            ev.synchronize()  # recorded check_every steps ago: long done
+            ahead = 1.0 + 2.0 * (self._since_migration + k - at) / at
+            skin = next(iter(self.domains.values())).skin
+            due = float(host.item()) ** 0.5 * ahead > 0.5 * skin
+        if not due:
+            if self.local:
+                t = torch.stack([d.disp2[0] for d in self.domains.values()]).max().reshape(1)
+            else:  # reduced in place: the flag becomes the maximum over all ranks, which is what it is used for
+                t = self.transport.max_(next(iter(self.domains.values())).disp2)
+            if self._host_ring is None:  # two pinned slots and events, reused alternately
+                self._host_ring = [(torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event())
+                                   for _ in range(2)]
+            self._ring_pos ^= 1
+            host, ev = self._host_ring[self._ring_pos]
+            host.copy_(t, non_blocking=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self._pending = (ev, host, self._since_migration)
+        return due
 
     def migrate(self):
         """Re-assign atoms to bricks, rebuild halo plans and engines."""
@@ -391,6 +492,11 @@ class DomainSet:
             d.from_rows(rows)
         self.migrations += 1
         self._since_migration = 0
+        self._pending = None
+        if not self.local and self.transport.native():
+            from . import _lib as L
+
+            L.check(L.load().tmdhip_dd_reset(self.transport.native()))
         self._exchange(static=True)
 
     # -- dynamics -------------------------------------------------------------------------------
@@ -408,29 +514,85 @@ class DomainSet:
         code = L.dtype_code(self.dtype)
         gamma = gamma_ps / PICOSEC2TIMEU if gamma_ps is not None else 0.0
         stream = lambda: torch.cuda.current_stream(self.device).cuda_stream  # noqa: E731
+        vnoise = float(np.sqrt(2.0 * gamma * BOLTZMAN * T * dt)) if T else 0.0
+
+        def dd_step(d, phases):
+            """phases 1: second half kick of the step that just got its forces; 2: first half of the next; 3: both."""
+            vc = 0
+            if T and (phases & 1):
+                if getattr(d, "_vc_key", None) != (vnoise, d.nown, id(d.vcoeff_unit)):
+                    d._vc = (d.vcoeff_unit * vnoise).contiguous()
+                    d._vc_key = (vnoise, d.nown, id(d.vcoeff_unit))
+                vc = d._vc.data_ptr()
+            L.check(lib.tmdhip_dd_step(code, d.nown, d.pos.data_ptr(), d.vel.data_ptr(), d.forces.data_ptr(),
+                                       d.masses.data_ptr(), vc, dt, gamma, seed + 7919 * d.rank, max(self._nstep - 1, 0),
+                                       phases, d.ref.data_ptr(), d.disp2.data_ptr(), stream()))
+
+        comm = None if self.local else self.transport.native()
+        if comm is not None:
+            return self._step_native(comm, niter, dt, gamma, vnoise if T else None, seed)
         for it in range(niter):
             for d in self.domains.values():
-                L.check(lib.tmdhip_first_vv(code, 1, d.nown, d.pos.data_ptr(), d.vel.data_ptr(),
-                                            d.forces.contiguous().data_ptr(), d.masses.data_ptr(), dt, stream()))
+                dd_step(d, 2 if it == 0 else 3)
             if self._migration_due():
                 self.migrate()
             else:
                 self._exchange(static=False)
             self.compute_forces()
-            for d in self.domains.values():
-                f = d.forces.contiguous()
-                if T:
-                    if getattr(d, "_vc_key", None) != (gamma, T, dt, d.nown, id(d.vcoeff_unit)):
-                        d._vc = (d.vcoeff_unit * float(np.sqrt(2.0 * gamma * BOLTZMAN * T * dt))).contiguous()
-                        d._vc_key = (gamma, T, dt, d.nown, id(d.vcoeff_unit))
-                    vc = d._vc
-                    L.check(lib.tmdhip_langevin_second_vv(code, 1, d.nown, d.vel.data_ptr(), f.data_ptr(),
-                                                          d.masses.data_ptr(), vc.data_ptr(), dt, gamma,
-                                                          seed + 7919 * d.rank, self._nstep, stream()))
-                else:
-                    L.check(lib.tmdhip_second_vv(code, 1, d.nown, d.vel.data_ptr(), f.data_ptr(),
-                                                 d.masses.data_ptr(), dt, stream()))
             self._nstep += 1
+        for d in self.domains.values():
+            dd_step(d, 1)
+
+    def _step_native(self, comm, niter, dt, gamma, vnoise, seed):
+        """`niter` iterations enqueued from C (`tmdhip_dd_run`: RCCL send/recv on the compute stream); Python
+        only takes over for a migration."""
+        import ctypes as C
+
+        from . import _lib as L
+
+        lib = L.load()
+        d = next(iter(self.domains.values()))
+        remaining, first = niter, 2
+        done = C.c_int32(0)
+        while True:
+            eng = d.forces_engine._engine(d.local_pos)
+            if not eng.stores_forces:
+                raise RuntimeError("domain decomposition needs the cell-list engine (brick too small)")
+            vc = 0
+            if vnoise is not None:
+                if getattr(d, "_vc_key", None) != (vnoise, d.nown, id(d.vcoeff_unit)):
+                    d._vc = (d.vcoeff_unit * vnoise).contiguous()
+                    d._vc_key = (vnoise, d.nown, id(d.vcoeff_unit))
+                vc = d._vc.data_ptr()
+            sc = (C.c_int64 * self.grid.world)(*d.plan.send_counts)
+            rc_ = (C.c_int64 * self.grid.world)(*self._recv_counts["halo"])
+            desc = L.DdDesc(
+                struct_size=C.sizeof(L.DdDesc), dtype=L.dtype_code(self.dtype), niter=remaining, first_phases=first,
+                check_every=self.check_every, nown=d.nown, nhalo=d.local_pos.shape[1] - d.nown,
+                pos_dev=d.local_pos.data_ptr(), vel_dev=d.vel.data_ptr(), forces_dev=d.local_forces.data_ptr(),
+                mass_dev=d.masses.data_ptr(), vcoeff_dev=vc, ref_dev=d.ref.data_ptr(), disp2_dev=d.disp2.data_ptr(),
+                dt=dt, gamma=gamma, seed=seed + 7919 * d.rank, step0=self._nstep, nsend=len(d.send_index32),
+                send_index_dev=d.send_index32.data_ptr(), send_shift_dev=d.send_shift.data_ptr(),
+                send_buf_dev=d.send_buf.data_ptr(), send_counts_host=C.addressof(sc), recv_counts_host=C.addressof(rc_),
+                skin=d.skin, since_migration=self._since_migration,
+            )
+            with torch.cuda.device(self.device):
+                rc = L.check(lib.tmdhip_dd_run(eng.ctx, comm, C.byref(desc), C.byref(done),
+                                               torch.cuda.current_stream(self.device).cuda_stream), "tmdhip_dd_run")
+            d.forces = d.local_forces[0, : d.nown]
+            self._nstep += done.value
+            self._since_migration += done.value + (1 if rc == 1 else 0)
+            remaining -= done.value
+            if rc == 0:
+                break
+            self.migrate()  # the iteration that has already drifted: new bricks, new halo, then its forces
+            self.compute_forces()
+            self._nstep += 1
+            remaining -= 1
+            first = 3
+        if not d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos):
+            raise RuntimeError("a neighbour list of the brick was truncated during the batch (capacity has been grown): "
+                               "repeat the batch")
 
     # -- gathering (tests / output) ---------------------------------------------------------------
     def gather(self, natoms):
