@@ -340,6 +340,26 @@ exp = torch.cat(exp)
 key = lambda t: t[np.lexsort((t[:, 2].numpy(), t[:, 1].numpy(), t[:, 0].numpy(), t[:, 3].numpy()))]
 assert got.shape == exp.shape, (got.shape, exp.shape)
 assert torch.allclose(key(got), key(exp), atol=1e-12)
+# the layout tmdhip_comm_exchange uses (csrc/domain.hip exchange_rows: one send and one recv per peer, offsets =
+# running sums of the per-peer counts in rank order), replayed with point-to-point gloo ops: same rows as the
+# all-to-all (a message to oneself is a local copy here; RCCL takes it inside the group)
+p2p = torch.zeros_like(got)
+so = ro = 0
+ops = []
+for p in range(world):
+    ns, nr = plan.send_counts[p], recv_counts[p]
+    if p == rank:
+        p2p[ro: ro + nr] = payload[so: so + ns]
+    else:
+        if ns:
+            ops.append(dist.P2POp(dist.isend, payload[so: so + ns].contiguous(), p))
+        if nr:
+            ops.append(dist.P2POp(dist.irecv, p2p[ro: ro + nr], p))
+    so += ns
+    ro += nr
+for w_ in (dist.batch_isend_irecv(ops) if ops else []):
+    w_.wait()
+assert torch.equal(p2p, got)
 assert tr.any_true(torch.tensor(rank == world - 1)) and not tr.any_true(torch.tensor(False))
 assert float(tr.sum(torch.tensor([1.0 + rank]))) == world * (world + 1) / 2
 dist.barrier()
