@@ -202,7 +202,7 @@ def ns_per_day(steps, seconds, timestep_fs=TIMESTEP_FS):
     return steps / seconds * timestep_fs * 1e-6 * 86400.0  # reference run.py:19,279 (FS2NS)
 
 
-def build_system(nside, device, dtype, seed, skin=None):
+def build_system(nside, device, dtype, seed, skin=None, skin_weights="mass"):
     from torchmd_amd.builders import tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import maxwell_boltzmann
@@ -216,7 +216,8 @@ def build_system(nside, device, dtype, seed, skin=None):
     system.set_box(box)
     torch.manual_seed(seed)
     system.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
-    forces = Forces(par, terms=TERMS, cutoff=CUTOFF, rfa=True, **({} if skin is None else {"skin": skin}))
+    forces = Forces(par, terms=TERMS, cutoff=CUTOFF, rfa=True, skin_weights=skin_weights,
+                    **({} if skin is None else {"skin": skin}))
     return mol, par, system, forces, box
 
 
@@ -263,6 +264,8 @@ def main():
     ap.add_argument("--relax-steps", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin in A (default: the library's)")
+    ap.add_argument("--skin-weights", default="mass", choices=["mass", "none"],
+                    help="per-atom Verlet skins by mass (default) or one skin for every atom")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --dry)")
     ap.add_argument("--dry", action="store_true", help="launcher/collective plumbing only, no GPU work (CPU test)")
     ap.add_argument("--config", default="c3", choices=["c3", "c5"],
@@ -298,7 +301,8 @@ def main():
     fan = ReplicaFanout(total_replicas=world, device=device)
 
     dtype = torch.float32
-    mol, par, system, forces, box = build_system(args.nside, device, dtype, seed=1 + rank, skin=args.skin)
+    mol, par, system, forces, box = build_system(args.nside, device, dtype, seed=1 + rank, skin=args.skin,
+                                                 skin_weights=None if args.skin_weights == "none" else "mass")
     fan.check_same_topology(mol.bonds, mol.angles, mol.charge)
     natoms = mol.numAtoms
 
@@ -376,6 +380,7 @@ def main():
             "steps_per_rebuild": (args.steps / rebuilds) if rebuilds else None,
             "entries": int(st2["list_entries"]),
             "skin": st2["skin"],
+            "skin_weights": args.skin_weights,
             "capacity_per_atom": int(st2["max_neighbours"]),
             "ncell": list(st2["ncell"]),
         },

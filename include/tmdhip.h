@@ -211,6 +211,14 @@ int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream)
 int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, const void *charges_host,
                         int nactive);
 
+/* Per-atom Verlet skins (cell-list path).  By default every atom may move skin/2 before the list is rebuilt and
+ * every pair within cutoff + skin is listed.  With weights w_i in (0, 1] (real [natoms], host) atom i may move
+ * s_i = w_i * skin/2 and pair (i, j) is listed within cutoff + s_i + s_j — equally exact (a pair that is not
+ * listed cannot come within the cutoff before one of its atoms exceeds its s), but slow atoms (heavy ones: a
+ * water oxygen moves 0.28 of what its hydrogens move) stop paying for the skin the fast ones need.  NULL
+ * restores the uniform skin.  Synchronises the device; the next compute re-plans and rebuilds. */
+int tmdhip_set_skin_weights(tmdhip_ctx *ctx, const void *weights_host);
+
 /* Drop the neighbour list of a replica: the next tmdhip_compute_nonbonded rebuilds it (used after the
  * caller has changed positions out of band, and by the rebuild timing tool). */
 int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica);

@@ -382,7 +382,8 @@ def test_replica_batched_langevin_equals_stepwise_loop():
     assert (p0[0] - p0[2]).abs().max().item() > 1e-3
 
 
-def test_list_overflow_is_replayed_not_raised(monkeypatch):
+@pytest.mark.parametrize("skin_weights", [None, "mass"])
+def test_list_overflow_is_replayed_not_raised(monkeypatch, skin_weights):
     """A neighbour list that overflows during an Integrator.step() batch (a device-side rebuild finds more
     neighbours than the capacity sized at the first build) no longer invalidates the trajectory: the batch is
     rewound to its entry state (tmdhip_md_restore), the capacity grown, and the batch repeated with the same
@@ -418,7 +419,7 @@ def test_list_overflow_is_replayed_not_raised(monkeypatch):
         s.set_box(box)
         torch.manual_seed(5)
         s.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
-        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist", skin_weights=skin_weights)
         f.compute(s.pos, s.box, s.forces)
         cap0 = f.stats(s.pos)["max_neighbours"]
         torch.manual_seed(6)
@@ -433,7 +434,7 @@ def test_list_overflow_is_replayed_not_raised(monkeypatch):
 
     out_ref, cap_ref, st_ref, ferr_ref = run(False)
     out_t, cap_t, st_t, ferr_t = run(True)
-    assert cap_t < cap_ref and st_t["max_neighbours"] > cap_t  # the tight run had to grow its lists
+    assert cap_t < cap_ref and st_t["max_neighbours"] > cap_t, (cap_t, cap_ref, st_t)  # the tight run had to grow its lists
     assert st_t["overflow"] == 0 and st_ref["overflow"] == 0
     assert ferr_t < 2e-3 and ferr_ref < 2e-3
     assert abs(out_t[2][0] - out_ref[2][0]) < 15.0  # temperature (K)

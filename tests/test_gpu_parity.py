@@ -230,7 +230,7 @@ def test_water_box_celllist_vs_oracle(prec):
     f.compute(p, b, F)
     rebuilds0 = f.stats(p)["n_rebuilds"]
     rng = np.random.default_rng(1)
-    for scale, expect_rebuild in ((0.2, False), (1.5, True)):
+    for scale, expect_rebuild in ((0.1, False), (1.5, True)):  # 0.1 A: below the smallest per-atom half skin
         d = torch.tensor(rng.uniform(-1, 1, size=pos.shape) * scale / np.sqrt(3), dtype=dt)
         pm = (p32[0] + d)[None].contiguous()
         f.compute(pm.to(dev), b, F)

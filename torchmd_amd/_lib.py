@@ -182,6 +182,7 @@ SIGNATURES = {
     "tmdhip_md_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "tmdhip_invalidate_list": (C.c_int, [C.c_void_p, C.c_int]),
     "tmdhip_update_atoms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "tmdhip_set_skin_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tmdhip_get_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Stats)]),
     "tmdhip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tmdhip_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

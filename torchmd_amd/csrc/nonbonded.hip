@@ -233,22 +233,29 @@ template <typename R>
 struct ListCheck {
   const R *ref;  // positions at the last list build, original atom order [3N]
   R hard2;       // (skin/2)^2
+  const R *hs2;  // per-atom (half skin)^2, original atom order [N], or null: `hard2` for every atom
   int *flags;
   int parity;
 };
 
 // (rx, ry, rz) = position - reference position of one atom
 template <typename R>
-__device__ __forceinline__ void list_check_point(const ListCheck<R> &k, const PairConsts<R> &c, R rx, R ry, R rz) {
+__device__ __forceinline__ void list_check_point(const ListCheck<R> &k, const PairConsts<R> &c, R rx, R ry, R rz,
+                                                 R h2) {
   const R dx = min_image(rx, c.box[0], c.invbox[0]);
   const R dy = min_image(ry, c.box[1], c.invbox[1]);
   const R dz = min_image(rz, c.box[2], c.invbox[2]);
   const R d2 = dx * dx + dy * dy + dz * dz;
-  if (!(d2 <= k.hard2)) k.flags[F_REBUILD0 + k.parity] = 1;  // NaN positions also force a rebuild
+  if (!(d2 <= h2)) k.flags[F_REBUILD0 + k.parity] = 1;  // NaN positions also force a rebuild
+}
+// squared displacement atom i may reach before the list has to be rebuilt
+template <typename R>
+__device__ __forceinline__ R list_check_limit(const ListCheck<R> &k, int i) {
+  return k.hs2 ? k.hs2[i] : k.hard2;
 }
 template <typename R>
 __device__ __forceinline__ void list_check_atom(const ListCheck<R> &k, const PairConsts<R> &c, int i, R px, R py, R pz) {
-  list_check_point<R>(k, c, px - k.ref[3 * i + 0], py - k.ref[3 * i + 1], pz - k.ref[3 * i + 2]);
+  list_check_point<R>(k, c, px - k.ref[3 * i + 0], py - k.ref[3 * i + 1], pz - k.ref[3 * i + 2], list_check_limit(k, i));
 }
 
 // thread 0 of the check of a step: the other parity's request is history
@@ -330,7 +337,8 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
                                     const R *__restrict__ qs, const int *__restrict__ types,
                                     int *__restrict__ order, int *__restrict__ inv,
                                     typename Vec<R>::T4 *__restrict__ sorted, int *__restrict__ stype,
-                                    R *__restrict__ ref, const int *flag) {
+                                    R *__restrict__ ref, const R *__restrict__ half_skin,
+                                    R *__restrict__ sorted_hs, const int *flag) {
   if (*flag == 0) return;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
@@ -349,6 +357,7 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
   v.w = qs[me];
   sorted[dst] = v;
   stype[dst] = types[me];
+  if (half_skin) sorted_hs[dst] = half_skin[me];
   ref[3 * me + 0] = v.x;
   ref[3 * me + 1] = v.y;
   ref[3 * me + 2] = v.z;
@@ -396,10 +405,13 @@ __device__ __forceinline__ size_t list_slot(const ListGeom &lg, int a, int k) {
 // chunk of 64 candidates the wave loops over the atoms i of its cell (wave-uniform data), tests
 // |d|^2 <= rlist^2 and the exclusions, and appends the hits of atom i with a ballot / prefix-popcount
 // compaction.  Entry order per atom is fixed by the stencil order -> lists are bit-reproducible.
-template <typename R, bool LOOP>
+// WSKIN: per-atom skins — pair (i, j) is listed when |d| <= cutoff + s_i + s_j (s = the atom's half skin: the
+// displacement it may reach before a rebuild, see ListCheck), instead of cutoff + skin for every pair.
+template <typename R, bool LOOP, bool WSKIN>
 __global__ __launch_bounds__(64) void build_list_kernel(
-    int n, const typename Vec<R>::T4 *__restrict__ sorted, const int *__restrict__ stype,
-    const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2,
+    int n, const typename Vec<R>::T4 *__restrict__ sorted, const R *__restrict__ sorted_hs,
+    const int *__restrict__ stype,
+    const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
     int ncell, int nactive, int type_in_entry) {
@@ -493,13 +505,13 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   __syncthreads();
 
   // per-atom data of the i block staged in LDS as two 16-byte records that the inner loop reads with
-  // wave-uniform (broadcast) LDS loads: rec0 = {wrapped xyz, word offset of the atom's list row},
-  // rec1 = {own original index, first three excluded partners} (so "j == i" is just one more
-  // exclusion; longer exclusion rows spill to global reads).  PMC showed this loop limited by the
+  // wave-uniform (broadcast) LDS loads: rec0 = {wrapped xyz, cutoff + own half skin (WSKIN)},
+  // rec1 = {own original index, first two excluded partners, word offset of the atom's list row} (so
+  // "j == i" is just one more exclusion; longer exclusion rows spill to global reads).  PMC showed this loop limited by the
   // scalar unit (one SALU per CU, shared by the 4 SIMDs) as much as by VALU, hence: LDS addresses and
   // the row offset live in VGPRs, the per-atom hit counters move with readlane/writelane, and the
   // rare long-exclusion path is hoisted out as a separate loop version.
-  constexpr int EXS = 4;
+  constexpr int EXS = 3;
   __shared__ R4 s_rec0[64];
   __shared__ int4 s_rec1[64];
   __shared__ int s_eb[64], s_more[64], s_cnt[64];
@@ -518,8 +530,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       p.z = wrap_into_box(p.z, c.box[2], c.invbox[2]);
       const unsigned rowoff = (((unsigned)(a >> apw_shift) * (unsigned)lg.maxn) << apw_shift) +
                               ((unsigned)(a & (lg.apw - 1)) << (lg.lpa_shift + 2));
-      if constexpr (sizeof(R) == 4) p.w = __uint_as_float(rowoff);
-      else p.w = __longlong_as_double((long long)rowoff);
+      p.w = WSKIN ? rcut + sorted_hs[a] : R(0);
       const int oi = order[a];
       // passive atoms (original index >= nactive: halo images of a domain) get no list: parked out of reach
       if (oi >= nactive) p.x = (R)-1e18;
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       ex.x = oi;
       ex.y = 0 < ne ? excl_idx[eb + 0] : -1;
       ex.z = 1 < ne ? excl_idx[eb + 1] : -1;
-      ex.w = 2 < ne ? excl_idx[eb + 2] : -1;
+      ex.w = (int)rowoff;
       s_rec1[lane] = ex;
       long_rows = ne > EXS - 1;
     }
@@ -545,6 +556,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     // chunk q0 is processed, so their latency overlaps the i loop instead of stalling the wave at the
     // top of every chunk (the build is latency-bound: PMC showed VALU busy 57 %)
     R4 nx_p;
+    R nx_hs = 0;
     int nx_j = cs, nx_code = 0, nx_order = 0, nx_type = 0;
     bool nx_valid = false;
     auto fetch = [&](int q0) {
@@ -559,10 +571,12 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       nx_p = sorted[nx_j];
       nx_order = order[nx_j];
       nx_type = stype[nx_j];
+      if constexpr (WSKIN) nx_hs = sorted_hs[nx_j];
     };
     fetch(0);
     for (int q0 = 0; q0 < ncand; q0 += 64) {
       R4 pj = nx_p;
+      const R sj = nx_hs;
       const int j = nx_j, code = nx_code;
       const bool valid = nx_valid;
       const unsigned oj = (unsigned)nx_order;
@@ -584,8 +598,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
         // directly, they are combined on the scalar unit, and the prefix count is two v_mbcnt
         mask &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) |
                   __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
-                  __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32) |
-                  __builtin_amdgcn_uicmp((unsigned)ex.w, oj, 32));
+                  __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32));
         if (any_long) {  // wave-uniform, rare (atoms with more than EXS-1 exclusions: proteins)
           const int more = s_more[t], eb = s_eb[t];
           for (int e = 0; e < more; ++e) mask &= ~__builtin_amdgcn_uicmp((unsigned)excl_idx[eb + e], oj, 32);
@@ -593,9 +606,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
         const unsigned k = (unsigned)base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
-          unsigned rowoff;
-          if constexpr (sizeof(R) == 4) rowoff = __float_as_uint(pi.w);
-          else rowoff = (unsigned)__double_as_longlong(pi.w);
+          const unsigned rowoff = (unsigned)ex.w;
           const unsigned kk = k >> lg.lpa_shift;
           nlist[rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u)] = entry;
         }
@@ -606,6 +617,10 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       };
       auto in_range = [&](const R4 &pi) -> unsigned long long {
         const R dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        if constexpr (WSKIN) {
+          const R reach = pi.w + sj;  // cutoff + s_i + s_j
+          return wave_mask_le(dx * dx + dy * dy + dz * dz, reach * reach);
+        }
         return wave_mask_le(dx * dx + dy * dy + dz * dz, rlist2);
       };
       // LDS byte offset of the current i record, kept in a VGPR on purpose (see above).  Two-level test:
@@ -999,7 +1014,7 @@ struct MdStepArgs {
 // position buffers would otherwise order the later loads (inv, ref, qs) behind them.
 template <typename R>
 struct AtomIn {
-  R m, vc, q;
+  R m, vc, q, h2;
   R v[3], f[3], p[3], r[3];
   int slot;
 };
@@ -1018,6 +1033,7 @@ __device__ __forceinline__ AtomIn<R> md_load_atom(const MdStepArgs<R> &s, int i,
     x.r[k] = (FIRST && CHECK) ? s.chk.ref[3 * i + k] : R(0);
   }
   x.q = (FIRST && CHECK) ? s.qs[i] : R(0);
+  x.h2 = (FIRST && CHECK) ? list_check_limit(s.chk, i) : R(0);
   x.slot = (FIRST && CHECK) ? s.inv[i] : 0;
   return x;
 }
@@ -1071,7 +1087,7 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
       sv.z = p[2];
       sv.w = x.q;
       s.sorted[x.slot] = sv;
-      list_check_point<R>(s.chk, c, p[0] - x.r[0], p[1] - x.r[1], p[2] - x.r[2]);
+      list_check_point<R>(s.chk, c, p[0] - x.r[0], p[1] - x.r[1], p[2] - x.r[2], x.h2);
     }
   }
 #pragma unroll
@@ -1198,11 +1214,12 @@ struct Replica {
   ListGeom lg{1, 64, 0, 0};
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
+  DevBuf sorted_hs;  // per-atom half skins in cell-sorted order (contexts with skin weights)
   DevBuf pos_alt;  // second position buffer of tmdhip_md_run's double-buffered integrator kernel
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf paircount;  // unsigned long long
   void release() {
-    for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref,
+    for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs,
                       &nlist, &nneigh, &flags, &paircount, &pos_alt})
       b->release();
   }
@@ -1223,6 +1240,10 @@ struct tmdhip_ctx {
   DevBuf obs_ke;              // tmdhip_md_observe: kinetic energies [R] ...
   void *obs_host = nullptr;   // ... and the pinned landing zone of energies, kinetic energies and list flags
   DevBuf types, qs, tab, excl_off, excl_idx;
+  // per-atom Verlet skins (tmdhip_set_skin_weights): half_skin[i] = w_i * skin / 2 and its square, original atom
+  // order; empty = skin / 2 for every atom
+  DevBuf half_skin, half_skin2;
+  double mean_list_scale = 1;  // mean list length / length of a list at the largest pair radius (per-atom skins)
   DevBuf escratch;  // nreplicas x kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
   DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
   DevBuf pos_alt_all;  // second position buffer [nreplicas][natoms][3] of the batched MD loop
@@ -1464,6 +1485,7 @@ ListCheck<R> make_check(const tmdhip_ctx *ctx, Replica &rp) {
   ListCheck<R> k;
   k.ref = rp.ref.as<R>();
   k.hard2 = (R)(0.25 * ctx->skin * ctx->skin);
+  k.hs2 = ctx->half_skin2.p ? ctx->half_skin2.as<R>() : nullptr;
   k.flags = rp.flags.as<int>();
   k.parity = (int)(rp.step & 1);
   return k;
@@ -1562,9 +1584,11 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.inv.ensure(sizeof(int) * n));
   TMD_TRY(rp.sorted.ensure(sizeof(R4) * n));
   TMD_TRY(rp.stype.ensure(sizeof(int) * n));
+  if (ctx->half_skin.p) TMD_TRY(rp.sorted_hs.ensure(ctx->real_size * (size_t)n));
   TMD_TRY(rp.ref.ensure(sizeof(R) * 3 * n));
   TMD_TRY(rp.nneigh.ensure(sizeof(int) * n));
-  if (rp.lg.maxn == 0 || !rp.have_list) rp.lg.lpa = pick_lpa(n, maxn);  // fixed once a list exists
+  // lanes per atom from the MEAN list length (capacities are sized for the longest lists); fixed once a list exists
+  if (rp.lg.maxn == 0 || !rp.have_list) rp.lg.lpa = pick_lpa(n, (int)((maxn - 32) * ctx->mean_list_scale) + 32);
   rp.lg.apw = 64 / rp.lg.lpa;
   rp.lg.lpa_shift = 0;
   while ((1 << rp.lg.lpa_shift) < rp.lg.lpa) rp.lg.lpa_shift++;
@@ -1600,22 +1624,27 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
                      rp.cell_start.as<int>(), rp.order_tmp.as<int>(), flag);
   hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(),
                      rp.cell_start.as<int>(), rp.order_tmp.as<int>(), pos, ctx->qs.as<R>(), ctx->types.as<int>(),
-                     rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(), flag);
+                     rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(),
+                     ctx->half_skin.as<R>(), rp.sorted_hs.as<R>(), flag);
   if (!prechecked)
     hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.order.as<int>(),
                        rp.sorted.as<R4>(), flag);
   const R rl = (R)ctx->rlist;
   constexpr int kMaxBuildBlocks = 16384;
-  if (rp.ncell <= kMaxBuildBlocks)
-    hipLaunchKernelGGL((build_list_kernel<R, false>), dim3(rp.ncell), dim3(64), 0, st, n, rp.sorted.as<R4>(),
+  const bool wskin = ctx->half_skin.p != nullptr;
+  auto launch_build = [&](auto kernel, int blocks) {
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, n, rp.sorted.as<R4>(), rp.sorted_hs.as<R>(),
                        rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
-                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
+                       (R)ctx->d.cutoff, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
                        rp.nneigh.as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes);
-  else
-    hipLaunchKernelGGL((build_list_kernel<R, true>), dim3(kMaxBuildBlocks), dim3(64), 0, st, n, rp.sorted.as<R4>(),
-                       rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
-                       ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
-                       rp.nneigh.as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes);
+  };
+  if (rp.ncell <= kMaxBuildBlocks) {
+    if (wskin) launch_build(build_list_kernel<R, false, true>, rp.ncell);
+    else launch_build(build_list_kernel<R, false, false>, rp.ncell);
+  } else {
+    if (wskin) launch_build(build_list_kernel<R, true, true>, kMaxBuildBlocks);
+    else launch_build(build_list_kernel<R, true, false>, kMaxBuildBlocks);
+  }
   TMD_HIP(hipGetLastError());
   return 0;
 }
@@ -2071,7 +2100,7 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
 void tmdhip_destroy(tmdhip_ctx *ctx) {
   if (!ctx) return;
   for (auto &rp : ctx->rep) rp.release();
-  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all, &ctx->snap})
+  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->half_skin, &ctx->half_skin2, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all, &ctx->snap})
     b->release();
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
@@ -2156,10 +2185,56 @@ int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, 
   }
   TMD_TRY(ctx->excl_off.ensure(sizeof(int) * ((size_t)n + 1)));
   TMD_HIP(hipMemset(ctx->excl_off.p, 0, sizeof(int) * ((size_t)n + 1)));
+  ctx->half_skin.release();  // per-atom skins belonged to the old atom set
+  ctx->half_skin2.release();
+  ctx->rlist = ctx->d.cutoff > 0 ? ctx->d.cutoff + ctx->skin : 0;
+  ctx->mean_list_scale = 1;
   for (auto &rp : ctx->rep) {  // the next compute re-plans the grid, re-sizes the buffers and rebuilds
     rp.have_list = false;
     rp.lg.maxn = 0;
   }
+  return 0;
+}
+
+int tmdhip_set_skin_weights(tmdhip_ctx *ctx, const void *weights_host) {
+  if (!ctx) return fail("tmdhip_set_skin_weights: null ctx");
+  TMD_HIP(hipDeviceSynchronize());  // nothing may still be reading the old skins
+  const int n = ctx->d.natoms;
+  for (auto &rp : ctx->rep) rp.have_list = false;  // the next compute re-plans and rebuilds
+  if (!weights_host) {
+    ctx->half_skin.release();
+    ctx->half_skin2.release();
+    ctx->rlist = ctx->d.cutoff > 0 ? ctx->d.cutoff + ctx->skin : 0;
+    ctx->mean_list_scale = 1;
+    return 0;
+  }
+  if (ctx->algorithm != TMDHIP_ALGO_CELLLIST) return fail("tmdhip_set_skin_weights: only for the cell-list path");
+  double wmax = 0, wsum = 0;
+  auto fill = [&](auto *w, auto &hs, auto &hs2) {
+    for (int i = 0; i < n; ++i) {
+      if (!(w[i] > 0) || !(w[i] <= 1)) return fail("tmdhip_set_skin_weights: weights must lie in (0, 1]");
+      wmax = std::max(wmax, (double)w[i]);
+      wsum += (double)w[i];
+      hs[i] = (std::remove_reference_t<decltype(hs[0])>)(0.5 * ctx->skin * (double)w[i]);
+      hs2[i] = hs[i] * hs[i];
+    }
+    return 0;
+  };
+  TMD_TRY(ctx->half_skin.ensure(ctx->real_size * (size_t)n));
+  TMD_TRY(ctx->half_skin2.ensure(ctx->real_size * (size_t)n));
+  if (ctx->d.dtype == TMDHIP_F32) {
+    std::vector<float> hs(n), hs2(n);
+    TMD_TRY(fill((const float *)weights_host, hs, hs2));
+    TMD_HIP(hipMemcpy(ctx->half_skin.p, hs.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    TMD_HIP(hipMemcpy(ctx->half_skin2.p, hs2.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+  } else {
+    std::vector<double> hs(n), hs2(n);
+    TMD_TRY(fill((const double *)weights_host, hs, hs2));
+    TMD_HIP(hipMemcpy(ctx->half_skin.p, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    TMD_HIP(hipMemcpy(ctx->half_skin2.p, hs2.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  ctx->rlist = ctx->d.cutoff + ctx->skin * wmax;  // the largest pair radius: sizes the cells and the stencil reach
+  ctx->mean_list_scale = std::pow((ctx->d.cutoff + ctx->skin * wsum / n) / ctx->rlist, 3.0);
   return 0;
 }
 

@@ -348,7 +348,9 @@ class Domain:
         par = _local_parameters(q, t, m, self.A, self.B)
         n = self.nown + nhalo
         if self.forces_engine is None:
-            self.forces_engine = Forces(par, terms=self.terms, cutoff=self.cutoff, **self.engine_kwargs)
+            kw = dict(skin_weights=None)  # halo atoms carry a dummy mass: one skin for all
+            kw.update(self.engine_kwargs)
+            self.forces_engine = Forces(par, terms=self.terms, cutoff=self.cutoff, **kw)
             # create the context now, then mark the halo atoms passive
             self.forces_engine._engine(torch.empty(1, n, 3, dtype=self.dtype, device=self.device))
         # the device context and its buffers survive migrations: only the atom set is swapped; halo atoms

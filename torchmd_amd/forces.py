@@ -193,6 +193,9 @@ class _Engine:
         # the nonbonded kernels *store* forces when asked to (the cell-list pair kernel owns every atom
         # exactly once; the all-pairs path zero-fills internally), which saves a zero-fill pass here
         self.stores_forces = self.has_nonbonded
+        w = owner._skin_weight_array()
+        if w is not None and st.algorithm == L.ALGO_CELLLIST:
+            L.check(lib.tmdhip_set_skin_weights(self.ctx, ptr(_np_real(torch.as_tensor(w), dtype))), "tmdhip_set_skin_weights")
         # per-term energies [R, NENERGY] followed by the kinetic energies [R] in ONE buffer, so that
         # Integrator.step reads everything back with a single device-to-host copy
         self.comb = torch.zeros(nreplicas * (L.NENERGY + 1), dtype=torch.float64, device=device)
@@ -230,7 +233,13 @@ class Forces:
 
     Extra keyword-only knobs of this implementation
     ----------
-    skin : float          Verlet-list skin in Angstrom (default 1.2)
+    skin : float          Verlet-list skin in Angstrom (default 1.2; the largest pair skin when per-atom skins are on)
+    skin_weights          "mass" (default) | None | array [natoms] in (0, 1]: per-atom share of the skin.  Atom i may
+                          move w_i * skin / 2 before the list is rebuilt and pair (i, j) is listed within
+                          cutoff + (w_i + w_j) * skin / 2 — exactly as safe as one skin for all, but slow (heavy)
+                          atoms stop paying for the room the fast ones need.  "mass": w_i = (m_min / m_i)^0.45,
+                          at least 0.2 (measured on flexible TIP3P: the oxygens' largest displacement is 0.28 of
+                          the hydrogens'); systems with a single mass keep the uniform skin.
     algorithm : str       "auto" | "allpairs" | "celllist"
     switch_mode : str     "reference" (upstream's explicit switching force, extra 1/r,
                           forces.py:410-412) | "exact" (-dE/dr)
@@ -252,6 +261,7 @@ class Forces:
         exclusions=("bonds", "angles", "1-4"),
         *,
         skin=None,
+        skin_weights="mass",
         algorithm="auto",
         switch_mode="reference",
     ):
@@ -294,6 +304,7 @@ class Forces:
         self.switch_dist = switch_dist
         self.exclusions = tuple(exclusions)
         self.skin = skin  # None -> library default
+        self.skin_weights = skin_weights
         self.algorithm = algorithm
         self.switch_mode = switch_mode
         self._excl_csr = build_exclusion_csr(
@@ -302,6 +313,23 @@ class Forces:
         self._engines = {}
         self._box_cache = None
         self._ava_idx = None
+
+    def _skin_weight_array(self):
+        """Per-atom skin weights in (0, 1] as a numpy array, or None for the uniform skin."""
+        sw = self.skin_weights
+        if sw is None:
+            return None
+        if isinstance(sw, str):
+            if sw != "mass":
+                raise ValueError("skin_weights must be 'mass', None or an array of per-atom weights")
+            m = np.asarray(self.par.masses.detach().cpu().numpy(), dtype=np.float64).ravel()
+            if len(m) != self.natoms or not (m > 0).all() or m.min() == m.max():
+                return None
+            return np.maximum((m.min() / m) ** 0.45, 0.2)
+        w = np.asarray(sw, dtype=np.float64).ravel()
+        if len(w) != self.natoms or not ((w > 0) & (w <= 1)).all():
+            raise ValueError("skin_weights: one weight in (0, 1] per atom")
+        return w
 
     def update_atoms(self, parameters, nactive=None):
         """Atomic systems only (no bonded terms, no exclusions): swap in a new atom set — `parameters`
