@@ -109,7 +109,12 @@ def test_native_exchange_and_step_loop_single_rank():
     torch.manual_seed(3)
     vel = maxwell_boltzmann(par.masses, 4000.0, 1)[0].numpy()
     A, B = par.get_AB()
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=dev)
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a port nobody listens on right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     try:
         results = {}
         for native in ("1", "0"):

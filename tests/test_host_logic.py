@@ -205,7 +205,7 @@ def test_replica_fanout_gloo_world2(tmp_path):
     """N>1 path on CPU: two processes over gloo (the GPU run uses the same code over nccl = RCCL)."""
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
     procs = [
         subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT)
@@ -306,6 +306,15 @@ def test_parameters_match_reference_prmtop_fixtures(folder):
     assert sorted(map(tuple, mine.get_exclusions())) == sorted(map(tuple, ref.get_exclusions()))
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (fixed ports collide with sockets of an earlier run in TIME_WAIT)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 _DD_WORKER = r"""
 import os, sys, itertools
 sys.path.insert(0, sys.argv[1])
@@ -375,7 +384,7 @@ def test_halo_exchange_gloo(tmp_path, world):
     to itself across the periodic boundary when a dimension has one brick)."""
     script = tmp_path / "dd_worker.py"
     script.write_text(_DD_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29580 + world), WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
     procs = [
         subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT)
