@@ -381,6 +381,7 @@ def main():
             "entries": int(st2["list_entries"]),
             "skin": st2["skin"],
             "skin_weights": args.skin_weights,
+            "rebuild_chains_left_out": int(st1["chains_skipped"] - st0["chains_skipped"]),
             "capacity_per_atom": int(st2["max_neighbours"]),
             "ncell": list(st2["ncell"]),
         },

@@ -132,6 +132,7 @@ typedef struct tmdhip_stats {
   int32_t overflow;         /* != 0: a list is currently truncated (see tmdhip_check)       */
   int32_t ncell[3];
   double skin;              /* Verlet skin in use (Angstrom)                                */
+  int64_t chains_skipped;   /* MD steps whose rebuild chain the host left out (tmdhip_md_run)  */
 } tmdhip_stats;
 
 int tmdhip_abi_version(void);

@@ -439,3 +439,62 @@ def test_list_overflow_is_replayed_not_raised(monkeypatch, skin_weights):
     assert ferr_t < 2e-3 and ferr_ref < 2e-3
     assert abs(out_t[2][0] - out_ref[2][0]) < 15.0  # temperature (K)
     assert abs(out_t[1][0] - out_ref[1][0]) < 0.01 * abs(out_ref[1][0])  # potential energy
+
+
+def test_rebuild_chain_left_out_and_violation_rewound(monkeypatch):
+    """Chain skipping of `tmdhip_md_run` (the host leaves the five early-exit launches of the rebuild chain out
+    while no atom is near its displacement limit).  (i) Regular operation on a small box (size gate lowered):
+    chains are left out, no violation, same physics as with every chain in place.  (ii) With the "near" report
+    disabled (fraction 2: no atom ever counts as near) the first atom to cross its limit does so in a step without
+    a chain: the violation flag rewinds the batch, it is repeated with every chain, and forces are still those of
+    a fresh evaluation."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(16, seed=2)  # 12 288 atoms
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    monkeypatch.setenv("TMDHIP_LPA", "8")
+    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+
+    def run(skip, near=None):
+        monkeypatch.setenv("TMDHIP_CHAIN_SKIP", "1" if skip else "0")
+        if near is None:
+            monkeypatch.delenv("TMDHIP_DEBUG_CHAIN_NEAR", raising=False)
+        else:
+            monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_NEAR", str(near))
+        s = System(mol.numAtoms, 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        torch.manual_seed(5)
+        s.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        f.compute(s.pos, s.box, s.forces)
+        torch.manual_seed(6)
+        integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+        out = None
+        for _ in range(3):
+            out = integ.step(60)
+        st = f.stats(s.pos)
+        fresh = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        F2 = torch.zeros_like(s.pos)
+        fresh.compute(s.pos, s.box, F2)
+        return out, st, (F2 - s.forces).abs().max().item()
+
+    out0, st0, ferr0 = run(False)
+    out1, st1, ferr1 = run(True)
+    out2, st2, ferr2 = run(True, near=2.0)
+    assert st0["chains_skipped"] == 0 and st1["chains_skipped"] > 60 and st2["chains_skipped"] > 0
+    assert st0["n_rebuilds"] > 5 and st1["n_rebuilds"] > 5
+    for st in (st0, st1, st2):
+        assert st["overflow"] == 0
+    assert ferr0 < 2e-3 and ferr1 < 2e-3 and ferr2 < 2e-3
+    # regular skipping changes nothing but the launches that would have returned at once: same trajectory
+    assert out1[1][0] == out0[1][0] and out1[2][0] == out0[2][0]
+    # the rewound run rebuilt its lists at other steps: same physics, different rounding
+    assert abs(out2[2][0] - out0[2][0]) < 25.0
+    assert abs(out2[1][0] - out0[1][0]) < 0.02 * abs(out0[1][0])

@@ -157,6 +157,7 @@ class Stats(C.Structure):
         ("overflow", C.c_int32),
         ("ncell", C.c_int32 * 3),
         ("skin", C.c_double),
+        ("chains_skipped", C.c_int64),
     ]
 
 

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -223,7 +224,9 @@ __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
 //                 SET flags[p] and CLEAR flags[p^1]; every other kernel of that step only reads flags[p].
 //   F_MAXN        largest neighbour count seen by a build (> capacity: a list was truncated)
 //   F_NREBUILD    rebuild counter
-enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_COUNT = 4 };
+//   F_VIOLATION   a rebuild was requested in a step whose rebuild chain the host had not enqueued (see
+//                 ListCheck::skipped): the forces since then are invalid, the caller rewinds and repeats
+enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_COUNT = 5 };
 
 // Displacement test that drives the rebuilds: the list (cutoff + skin) is valid while no atom has moved
 // further than skin/2 from `ref`; the test runs on the device (in the fused integrator kernel, or in
@@ -236,6 +239,16 @@ struct ListCheck {
   const R *hs2;  // per-atom (half skin)^2, original atom order [N], or null: `hard2` for every atom
   int *flags;
   int parity;
+  // Chain skipping (tmdhip_md_run on large systems).  The five launches of the rebuild chain return at once on
+  // ~8 of 9 steps and still cost ~1.6 us each; the host leaves them out for a step when it knows that in the
+  // step before no atom had used up more than `near_frac2` of its (squared) limit.  It learns that from host-
+  // mapped memory: every atom beyond that fraction stores `seq` into *near_host, and the pair kernel of the
+  // same step publishes `seq` as progress.  Should an atom nevertheless cross its limit in a step without a
+  // chain (`skipped`), F_VIOLATION makes the caller rewind the batch and repeat it with every chain in place.
+  unsigned *near_host;  // null: no reporting
+  unsigned seq;
+  R near_frac2;
+  int skipped;
 };
 
 // (rx, ry, rz) = position - reference position of one atom
@@ -246,7 +259,12 @@ __device__ __forceinline__ void list_check_point(const ListCheck<R> &k, const Pa
   const R dy = min_image(ry, c.box[1], c.invbox[1]);
   const R dz = min_image(rz, c.box[2], c.invbox[2]);
   const R d2 = dx * dx + dy * dy + dz * dz;
-  if (!(d2 <= h2)) k.flags[F_REBUILD0 + k.parity] = 1;  // NaN positions also force a rebuild
+  if (!(d2 <= h2)) {  // NaN positions also force a rebuild
+    k.flags[F_REBUILD0 + k.parity] = 1;
+    if (k.skipped) k.flags[F_VIOLATION] = 1;
+    if (k.near_host) k.near_host[2] = k.seq;  // "this step rebuilds": its successor needs no chain either
+  }
+  if (k.near_host && !(d2 <= h2 * k.near_frac2)) *k.near_host = k.seq;  // host-mapped: only the few fast atoms store
 }
 // squared displacement atom i may reach before the list has to be rebuilt
 template <typename R>
@@ -821,9 +839,12 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
-    double *__restrict__ energies) {
+    double *__restrict__ energies, unsigned *publish, unsigned publish_value) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
+  // tells the host (host-mapped word) that everything enqueued before this launch has completed
+  if (publish && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __shared__ __align__(16) float2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
   for (int t = threadIdx.x; t < kEntryTypes * kEntryTypes; t += blockDim.x) {
     const int ti = t >> 5, tj = t & 31;
@@ -1215,6 +1236,15 @@ struct Replica {
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
   DevBuf sorted_hs;  // per-atom half skins in cell-sorted order (contexts with skin weights)
+  // chain skipping (see ListCheck): host-mapped words {progress, near[2], rebuilds[2]}, sequence number of the last
+  // integrator kernel that ran the displacement test, and what the pair kernel of the current step publishes
+  unsigned *hostpub = nullptr;
+  unsigned seq = 0;
+  bool seq_valid = false;
+  bool prev_skipped = false;
+  unsigned *pub_ptr = nullptr;
+  unsigned pub_val = 0;
+  int64_t chains_skipped = 0;
   DevBuf pos_alt;  // second position buffer of tmdhip_md_run's double-buffered integrator kernel
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf paircount;  // unsigned long long
@@ -1243,6 +1273,7 @@ struct tmdhip_ctx {
   // per-atom Verlet skins (tmdhip_set_skin_weights): half_skin[i] = w_i * skin / 2 and its square, original atom
   // order; empty = skin / 2 for every atom
   DevBuf half_skin, half_skin2;
+  bool no_chain_skip_once = false;  // the next tmdhip_md_run enqueues every rebuild chain (repetition of a rewound batch)
   double mean_list_scale = 1;  // mean list length / length of a list at the largest pair radius (per-atom skins)
   DevBuf escratch;  // nreplicas x kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
   DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
@@ -1486,6 +1517,10 @@ ListCheck<R> make_check(const tmdhip_ctx *ctx, Replica &rp) {
   k.ref = rp.ref.as<R>();
   k.hard2 = (R)(0.25 * ctx->skin * ctx->skin);
   k.hs2 = ctx->half_skin2.p ? ctx->half_skin2.as<R>() : nullptr;
+  k.near_host = nullptr;
+  k.seq = 0;
+  k.near_frac2 = R(0);
+  k.skipped = 0;
   k.flags = rp.flags.as<int>();
   k.parity = (int)(rp.step & 1);
   return k;
@@ -1519,7 +1554,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   hipLaunchKernelGGL((list_pair_fast_f32_kernel<L, A, B, ENERGY, S>), dim3((blocks + 7) / 8 * 8), dim3(256), shfast, st, n, \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
                      rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,                   \
-                     ctx->escratch.as<double>())
+                     ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val)
 #define TMD_LAUNCH_FAST(L)                  \
   if (lj && el) {                           \
     TMD_LAUNCH_FAST_T(L, true, true);       \
@@ -1650,6 +1685,7 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
 }
 
 constexpr int kPrechecked = 1 << 16;  // internal compute flag: displacement test already enqueued
+constexpr int kSkipChain = 1 << 18;   // internal compute flag: the host leaves the rebuild chain out for this step
 constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
 
 template <typename R>
@@ -1700,6 +1736,11 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     force = 1;
   }
   for (int attempt = 0; attempt < 8; ++attempt) {
+    if (!force && (flags & kSkipChain)) {  // (the integrator kernel has run this step's test with `skipped` set)
+      rp.step++;
+      rp.chains_skipped++;
+      break;
+    }
     TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked)));
     rp.step++;
     if (!force) break;
@@ -1807,10 +1848,42 @@ void launch_md_step_bonded(const MdStepArgs<R> &a, const PairConsts<R> &c, const
 #undef TMD_MSB
 }
 
+// ---- chain skipping (ListCheck) --------------------------------------------------------------------
+constexpr int64_t kChainSkipMinEntries = 20'000'000;  // list slots below which the pair kernel is too short to hide the host
+constexpr double kChainSkipNear = 0.75;  // "near": beyond this fraction of the displacement limit (0.15 A of room at
+                                         // skin 1.2: 2.2 x the largest per-step move seen in the water box, 9.5
+                                         // standard deviations of a hydrogen's thermal velocity at 300 K)
+
+// the launch conditions of list_pair_fast_f32_kernel (the kernel that publishes progress), see launch_list_pair
+template <typename R>
+bool lean_pair_kernel(const tmdhip_ctx *ctx, const PairConsts<R> &c) {
+  const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
+  return std::is_same<R, float>::value && only_lj_el && ctx->d.ntypes <= kEntryTypes && ctx->d.natoms <= (1 << 20);
+}
+
+// spin until the device has published sequence number `target` (wrap-around safe); false after 0.2 s
+bool wait_published(volatile unsigned *hp, unsigned target) {
+  if ((int)(hp[0] - target) >= 0) return true;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    if ((int)(hp[0] - target) >= 0) return true;
+    __builtin_ia32_pause();
+    if ((spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;
+  }
+}
+
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   using R4 = typename Vec<R>::T4;
   const int n = ctx->d.natoms;
+  // TMDHIP_CHAIN_SKIP=0 switches the feature off; the two DEBUG knobs let a test reach the violation + rewind path
+  // on a small box (minimum list size, "near" fraction: > 1 = an atom is never reported near its limit)
+  const char *e_on = std::getenv("TMDHIP_CHAIN_SKIP"), *e_min = std::getenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES"),
+             *e_near = std::getenv("TMDHIP_DEBUG_CHAIN_NEAR");
+  const bool chain_skip_on = !(e_on && std::atoi(e_on) == 0) && !ctx->no_chain_skip_once;
+  const int64_t chain_min_entries = e_min ? std::atoll(e_min) : kChainSkipMinEntries;
+  const double chain_near = e_near ? std::atof(e_near) : kChainSkipNear;
+  ctx->no_chain_skip_once = false;
   const int nrep = (int)ctx->rep.size();
   const bool langevin = d->vcoeff_dev != nullptr;
   const size_t stride = (size_t)n * 3;
@@ -1925,6 +1998,40 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       const bool zeroed = a.f_zero != nullptr;
       a.row0 = (uint64_t)r * (uint64_t)n;
       a.chk = make_check<R>(ctx, rp);
+      // Chain skipping (ListCheck): on large lists the host stays one step behind the device — it waits until the
+      // pair kernel of the previous step has started (45 us of kernel time are then still ahead of it) — and
+      // leaves the rebuild chain out when no atom was near its limit in that step.  Never on the first step of a
+      // call (the caller may have moved atoms in between), nor in the repetition of a rewound batch.
+      bool skip_chain = false;
+      const bool pace = check && chain_skip_on && (int64_t)n * rp.lg.maxn >= chain_min_entries && lean_pair_kernel(ctx, c);
+      if (pace) {
+        if (!rp.hostpub) {
+          TMD_HIP(hipHostMalloc((void **)&rp.hostpub, 8 * sizeof(unsigned), hipHostMallocMapped));
+          for (int w = 0; w < 8; ++w) rp.hostpub[w] = 0u;
+          rp.seq = 0;
+          rp.seq_valid = false;
+        }
+        volatile unsigned *hp = rp.hostpub;
+        if (rp.seq_valid && it > 0 && wait_published(hp, rp.seq)) {
+          // no chain when nobody was near its limit in the previous step — or when that step rebuilt the list
+          // (with its chain in place: every displacement is one step old now)
+          const bool near = hp[1 + (rp.seq & 1u)] == rp.seq, rebuilt = hp[3 + (rp.seq & 1u)] == rp.seq;
+          skip_chain = !near || (rebuilt && !rp.prev_skipped);
+        }
+        rp.prev_skipped = skip_chain;
+        rp.seq += 1;
+        if (rp.seq == 0) rp.seq = 1;  // 0 = nothing published yet
+        a.chk.near_host = rp.hostpub + 1 + (rp.seq & 1u);
+        a.chk.seq = rp.seq;
+        a.chk.near_frac2 = (R)(chain_near * chain_near);
+        a.chk.skipped = skip_chain ? 1 : 0;
+        rp.seq_valid = true;
+        rp.pub_ptr = rp.hostpub;
+        rp.pub_val = rp.seq;
+      } else {
+        rp.seq_valid = false;
+        rp.pub_ptr = nullptr;
+      }
       a.sorted = rp.sorted.as<R4>();
       a.inv = rp.inv.as<int>();
       a.pos_in = a.pos_out = cur[r];
@@ -1961,7 +2068,9 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         rp.n_compute++;
         if (list) {
           const int rc = compute_list<R>(ctx, rp, pos, box, f, en,
-                                         flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0), st);
+                                         flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0) |
+                                             (skip_chain ? kSkipChain : 0), st);
+          rp.pub_ptr = nullptr;
           if (rc == kFallbackAllPairs) {
             ctx->algorithm = TMDHIP_ALGO_ALLPAIRS;
             list = false;
@@ -2099,7 +2208,11 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
 
 void tmdhip_destroy(tmdhip_ctx *ctx) {
   if (!ctx) return;
-  for (auto &rp : ctx->rep) rp.release();
+  for (auto &rp : ctx->rep) {
+    if (rp.hostpub) (void)hipHostFree(rp.hostpub);
+    rp.hostpub = nullptr;
+    rp.release();
+  }
   for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->half_skin, &ctx->half_skin2, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all, &ctx->snap})
     b->release();
   for (auto &ev : ctx->events) {
@@ -2251,6 +2364,7 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   out->n_compute = rp.n_compute;
   out->n_rebuilds = h[F_NREBUILD];
   out->skin = ctx->skin;
+  out->chains_skipped = rp.chains_skipped;
   out->pairs_in_cutoff = (int64_t)pc;
   out->algorithm = ctx->algorithm;
   out->max_neighbours = rp.lg.maxn;
@@ -2268,6 +2382,15 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
 
 // verdict on the list flags of one replica (already on the host): 0 valid, 1 repeat the work, < 0 error
 static int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
+  if (h[F_VIOLATION]) {
+    // an atom crossed its displacement limit in a step whose rebuild chain had been left out (ListCheck)
+    (void)hipMemsetAsync(rp.flags.as<int>() + F_VIOLATION, 0, sizeof(int), st);
+    ctx->no_chain_skip_once = true;
+    rp.seq_valid = false;
+    rp.box[0] = -1;  // re-plan + rebuild
+    last_error() = "a neighbour list outlived its skin in a step without a rebuild chain (results since the last check are invalid)";
+    if (h[F_MAXN] <= rp.lg.maxn) return 1;
+  }
   if (h[F_MAXN] <= rp.lg.maxn) return 0;
   // a device-side rebuild truncated a list: grow the capacity and force a rebuild on the next call
   const int want = (int)(h[F_MAXN] * 1.25) + 16;
@@ -2407,6 +2530,7 @@ int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream)
   TMD_HIP(hipMemcpyAsync(desc->vel_dev, sn + padded, bytes, hipMemcpyDeviceToDevice, st));
   TMD_HIP(hipMemcpyAsync(desc->forces_dev, sn + 2 * padded, bytes, hipMemcpyDeviceToDevice, st));
   for (auto &rp : ctx->rep) rp.box[0] = -1;  // re-plan + rebuild from the restored positions
+  ctx->no_chain_skip_once = true;            // and no chain is left out while the batch is repeated
   return 0;
 }
 

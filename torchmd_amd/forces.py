@@ -694,6 +694,7 @@ class Forces:
             "overflow": st.overflow,
             "ncell": tuple(st.ncell),
             "skin": st.skin,
+            "chains_skipped": int(st.chains_skipped),
         }
 
     def enable_timing(self, pos, on=True, every=1):
