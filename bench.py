@@ -243,11 +243,20 @@ def cpu_baseline(par, system, box, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 50:
             break
+    ref = None  # the reference's OWN Forces + Integrator with a sparse pair list, timed in the build container
+    try:         # (tools/ref_cpu_sparse.py; /root/reference does not exist on the GPU box): recorded beside the port
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_ref_cpu_sparse.json")) as fh:
+            r = json.load(fh)
+        ref = {"value": r["ns_per_day"], "unit": "ns/day", "s_per_step": r["s_per_step"], "cores": r["threads"],
+               "kind": "reference", "where": r["host"], "source": "profiles/r02_ref_cpu_sparse.json"}
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "value": ns_per_day(n, el),
         "unit": "ns/day",
         "cores": torch.get_num_threads(),
         "kind": "port",
+        "reference_in_build_container": ref,
         "source": "oracle (pinned port of the reference arithmetic; /root/reference does not exist on the GPU box)",
         "s_per_step": el / n,
         "sample": f"{n} MD steps of the same {pos.shape[1]}-atom box (oracle/torchmd_oracle.py md_step, "
