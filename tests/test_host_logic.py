@@ -29,14 +29,17 @@ def test_capi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.tmdhip_abi_version() == _lib.ABI_VERSION
     # struct layouts agree with the C compiler's view of the header
-    src = '#include "tmdhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n", sizeof(tmdhip_nonbonded_desc), sizeof(tmdhip_bonded_desc), sizeof(tmdhip_stats));return 0;}'
+    src = ('#include "tmdhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", '
+           "sizeof(tmdhip_nonbonded_desc), sizeof(tmdhip_bonded_desc), sizeof(tmdhip_stats), sizeof(tmdhip_md_desc), "
+           "sizeof(tmdhip_dd_desc));return 0;}")
     exe = os.path.join(ROOT, "tests", ".sizeof_probe")
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     try:
         sizes = [int(x) for x in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
     finally:
         os.remove(exe)
-    assert sizes == [C.sizeof(_lib.NonbondedDesc), C.sizeof(_lib.BondedDesc), C.sizeof(_lib.Stats)]
+    assert sizes == [C.sizeof(_lib.NonbondedDesc), C.sizeof(_lib.BondedDesc), C.sizeof(_lib.Stats),
+                     C.sizeof(_lib.MdDesc), C.sizeof(_lib.DdDesc)]
 
 
 def test_capi_argument_validation_without_gpu():
@@ -57,6 +60,21 @@ def test_capi_argument_validation_without_gpu():
     assert lib.tmdhip_md_run(None, None, None) < 0
     assert lib.tmdhip_check(None, 0, None) < 0
     assert lib.tmdhip_timing_enable(None, 1) < 0
+    assert lib.tmdhip_set_skin_weights(None, None) < 0
+    # domain-decomposition entry points
+    assert lib.tmdhip_dd_step(9, 1, None, None, None, None, None, 0.1, 0.0, 0, 0, 3, None, None, None) < 0
+    assert "dtype" in _lib.last_error()
+    assert lib.tmdhip_dd_step(_lib.F32, 4, None, None, None, None, None, 0.1, 0.0, 0, 0, 0, None, None, None) < 0  # no phase
+    assert lib.tmdhip_dd_step(_lib.F32, 0, None, None, None, None, None, 0.1, 0.0, 0, 0, 3, None, None, None) == 0  # nothing to do
+    assert lib.tmdhip_halo_pack(_lib.F32, -1, None, None, None, None, None) < 0
+    assert lib.tmdhip_halo_pack(_lib.F32, 0, None, None, None, None, None) == 0
+    assert lib.tmdhip_halo_pack(_lib.F32, 5, None, None, None, None, None) < 0 and "null" in _lib.last_error()
+    assert lib.tmdhip_comm_exchange(None, _lib.F32, None, None, None, None, 3, None) < 0
+    assert lib.tmdhip_comm_create(None, b"", None, 0, 1) < 0
+    assert lib.tmdhip_comm_unique_id(b"", None) < 0
+    assert lib.tmdhip_dd_run(None, None, None, None, None) < 0
+    assert lib.tmdhip_dd_reset(None) < 0
+    lib.tmdhip_comm_destroy(None)  # a no-op
 
 
 def test_no_cpu_fallback():
