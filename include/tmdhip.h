@@ -216,8 +216,10 @@ int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, 
  * every pair within cutoff + skin is listed.  With weights w_i in (0, 1] (real [natoms], host) atom i may move
  * s_i = w_i * skin/2 and pair (i, j) is listed within cutoff + s_i + s_j — equally exact (a pair that is not
  * listed cannot come within the cutoff before one of its atoms exceeds its s), but slow atoms (heavy ones: a
- * water oxygen moves 0.28 of what its hydrogens move) stop paying for the skin the fast ones need.  NULL
- * restores the uniform skin.  Synchronises the device; the next compute re-plans and rebuilds. */
+ * water oxygen moves 0.28 of what its hydrogens move) stop paying for the skin the fast ones need.  Inside
+ * tmdhip_md_run, where velocities are known, a rebuild sizes s_i from the atom's speed as well (0.8 of the static
+ * share + the path it covers in 6 fs, at most 1.2 x the largest static share; TMDHIP_VSKIN=0 switches that off).
+ * NULL restores the uniform skin.  Synchronises the device; the next compute re-plans and rebuilds. */
 int tmdhip_set_skin_weights(tmdhip_ctx *ctx, const void *weights_host);
 
 /* Drop the neighbour list of a replica: the next tmdhip_compute_nonbonded rebuilds it (used after the

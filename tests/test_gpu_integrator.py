@@ -256,9 +256,12 @@ def test_wrapper_vs_reference_golden(prec, case):
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
-def test_fused_md_run_equals_stepwise_loop(prec):
+def test_fused_md_run_equals_stepwise_loop(prec, monkeypatch):
     """tmdhip_md_run (fused half-kick / drift / displacement-test kernels, whole loop in C) reproduces the
-    step-by-step Python loop (first_vv -> compute -> langevin_second_vv) bit for bit, incl. the noise."""
+    step-by-step Python loop (first_vv -> compute -> langevin_second_vv) bit for bit, incl. the noise.
+    (Velocity-dependent skins off: only the fused loop knows velocities at a rebuild, so the two would rebuild
+    at different steps and sum a list's entries in a different order.)"""
+    monkeypatch.setenv("TMDHIP_VSKIN", "0")
     from torchmd_amd.builders import tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import Integrator, maxwell_boltzmann

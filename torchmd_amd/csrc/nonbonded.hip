@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -356,7 +357,8 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
                                     int *__restrict__ order, int *__restrict__ inv,
                                     typename Vec<R>::T4 *__restrict__ sorted, int *__restrict__ stype,
                                     R *__restrict__ ref, const R *__restrict__ half_skin,
-                                    R *__restrict__ sorted_hs, const int *flag) {
+                                    R *__restrict__ sorted_hs, const R *__restrict__ vel, R vs_floor, R vs_time,
+                                    R vs_cap, R *__restrict__ hs2_dyn, const int *flag) {
   if (*flag == 0) return;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
@@ -375,7 +377,20 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
   v.w = qs[me];
   sorted[dst] = v;
   stype[dst] = types[me];
-  if (half_skin) sorted_hs[dst] = half_skin[me];
+  if (half_skin) {
+    // this list's half skin of the atom: its static share, or — inside an MD run, where the velocity is known —
+    // a reduced floor plus the distance it covers in `vs_time` at its present speed, capped at vs_cap times the
+    // largest static share (the cells are sized for that).  Any choice is safe: the displacement test uses the
+    // same number (hs2_dyn); a good choice lets fast atoms go further before they force a rebuild while slow
+    // ones keep short lists.
+    R h = half_skin[me];
+    if (vel) {
+      const R vx = vel[3 * me + 0], vy = vel[3 * me + 1], vz = vel[3 * me + 2];
+      h = min(vs_floor * h + vs_time * sqrt(vx * vx + vy * vy + vz * vz), vs_cap);
+    }
+    sorted_hs[dst] = h;
+    if (hs2_dyn) hs2_dyn[me] = h * h;
+  }
   ref[3 * me + 0] = v.x;
   ref[3 * me + 1] = v.y;
   ref[3 * me + 2] = v.z;
@@ -1236,6 +1251,8 @@ struct Replica {
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
   DevBuf sorted_hs;  // per-atom half skins in cell-sorted order (contexts with skin weights)
+  DevBuf hs2_dyn;    // (half skin)^2 of the CURRENT list per atom, original order: what the displacement test uses
+  const void *skin_vel = nullptr;  // velocities of this replica while tmdhip_md_run is enqueuing (velocity-dependent skins)
   // chain skipping (see ListCheck): host-mapped words {progress, near[2], rebuilds[2]}, sequence number of the last
   // integrator kernel that ran the displacement test, and what the pair kernel of the current step publishes
   unsigned *hostpub = nullptr;
@@ -1249,7 +1266,7 @@ struct Replica {
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf paircount;  // unsigned long long
   void release() {
-    for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs,
+    for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
                       &nlist, &nneigh, &flags, &paircount, &pos_alt})
       b->release();
   }
@@ -1274,6 +1291,8 @@ struct tmdhip_ctx {
   // order; empty = skin / 2 for every atom
   DevBuf half_skin, half_skin2;
   bool no_chain_skip_once = false;  // the next tmdhip_md_run enqueues every rebuild chain (repetition of a rewound batch)
+  // velocity-dependent skins inside tmdhip_md_run (place_sorted_kernel): s_i = min(floor * static_i + time * |v_i|, cap)
+  double vskin_floor = 0.8, vskin_time = 0, vskin_cap = 1.2, vskin_cap_len = 0;
   double mean_list_scale = 1;  // mean list length / length of a list at the largest pair radius (per-atom skins)
   DevBuf escratch;  // nreplicas x kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
   DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
@@ -1516,7 +1535,7 @@ ListCheck<R> make_check(const tmdhip_ctx *ctx, Replica &rp) {
   ListCheck<R> k;
   k.ref = rp.ref.as<R>();
   k.hard2 = (R)(0.25 * ctx->skin * ctx->skin);
-  k.hs2 = ctx->half_skin2.p ? ctx->half_skin2.as<R>() : nullptr;
+  k.hs2 = ctx->half_skin2.p ? (rp.hs2_dyn.p ? rp.hs2_dyn.as<R>() : ctx->half_skin2.as<R>()) : nullptr;
   k.near_host = nullptr;
   k.seq = 0;
   k.near_frac2 = R(0);
@@ -1619,7 +1638,10 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.inv.ensure(sizeof(int) * n));
   TMD_TRY(rp.sorted.ensure(sizeof(R4) * n));
   TMD_TRY(rp.stype.ensure(sizeof(int) * n));
-  if (ctx->half_skin.p) TMD_TRY(rp.sorted_hs.ensure(ctx->real_size * (size_t)n));
+  if (ctx->half_skin.p) {
+    TMD_TRY(rp.sorted_hs.ensure(ctx->real_size * (size_t)n));
+    TMD_TRY(rp.hs2_dyn.ensure(ctx->real_size * (size_t)n));
+  }
   TMD_TRY(rp.ref.ensure(sizeof(R) * 3 * n));
   TMD_TRY(rp.nneigh.ensure(sizeof(int) * n));
   // lanes per atom from the MEAN list length (capacities are sized for the longest lists); fixed once a list exists
@@ -1660,7 +1682,8 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
   hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(),
                      rp.cell_start.as<int>(), rp.order_tmp.as<int>(), pos, ctx->qs.as<R>(), ctx->types.as<int>(),
                      rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(),
-                     ctx->half_skin.as<R>(), rp.sorted_hs.as<R>(), flag);
+                     ctx->half_skin.as<R>(), rp.sorted_hs.as<R>(), ctx->vskin_time > 0 ? (const R *)rp.skin_vel : nullptr,
+                     (R)ctx->vskin_floor, (R)ctx->vskin_time, (R)ctx->vskin_cap_len, rp.hs2_dyn.as<R>(), flag);
   if (!prechecked)
     hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.order.as<int>(),
                        rp.sorted.as<R4>(), flag);
@@ -1997,6 +2020,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       a.f_zero = (first && !list && ctx->d.terms != 0) ? f : nullptr;
       const bool zeroed = a.f_zero != nullptr;
       a.row0 = (uint64_t)r * (uint64_t)n;
+      rp.skin_vel = a.vel;  // a rebuild in this step sizes the skins from the current velocities
       a.chk = make_check<R>(ctx, rp);
       // Chain skipping (ListCheck): on large lists the host stays one step behind the device — it waits until the
       // pair kernel of the previous step has started (45 us of kernel time are then still ahead of it) — and
@@ -2346,7 +2370,19 @@ int tmdhip_set_skin_weights(tmdhip_ctx *ctx, const void *weights_host) {
     TMD_HIP(hipMemcpy(ctx->half_skin.p, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     TMD_HIP(hipMemcpy(ctx->half_skin2.p, hs2.data(), sizeof(double) * n, hipMemcpyHostToDevice));
   }
-  ctx->rlist = ctx->d.cutoff + ctx->skin * wmax;  // the largest pair radius: sizes the cells and the stencil reach
+  // velocity-dependent skins: TMDHIP_VSKIN = "floor,time_fs,cap" (defaults 0.8, 6, 1.2; "0" switches them off)
+  ctx->vskin_floor = 0.8, ctx->vskin_cap = 1.2;
+  double time_fs = 6.0;
+  if (const char *e = std::getenv("TMDHIP_VSKIN")) {
+    double a = 0, b = 0, cc = 0;
+    const int got = std::sscanf(e, "%lf,%lf,%lf", &a, &b, &cc);
+    if (got == 3 && a > 0 && a <= 1 && b >= 0 && cc >= 1 && cc <= 2) ctx->vskin_floor = a, time_fs = b, ctx->vskin_cap = cc;
+    else if (got >= 1 && a == 0) time_fs = 0;
+  }
+  ctx->vskin_time = time_fs / 48.88821;  // internal time unit (integrator.py:4)
+  if (!(ctx->vskin_time > 0)) ctx->vskin_cap = 1.0;
+  ctx->vskin_cap_len = 0.5 * ctx->skin * wmax * ctx->vskin_cap;
+  ctx->rlist = ctx->d.cutoff + 2.0 * ctx->vskin_cap_len;  // the largest pair radius: sizes the cells and the stencil reach
   ctx->mean_list_scale = std::pow((ctx->d.cutoff + ctx->skin * wsum / n) / ctx->rlist, 3.0);
   return 0;
 }
@@ -2481,7 +2517,9 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     }
     ctx->snap_bytes = bytes;
   }
-  return ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
+  const int rc = ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
+  for (auto &rp : ctx->rep) rp.skin_vel = nullptr;  // rebuilds outside an MD run know no velocities: static skins
+  return rc;
 }
 
 int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev, const double *energies_dev,
