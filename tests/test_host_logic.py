@@ -618,3 +618,30 @@ def test_bench_self_launch_gloo_world2():
                          text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     assert json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_skin_weight_rules():
+    """Per-atom skin weights (host logic): by mass with exponent 0.45 and a floor of 0.2, none for single-mass
+    systems, explicit arrays validated."""
+    import numpy as np
+    import torch
+
+    from _golden import GoldenParameters, load
+    from torchmd_amd.forces import Forces
+
+    par = GoldenParameters(load("water291"), torch.float32)
+    f = Forces(par, terms=["lj", "electrostatics"], cutoff=7.3)
+    w = f._skin_weight_array()
+    m = par.masses.numpy().ravel()
+    assert w.shape == (291,) and w.max() == 1.0 and np.all(w[m < 2] == 1.0)
+    assert np.allclose(w[m > 2], (m.min() / m[m > 2]) ** 0.45) and 0.27 < w[m > 2][0] < 0.30
+    assert Forces(par, terms=["lj"], cutoff=7.3, skin_weights=None)._skin_weight_array() is None
+    ones = Forces(par, terms=["lj"], cutoff=7.3, skin_weights=np.full(291, 0.5))._skin_weight_array()
+    assert np.all(ones == 0.5)
+    for bad in (np.full(290, 0.5), np.full(291, 1.5), np.zeros(291), "speed"):
+        with pytest.raises(ValueError):
+            Forces(par, terms=["lj"], cutoff=7.3, skin_weights=bad)._skin_weight_array()
+    # one mass for every atom: nothing to weigh
+    par1 = GoldenParameters(load("water291"), torch.float32)
+    par1.masses = torch.full_like(par1.masses, 12.0)
+    assert Forces(par1, terms=["lj"], cutoff=7.3)._skin_weight_array() is None
