@@ -711,11 +711,14 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
     const int *__restrict__ order, int ntypes, const typename Vec<R>::T2 *__restrict__ tab,
     const unsigned *__restrict__ nlist, const int *__restrict__ nneigh, int maxn, PairConsts<R> c,
     R *__restrict__ forces, int overwrite, double *__restrict__ energies,
-    unsigned long long *__restrict__ paircount) {
+    unsigned long long *__restrict__ paircount, unsigned *publish, unsigned publish_value) {
   using R4 = typename Vec<R>::T4;
   using R2 = typename Vec<R>::T2;
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
+  // tells the host (host-mapped word) that everything enqueued before this launch has completed
+  if (publish && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   extern __shared__ __align__(16) unsigned char smem[];
   R2 *stab = reinterpret_cast<R2 *>(smem);
   for (int t = threadIdx.x; t < ntypes * ntypes; t += blockDim.x) stab[t] = tab[t];
@@ -1601,7 +1604,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   hipLaunchKernelGGL((list_pair_kernel<R, ENERGY, L, F>), dim3(blocks), dim3(256), shmem, st, n,        \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,          \
                      ctx->tab.as<R2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
-                     overwrite, ctx->escratch.as<double>(), paircount)
+                     overwrite, ctx->escratch.as<double>(), paircount, rp.pub_ptr, rp.pub_val)
   // the generic kernel's branch-free FAST=1 body hard-codes LJ + electrostatics (krf = 0: plain Coulomb)
   const bool fast_generic =
       fast && !c.switch_on && !ENERGY && c.terms == (TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS);
@@ -1877,13 +1880,6 @@ constexpr double kChainSkipNear = 0.75;  // "near": beyond this fraction of the 
                                          // skin 1.2: 2.2 x the largest per-step move seen in the water box, 9.5
                                          // standard deviations of a hydrogen's thermal velocity at 300 K)
 
-// the launch conditions of list_pair_fast_f32_kernel (the kernel that publishes progress), see launch_list_pair
-template <typename R>
-bool lean_pair_kernel(const tmdhip_ctx *ctx, const PairConsts<R> &c) {
-  const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
-  return std::is_same<R, float>::value && only_lj_el && ctx->d.ntypes <= kEntryTypes && ctx->d.natoms <= (1 << 20);
-}
-
 // spin until the device has published sequence number `target` (wrap-around safe); false after 0.2 s
 bool wait_published(volatile unsigned *hp, unsigned target) {
   if ((int)(hp[0] - target) >= 0) return true;
@@ -2027,7 +2023,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       // leaves the rebuild chain out when no atom was near its limit in that step.  Never on the first step of a
       // call (the caller may have moved atoms in between), nor in the repetition of a rewound batch.
       bool skip_chain = false;
-      const bool pace = check && chain_skip_on && (int64_t)n * rp.lg.maxn >= chain_min_entries && lean_pair_kernel(ctx, c);
+      const bool pace = check && chain_skip_on && (int64_t)n * rp.lg.maxn >= chain_min_entries;
       if (pace) {
         if (!rp.hostpub) {
           TMD_HIP(hipHostMalloc((void **)&rp.hostpub, 8 * sizeof(unsigned), hipHostMallocMapped));
