@@ -501,3 +501,44 @@ def test_rebuild_chain_left_out_and_violation_rewound(monkeypatch):
     # the rewound run rebuilt its lists at other steps: same physics, different rounding
     assert abs(out2[2][0] - out0[2][0]) < 25.0
     assert abs(out2[1][0] - out0[1][0]) < 0.02 * abs(out0[1][0])
+
+
+def test_rebuild_chain_left_out_with_two_list_replicas(monkeypatch):
+    """Chain skipping with two replicas on the cell-list path (each has its own list, flags and progress words):
+    bit-identical to the run with every chain in place."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(12, seed=3)  # 5 184 atoms
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    rng = np.random.default_rng(0)
+    pos2 = np.stack([pos, pos + rng.normal(0, 0.02, size=pos.shape)], axis=2)  # two slightly different replicas
+
+    def run(skip):
+        monkeypatch.setenv("TMDHIP_CHAIN_SKIP", "1" if skip else "0")
+        s = System(mol.numAtoms, 2, dt, dev)
+        s.set_positions(pos2)
+        s.set_box(np.stack([box, box], axis=1))
+        torch.manual_seed(5)
+        s.set_velocities(maxwell_boltzmann(par.masses, 300.0, 2))
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        f.compute(s.pos, s.box, s.forces)
+        torch.manual_seed(6)
+        integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+        for _ in range(2):
+            out = integ.step(50)
+        st = [f.stats(s.pos, r) for r in range(2)]
+        return out, st, s.pos.clone(), s.vel.clone()
+
+    out0, st0, p0, v0 = run(False)
+    out1, st1, p1, v1 = run(True)
+    assert all(st["chains_skipped"] == 0 for st in st0) and all(st["chains_skipped"] > 30 for st in st1)
+    assert all(st["n_rebuilds"] > 3 and st["overflow"] == 0 for st in st0 + st1)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+    assert (p0[0] - p0[1]).abs().max().item() > 1e-3
