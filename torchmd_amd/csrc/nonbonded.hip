@@ -1903,6 +1903,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   const int64_t chain_min_entries = e_min ? std::atoll(e_min) : kChainSkipMinEntries;
   const double chain_near = e_near ? std::atof(e_near) : kChainSkipNear;
   ctx->no_chain_skip_once = false;
+  bool pace_timed_out = false;  // the device did not report within wait_published's limit: no more waiting in this call
   const int nrep = (int)ctx->rep.size();
   const bool langevin = d->vcoeff_dev != nullptr;
   const size_t stride = (size_t)n * 3;
@@ -2032,7 +2033,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
           rp.seq_valid = false;
         }
         volatile unsigned *hp = rp.hostpub;
-        if (rp.seq_valid && it > 0 && wait_published(hp, rp.seq)) {
+        if (rp.seq_valid && it > 0 && !pace_timed_out && !wait_published(hp, rp.seq)) pace_timed_out = true;
+        if (rp.seq_valid && it > 0 && !pace_timed_out) {
           // no chain when nobody was near its limit in the previous step — or when that step rebuilt the list
           // (with its chain in place: every displacement is one step old now)
           const bool near = hp[1 + (rp.seq & 1u)] == rp.seq, rebuilt = hp[3 + (rp.seq & 1u)] == rp.seq;
