@@ -542,3 +542,49 @@ def test_rebuild_chain_left_out_with_two_list_replicas(monkeypatch):
     assert all(st["n_rebuilds"] > 3 and st["overflow"] == 0 for st in st0 + st1)
     assert torch.equal(p0, p1) and torch.equal(v0, v1)
     assert (p0[0] - p0[1]).abs().max().item() > 1e-3
+
+
+def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
+    """Exactness of the skin policy over a trajectory: per-atom skins by mass, skins sized from the velocities at
+    every rebuild and rebuild chains left out.  After every few MD steps the number of pairs inside the cutoff
+    found through the CURRENT list (aged by several steps, no rebuild forced) must equal the oracle's count at
+    those positions — a pair missing from a list would show — and the forces must be those of a fresh evaluation."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(16, seed=7)  # 12 288 atoms
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    monkeypatch.setenv("TMDHIP_LPA", "8")
+    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    s = System(mol.numAtoms, 1, dt, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    torch.manual_seed(11)
+    s.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
+    f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+    f.compute(s.pos, s.box, s.forces)
+    integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+    integ.step(150)  # melt the lattice start
+    excl = orc.exclusion_pairs(par)
+    aged = 0
+    for k in range(12):
+        r0 = f.stats(s.pos)["n_rebuilds"]
+        integ.step(4)
+        n_gpu = f.count_pairs(s.pos, s.box)[0]  # displacement test only: the list of the MD run is used as it is
+        aged += f.stats(s.pos)["n_rebuilds"] == r0
+        p = s.pos.detach().cpu()
+        pairs = orc.candidate_pairs(p[0].double().numpy(), box, 9.3, excl)
+        _, Fo, npairs = orc.compute(par, p, s.box.cpu(), ["lj", "electrostatics"], pairs=pairs, cutoff=9.0, rfa=True)
+        assert n_gpu == npairs[0], (k, n_gpu, npairs)
+    st = f.stats(s.pos)
+    assert aged >= 3 and st["chains_skipped"] > 20 and st["overflow"] == 0
+    fresh = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist", skin_weights=None)
+    F2 = torch.zeros_like(s.pos)
+    fresh.compute(s.pos, s.box, F2)
+    assert (F2 - s.forces).abs().max().item() < 2e-3
