@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void list_pair_kernel(
 //   force scale factored as  rinv2 * ((a12 rinv6 + b6) rinv6 - qq rinv) + qq 2 krf   (9 ops)
 // Same decision arithmetic (bit-exact) as pair_math.h.  Terms: LJ and/or electrostatics (plain Coulomb or
 // reaction field), optionally the LJ switching function (SWITCH) and the per-term energies (ENERGY);
-// repulsion terms, fp64, more than 16 LJ classes and pair counting take list_pair_kernel.
+// repulsion terms, fp64, more than 32 LJ classes and pair counting take list_pair_kernel.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // k = round-half-even(d / box) by the magic-number trick: fma(d, 1/box, 1.5*2^23) - 1.5*2^23 is exact
@@ -1042,7 +1042,7 @@ struct MdStepArgs {
   const R *mass, *vcoeff;
   R dt, half_dt, gamma;
   uint64_t seed, noise_step, row0;
-  ListCheck<R> chk;  // displacement test that drives rebuilds / prunes (CHECK variants)
+  ListCheck<R> chk;  // displacement test that drives the rebuilds (CHECK variants)
   typename Vec<R>::T4 *sorted;
   const int *inv;
   const R *qs;
