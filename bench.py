@@ -168,8 +168,9 @@ def run_c5(args, rank, world, local_rank, device, launched):
         t0 = time.perf_counter()
         ds.step(args.steps, timestep_fs=TIMESTEP_FS, gamma_ps=1.0, T=85.0, seed=3)
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0  # this rank's K steps are complete; the slowest rank is the job's time
         fan.barrier()
-        elapsed = fan.max_over_ranks(time.perf_counter() - t0)
+        elapsed = fan.max_over_ranks(elapsed)
         d = next(iter(ds.domains.values()))
         info = torch.tensor([d.nown, d.local_pos.shape[1] - d.nown], dtype=torch.float64, device=device)
         allinfo = [torch.empty_like(info) for _ in range(world)]
@@ -334,8 +335,8 @@ def main():
     t0 = time.perf_counter()
     ekin, epot, temp = integ.step(args.steps)
     torch.cuda.synchronize()
-    fan.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0  # this rank's K steps are complete (barrier + synchronize in front, synchronize
+    fan.barrier()                       # + barrier behind); the job's time is the slowest rank's
     elapsed = fan.max_over_ranks(elapsed)
     pair_ms, pair_launches = forces.read_timing(system.pos, reset=True)
     forces.enable_timing(system.pos, False)
