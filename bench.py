@@ -328,7 +328,8 @@ def main():
     # HIP events around every 16th launch of the pair kernel, spread over the whole timed region (an event
     # pair costs ~3 us of stream time: timing every launch slowed the loop from 84 to 91 us/step)
     stride = timing_stride(args.steps)
-    forces.enable_timing(system.pos, True, every=stride)
+    # short runs: exactly 8 timed launches (every event pair costs stream time that the step loop pays)
+    forces.enable_timing(system.pos, True, every=stride, limit=8 if args.steps < 128 else 0)
     forces.read_timing(system.pos, reset=True)
     fan.barrier()
     torch.cuda.synchronize()
@@ -408,7 +409,8 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_kernel_us": pair_avg_s * 1e6,
             "launches_timed": int(pair_launches),
-            "timing": f"HIP events on the launch stream around every {stride}th pair-kernel launch of the timed region"
+            "timing": (f"HIP events on the launch stream around every {stride}th pair-kernel launch of the timed region"
+                       + (" (the first 8 of them)" if args.steps < 128 else ""))
             if stride > 1 else "HIP events on the launch stream around every pair-kernel launch of the timed region",
             "step_frac_of_hbm_roofline": (step_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
         },

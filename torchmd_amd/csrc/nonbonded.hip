@@ -1321,6 +1321,8 @@ struct tmdhip_ctx {
   bool timing = false;
   int timing_stride = 1;    // every n-th launch is timed
   int64_t timing_seen = 0;  // launches since timing was enabled
+  int64_t timing_limit = 0; // stop after this many timed launches (0: no limit)
+  int64_t timing_taken = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   double timing_ms = 0;
@@ -1813,7 +1815,9 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
   hipEvent_t e0 = nullptr, e1 = nullptr;
   // every `timing_stride`-th launch is bracketed by events: an event pair costs ~3 us of stream time,
   // so timing every launch would slow down the very loop being measured
-  const bool timed = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0;
+  const bool timed = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 &&
+                     (ctx->timing_limit == 0 || ctx->timing_taken < ctx->timing_limit);
+  if (timed) ctx->timing_taken++;
   if (timed) {
     if (ctx->events_used >= 4096) TMD_TRY(tmdhip_timing_read(ctx, nullptr, nullptr, 0));
     if (ctx->events_used == ctx->events.size()) {
@@ -2590,8 +2594,9 @@ int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica) {
 int tmdhip_timing_enable(tmdhip_ctx *ctx, int on) {
   if (!ctx) return fail("tmdhip_timing_enable: null ctx");
   ctx->timing = on != 0;
-  ctx->timing_stride = on > 1 ? on : 1;
-  ctx->timing_seen = 0;
+  ctx->timing_stride = (on & 0xFFFF) > 1 ? (on & 0xFFFF) : 1;
+  ctx->timing_limit = on >> 16;
+  ctx->timing_seen = ctx->timing_taken = 0;
   // the events of the first launches are created here, not inside the region being timed (a hipEventCreate
   // costs ~10 us of host time: twenty of them in a 20-step run made the loop enqueue-bound)
   while (ctx->timing && ctx->events.size() < 192) {

@@ -697,10 +697,12 @@ class Forces:
             "chains_skipped": int(st.chains_skipped),
         }
 
-    def enable_timing(self, pos, on=True, every=1):
-        """HIP events around every `every`-th launch of the list pair kernel (an event pair costs ~3 us)."""
+    def enable_timing(self, pos, on=True, every=1, limit=0):
+        """HIP events around every `every`-th launch of the list pair kernel (an event pair costs 3-6 us of stream
+        time), at most `limit` of them (0: no limit)."""
         eng = self._engine(pos.detach())
-        L.check(eng.lib.tmdhip_timing_enable(eng.ctx, max(1, int(every)) if on else 0))
+        code = (min(max(1, int(every)), 0xFFFF) | (max(0, int(limit)) << 16)) if on else 0
+        L.check(eng.lib.tmdhip_timing_enable(eng.ctx, code))
 
     def read_timing(self, pos, reset=True):
         """(total ms, launches) of the list pair kernel measured with HIP events on the launch stream."""
