@@ -562,6 +562,8 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
     par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
     monkeypatch.setenv("TMDHIP_LPA", "8")
     monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    monkeypatch.setenv("TMDHIP_CHAIN_SKIP", "1")
+    monkeypatch.delenv("TMDHIP_VSKIN", raising=False)
     s = System(mol.numAtoms, 1, dt, dev)
     s.set_positions(pos[:, :, None])
     s.set_box(box)
