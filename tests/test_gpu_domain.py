@@ -159,3 +159,54 @@ def test_native_exchange_and_step_loop_single_rank():
     assert (F - s.forces[0]).abs().max().item() < 1e-6
     P0, V0, F0, mig0 = results["0"]
     assert mig0 == mig and torch.equal(P, P0) and torch.equal(V, V0) and torch.equal(F, F0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("langevin", [False, True])
+def test_dd_step_equals_the_separate_integrator_kernels(dt, langevin):
+    """`tmdhip_dd_step` (kick of the previous step + drift of this one in one launch) is bit-identical to
+    tmdhip_[langevin_]second_vv followed by tmdhip_first_vv, and its displacement maximum is max |x - ref|^2;
+    `tmdhip_halo_pack` equals index_select + shift."""
+    from torchmd_amd import _lib as L
+
+    lib, dev = L.load(), torch.device("cuda:0")
+    code = L.dtype_code(dt)
+    n = 5000
+    g = torch.Generator(device="cpu").manual_seed(4)
+    mk = lambda *shape: torch.randn(*shape, generator=g, dtype=torch.float64).to(dt).to(dev).contiguous()  # noqa: E731
+    pos, vel, frc = mk(n, 3) * 10, mk(n, 3), mk(n, 3) * 5
+    mass = (1.0 + 15.0 * torch.rand(n, generator=g, dtype=torch.float64)).to(dt).to(dev)
+    vc = (0.01 * torch.rand(n, generator=g, dtype=torch.float64)).to(dt).to(dev)
+    ref = (pos + 0.1 * mk(n, 3)).contiguous()
+    tstep, gamma, seed, step = 0.02, 0.3, 1234, 77
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p1, v1 = pos.clone(), vel.clone()
+    if langevin:
+        L.check(lib.tmdhip_langevin_second_vv(code, 1, n, v1.data_ptr(), frc.data_ptr(), mass.data_ptr(), vc.data_ptr(),
+                                              tstep, gamma, seed, step, st))
+    else:
+        L.check(lib.tmdhip_second_vv(code, 1, n, v1.data_ptr(), frc.data_ptr(), mass.data_ptr(), tstep, st))
+    L.check(lib.tmdhip_first_vv(code, 1, n, p1.data_ptr(), v1.data_ptr(), frc.data_ptr(), mass.data_ptr(), tstep, st))
+    p2, v2 = pos.clone(), vel.clone()
+    disp2 = torch.zeros(1, dtype=torch.float32, device=dev)
+    L.check(lib.tmdhip_dd_step(code, n, p2.data_ptr(), v2.data_ptr(), frc.data_ptr(), mass.data_ptr(),
+                               vc.data_ptr() if langevin else 0, tstep, gamma, seed, step, 3, ref.data_ptr(),
+                               disp2.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(v1, v2)
+    want = ((p2 - ref) ** 2).sum(dim=1).max().item()
+    assert abs(disp2.item() - want) <= 2e-6 * want and disp2.item() >= want * (1 - 1e-6)
+    # the two phases one at a time give the same state as both together
+    p3, v3 = pos.clone(), vel.clone()
+    for phases in (1, 2):
+        L.check(lib.tmdhip_dd_step(code, n, p3.data_ptr(), v3.data_ptr(), frc.data_ptr(), mass.data_ptr(),
+                                   vc.data_ptr() if langevin else 0, tstep, gamma, seed, step, phases, 0, 0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(p3, p2) and torch.equal(v3, v2)
+    # halo pack
+    idx = torch.randint(0, n, (777,), generator=g).to(torch.int32).to(dev)
+    shift = (mk(777, 3) * 3).contiguous()
+    out = torch.empty(777, 3, dtype=dt, device=dev)
+    L.check(lib.tmdhip_halo_pack(code, 777, p2.data_ptr(), idx.data_ptr(), shift.data_ptr(), out.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(out, p2.index_select(0, idx.long()) + shift)
