@@ -864,10 +864,12 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   if (publish && blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __shared__ __align__(16) float2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
-  for (int t = threadIdx.x; t < kEntryTypes * kEntryTypes; t += blockDim.x) {
+  // (only the rows of existing classes are ever read: ntypes x 32 entries instead of 32 x 32 — at 10^6 LJ atoms
+  // with 64 atoms per block the full table was 15 625 x 8 KB of staging)
+  for (int t = threadIdx.x; t < ntypes * kEntryTypes; t += blockDim.x) {
     const int ti = t >> 5, tj = t & 31;
     float2 ab = make_float2(0.f, 0.f);
-    if (ti < ntypes && tj < ntypes) ab = tab[ti * ntypes + tj];
+    if (tj < ntypes) ab = tab[ti * ntypes + tj];
     stab[t] = make_float2(-12.0f * ab.x, 6.0f * ab.y);
   }
   __syncthreads();
@@ -1051,10 +1053,10 @@ __global__ __launch_bounds__(256) void list_pair_lean_f64_kernel(
   if (publish && blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __shared__ __align__(16) double2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
-  for (int t = threadIdx.x; t < kEntryTypes * kEntryTypes; t += blockDim.x) {
+  for (int t = threadIdx.x; t < ntypes * kEntryTypes; t += blockDim.x) {  // rows of existing classes only
     const int ti = t >> 5, tj = t & 31;
     double2 ab = make_double2(0.0, 0.0);
-    if (ti < ntypes && tj < ntypes) ab = tab[ti * ntypes + tj];
+    if (tj < ntypes) ab = tab[ti * ntypes + tj];
     stab[t] = make_double2(-12.0 * ab.x, 6.0 * ab.y);
   }
   __syncthreads();
