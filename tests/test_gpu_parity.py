@@ -770,3 +770,34 @@ def test_minimum_image_known_geometry():
     r = box[0] - 15.1
     assert abs(ei - 332.06371307417066 / r) < 1e-9
     assert abs(Fi[0, 0, 0].item() - 332.06371307417066 / r**2) < 1e-9  # pushed apart: +x on the left ion
+
+
+def test_more_than_2_pow_20_atoms_stay_on_the_lean_kernel():
+    """1 124 864 argon atoms (> 2^20: the slot field of a list entry uses its bits 20..22, so the lean fp32 kernel
+    runs every iteration in its checked loop, which masks the table offset): forces agree with the fp64 kernel's,
+    vanish in the sum, and the energy per atom is that of the 10^6-atom box."""
+    from torchmd_amd.builders import argon_forcefield, lj_box
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev = _dev()
+    mol, pos, box = lj_box(104, seed=4)
+    assert mol.numAtoms > (1 << 20)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        par = Parameters(argon_forcefield(mol), mol, ["lj"], precision=dt)
+        f = Forces(par, terms=["lj"], cutoff=9.0)
+        p = torch.tensor(pos, dtype=dt, device=dev)[None].contiguous()
+        F = torch.zeros_like(p)
+        e = f.compute(p, box_tensor(box, 1, dt, dev), F)[0]
+        st = f.stats(p)
+        assert st["algorithm"] == "celllist" and st["overflow"] == 0
+        res[dt] = (e, F.double().cpu())
+        f.close()
+        del f, p, F
+        torch.cuda.empty_cache()
+    (e32, F32), (e64, F64) = res[torch.float32], res[torch.float64]
+    assert F32.sum(dim=1).abs().max().item() < 0.5
+    assert (F32 - F64).abs().max().item() < 1e-2
+    assert abs(e32 - e64) < 2e-5 * abs(e64)
+    assert -1.6 < e64 / mol.numAtoms < -0.6

@@ -412,7 +412,7 @@ __global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const int
 
 // list entry = type_j << 27 | j << 4 (j = cell-sorted slot, 23 bits): `entry & kEntryOffMask` is the byte offset
 // of atom j's float4 record, `entry >> 24` the byte offset of type j in an 8-byte-stride LDS table row (for
-// n <= 2^20).  Contexts with more than kEntryTypes LJ classes leave the type field 0 (kernels read stype[j]).
+// n <= 2^20; larger systems mask it).  Contexts with more than kEntryTypes LJ classes leave the type field 0 (kernels read stype[j]).
 constexpr unsigned kEntryOffMask = 0x07FFFFF0u;  // byte offset of atom j's float4 record
 constexpr int kEntryTypes = 32;                  // LJ classes that fit the entry's type field
 constexpr int kEntryTypeShift = 27;
@@ -901,7 +901,10 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     itmin = min(itmin, __shfl_xor(itmin, o, 64));
   }
   const int nkk = __builtin_amdgcn_readfirstlane(itmax);
-  const int nfull = __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL;  // iterations every lane has entries for
+  // iterations every lane has entries for.  The unchecked loop takes the table offset as `entry >> 24`, which needs
+  // the slot's bits 20..22 to be zero: systems of more than 2^20 atoms run all their iterations in the checked
+  // loop, which masks the offset
+  const int nfull = n > (1 << 20) ? 0 : __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL;
   // a lane's entries of iterations 4G .. 4G+3 are one 16-byte word at row4[G * 64]
   const v4u *row4 = reinterpret_cast<const v4u *>(nlist + (size_t)wave * maxn * APW) + lane;
   // bounds-checked raw buffer over sorted_xyzq: lanes past the end of their list read whatever the
@@ -1770,8 +1773,8 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
   const bool fast = only_lj_el;  // (switching, if any, acts on the LJ term and is a kernel variant)
   if constexpr (std::is_same<R, float>::value) {
-    // lean fp32 kernel: the entry's type field holds 32 LJ classes; the unmasked table offset needs j < 2^20
-    if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= kEntryTypes && n <= (1 << 20)) {
+    // lean fp32 kernel: the entry's type field holds 32 LJ classes (n > 2^20: every iteration in its checked loop)
+    if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= kEntryTypes) {
       const size_t shfast = 0;
       const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
 #define TMD_LAUNCH_FAST_T(L, A, B)       \
@@ -1810,7 +1813,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   }
   if constexpr (std::is_same<R, double>::value) {
     // lean fp64 kernel (same conditions as the fp32 one)
-    if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= kEntryTypes && n <= (1 << 20)) {
+    if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= kEntryTypes) {
       const size_t shfast = 0;
       const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
 #define TMD_LAUNCH_FAST_T(L, A, B)       \
@@ -2453,7 +2456,7 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
   if (algo == TMDHIP_ALGO_AUTO) algo = (desc->cutoff > 0 && n >= 2048) ? TMDHIP_ALGO_CELLLIST : TMDHIP_ALGO_ALLPAIRS;
   if (algo == TMDHIP_ALGO_CELLLIST) {
     if (!(desc->cutoff > 0)) return cleanup(fail("tmdhip_create: the cell-list path needs a cutoff"));
-    if (n >= (1 << 24)) return cleanup(fail("tmdhip_create: cell-list path supports < 2^24 atoms per context"));
+    if (n >= (1 << 23)) return cleanup(fail("tmdhip_create: cell-list path supports < 2^23 atoms per context (23-bit slot field of a list entry)"));
     if (desc->ntypes > 256) return cleanup(fail("tmdhip_create: cell-list path supports <= 256 atom types"));
     const size_t tabbytes = (size_t)desc->ntypes * desc->ntypes * 2 * ctx->real_size;
     if (tabbytes > 64 * 1024) return cleanup(fail("tmdhip_create: LJ table does not fit in LDS (too many atom types)"));
@@ -2544,7 +2547,7 @@ int tmdhip_compute_nonbonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, 
 int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, const void *charges_host,
                         int nactive) {
   if (!ctx || !types_host) return fail("tmdhip_update_atoms: null argument");
-  if (natoms <= 0 || natoms >= (1 << 24)) return fail("tmdhip_update_atoms: natoms out of range");
+  if (natoms <= 0 || natoms >= (1 << 23)) return fail("tmdhip_update_atoms: natoms out of range");
   if (ctx->nexcl != 0 || ctx->bonded) return fail("tmdhip_update_atoms: only for atomic systems (no exclusions, no bonded terms)");
   if ((ctx->d.terms & TMDHIP_TERM_ELECTROSTATICS) && !charges_host)
     return fail("tmdhip_update_atoms: electrostatics needs charges");
