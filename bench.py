@@ -34,8 +34,8 @@ PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
 
 
 def timing_stride(steps):
-    """HIP events bracket every n-th launch of the pair kernel (an event pair costs ~3 us of stream time):
-    n chosen so that any --steps >= 8 yields >= 8 timed launches (20 steps: every 2nd; >= 128: every 16th)."""
+    """HIP events time every n-th launch of the pair kernel: n chosen so that any --steps >= 8 yields >= 8 timed
+    launches (20 steps: every 2nd; >= 128: every 16th)."""
     return max(1, min(16, steps // 8))
 
 
@@ -325,8 +325,8 @@ def main():
         integ.step(args.warmup)
 
     st0 = forces.stats(system.pos)
-    # HIP events around every 16th launch of the pair kernel, spread over the whole timed region (an event
-    # pair costs ~3 us of stream time: timing every launch slowed the loop from 84 to 91 us/step)
+    # HIP events on every 16th launch of the pair kernel, spread over the whole timed region (attached to the
+    # dispatch itself since round 2: events recorded in front of and behind a launch cost 6.6 us of stream time each pair)
     stride = timing_stride(args.steps)
     # short runs: exactly 8 timed launches (every event pair costs stream time that the step loop pays)
     forces.enable_timing(system.pos, True, every=stride, limit=8 if args.steps < 128 else 0)
@@ -409,9 +409,9 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_kernel_us": pair_avg_s * 1e6,
             "launches_timed": int(pair_launches),
-            "timing": (f"HIP events on the launch stream around every {stride}th pair-kernel launch of the timed region"
-                       + (" (the first 8 of them)" if args.steps < 128 else ""))
-            if stride > 1 else "HIP events on the launch stream around every pair-kernel launch of the timed region",
+            "timing": (f"HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of every {stride}th pair-kernel "
+                       "launch of the timed region, on the launch stream" + (" (the first 8 of them)" if args.steps < 128 else ""))
+            if stride > 1 else "HIP start/stop events attached to the dispatch of every pair-kernel launch of the timed region",
             "step_frac_of_hbm_roofline": (step_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
         },
     }

@@ -230,8 +230,8 @@ int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica);
 int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out);
 
 /* HIP-event timing of the dominant (pair) kernel, recorded on the launch stream.  on = 0: off; low 16 bits = n:
- * every n-th launch (1: every launch; an event pair costs ~3-6 us of stream time); bits 16 and up = stop after
- * that many timed launches (0: no limit). */
+ * every n-th launch (1: every launch); bits 16 and up = stop after that many timed launches (0: no limit).  The
+ * start / stop events are attached to the kernel's own dispatch (hipExtLaunchKernel), not recorded around it. */
 int tmdhip_timing_enable(tmdhip_ctx *ctx, int on);
 int tmdhip_timing_read(tmdhip_ctx *ctx, double *pair_kernel_ms, int64_t *launches, int reset);
 
