@@ -282,14 +282,26 @@ __device__ __forceinline__ void list_check_atom(const ListCheck<R> &k, const Pai
 __device__ __forceinline__ void list_check_clear(int *flags, int parity) { flags[F_REBUILD0 + (parity ^ 1)] = 0; }
 
 template <typename R>
-__global__ void check_displacement_kernel(int n, const R *__restrict__ pos, ListCheck<R> k, PairConsts<R> c, int force) {
+__global__ void check_displacement_kernel(int n, const R *__restrict__ pos, ListCheck<R> k, PairConsts<R> c, int force,
+                                          const int *__restrict__ inv, const R *__restrict__ qs,
+                                          typename Vec<R>::T4 *__restrict__ sorted) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
     list_check_clear(k.flags, k.parity);
     if (force) k.flags[F_REBUILD0 + k.parity] = 1;
   }
   if (i >= n || force) return;
-  list_check_atom<R>(k, c, i, pos[3 * i + 0], pos[3 * i + 1], pos[3 * i + 2]);
+  const R x = pos[3 * i + 0], y = pos[3 * i + 1], z = pos[3 * i + 2];
+  list_check_atom<R>(k, c, i, x, y, z);
+  // callers of a plain evaluation hand in arbitrary new positions: refresh the cell-sorted copy the pair kernel
+  // reads in the same pass (on a rebuild place_sorted_kernel rewrites it in the new order; the MD loop's
+  // integrator kernel keeps the copy current itself)
+  typename Vec<R>::T4 rec;  // one full 16/32-byte store (partial writes of a record are slower)
+  rec.x = x;
+  rec.y = y;
+  rec.z = z;
+  rec.w = qs[i];
+  sorted[inv[i]] = rec;
 }
 
 template <typename R>
@@ -395,20 +407,6 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
   ref[3 * me + 0] = v.x;
   ref[3 * me + 1] = v.y;
   ref[3 * me + 2] = v.z;
-}
-
-// refresh of the cell-sorted coordinate copy for callers that hand in arbitrary new positions
-// (tmdhip_compute_nonbonded); the MD loop's integrator kernel writes the copy itself
-template <typename R>
-__global__ void gather_sorted_kernel(int n, const R *__restrict__ pos, const int *__restrict__ order,
-                                     typename Vec<R>::T4 *__restrict__ sorted, const int *flag) {
-  if (*flag) return;  // place_sorted_kernel has just written everything
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= n) return;
-  const int i = order[a];
-  sorted[a].x = pos[3 * i + 0];
-  sorted[a].y = pos[3 * i + 1];
-  sorted[a].z = pos[3 * i + 2];
 }
 
 // list entry = type_j << 27 | j << 4 (j = cell-sorted slot, 23 bits): `entry & kEntryOffMask` is the byte offset
@@ -1936,7 +1934,7 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
   const int nb = (n + 255) / 256;
   if (!prechecked)
     hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, make_check<R>(ctx, rp), c,
-                       force);
+                       force, rp.inv.as<int>(), ctx->qs.as<R>(), rp.sorted.as<R4>());
   hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, rp.cell_of.as<int>(),
                      rp.slot.as<int>(), rp.count.as<int>(), flag);
   hipLaunchKernelGGL(scan_cells_kernel, dim3(1), dim3(1024), 0, st, rp.ncell, rp.count.as<int>(),
@@ -1948,9 +1946,6 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
                      rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(),
                      ctx->half_skin.as<R>(), rp.sorted_hs.as<R>(), ctx->vskin_time > 0 ? (const R *)rp.skin_vel : nullptr,
                      (R)ctx->vskin_floor, (R)ctx->vskin_time, (R)ctx->vskin_cap_len, rp.hs2_dyn.as<R>(), flag);
-  if (!prechecked)
-    hipLaunchKernelGGL((gather_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.order.as<int>(),
-                       rp.sorted.as<R4>(), flag);
   const R rl = (R)ctx->rlist;
   constexpr int kMaxBuildBlocks = 16384;
   const bool wskin = ctx->half_skin.p != nullptr;
