@@ -162,7 +162,9 @@ int tmdhip_compute_bonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, con
 /* Forces.compute (forces.py:83-346) for every replica in ONE call with ONE host synchronisation: bonded +
  * nonbonded forces stored into forces_dev (real [R,N,3]; NULL: energies only, `calculateForces=False`) and the
  * per-term energies returned on the host (energies_host: double [R][TMDHIP_NENERGY]).  The neighbour-list
- * validity check rides on the same read-back.  Returns 0 = valid; 1 = a list was truncated (capacity grown):
+ * validity check rides on the same read-back (for up to 16 replicas one small kernel writes everything into
+ * host-mapped memory followed by a sequence word the host spins on; more replicas: copies + stream
+ * synchronisation).  Returns 0 = valid; 1 = a list was truncated (capacity grown):
  * call again; negative = error. */
 int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host, void *forces_dev,
                    double *energies_host, void *stream);

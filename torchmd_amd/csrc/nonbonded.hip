@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1405,6 +1406,42 @@ __global__ __launch_bounds__(256) void md_step_bonded_kernel(MdStepArgs<R> s, Pa
 
 __global__ void halve_count_kernel(unsigned long long *c) { *c >>= 1; }
 
+// tmdhip_md_observe: the per-term energies, the kinetic energies and the list flags of every replica written
+// straight into host-mapped memory by one small block, followed by a sequence word the host spins on — instead of
+// three device-to-host copy commands and a stream synchronisation (whose wake-up is the slowest part of a short
+// call).  flags.p[r] = replica r's int[F_COUNT], or null.
+struct ObsFlagPtrs {
+  const int *p[16];
+};
+__global__ void observe_publish_kernel(int nrep, const double *__restrict__ energies, const double *__restrict__ ke,
+                                       ObsFlagPtrs flags, double *host_e, double *host_ke, int *host_flags,
+                                       unsigned *host_seq, unsigned seq) {
+  const int t = threadIdx.x;
+  for (int k = t; k < nrep * TMDHIP_NENERGY; k += blockDim.x) host_e[k] = energies ? energies[k] : 0.0;
+  for (int k = t; k < nrep; k += blockDim.x) host_ke[k] = ke ? ke[k] : 0.0;
+  for (int k = t; k < nrep * F_COUNT; k += blockDim.x) {
+    const int r = k / F_COUNT;
+    host_flags[k] = flags.p[r] ? flags.p[r][k - r * F_COUNT] : 0;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// host side of observe_publish_kernel: spin until the device has written `seq` (all results are then in place)
+int wait_observed(volatile unsigned *hseq, unsigned seq, hipStream_t st) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1; *hseq != seq; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+      TMD_HIP(hipStreamSynchronize(st));  // surfaces a device error if there is one
+      if (*hseq != seq) return fail("the device did not report the results of the call");
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
 // state at the entry of an MD batch (positions, velocities, forces) in one launch; n4 = 16-byte words per array
 __global__ void snapshot3_kernel(size_t n4, const uint4 *__restrict__ a, const uint4 *__restrict__ b,
                                  const uint4 *__restrict__ c, uint4 *__restrict__ out) {
@@ -1497,6 +1534,7 @@ struct tmdhip_ctx {
   void *sync_host = nullptr;  // ... and their pinned host landing zone (+ the list flags of every replica)
   DevBuf obs_ke;              // tmdhip_md_observe: kinetic energies [R] ...
   void *obs_host = nullptr;   // ... and the pinned landing zone of energies, kinetic energies and list flags
+  unsigned obs_seq = 0;       // sequence number of the last observe_publish_kernel
   DevBuf types, qs, tab, excl_off, excl_idx;
   // per-atom Verlet skins (tmdhip_set_skin_weights): half_skin[i] = w_i * skin / 2 and its square, original atom
   // order; empty = skin / 2 for every atom
@@ -2710,7 +2748,10 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
   const size_t nrep = ctx->rep.size();
   const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, fbytes = sizeof(int) * F_COUNT * nrep;
   TMD_TRY(ctx->sync_e.ensure(ebytes));
-  if (!ctx->sync_host) TMD_HIP(hipHostMalloc(&ctx->sync_host, ebytes + fbytes, hipHostMallocDefault));
+  if (!ctx->sync_host) {
+    TMD_HIP(hipHostMalloc(&ctx->sync_host, ebytes + fbytes + sizeof(double) * nrep + 64, hipHostMallocMapped));
+    std::memset(ctx->sync_host, 0, ebytes + fbytes + sizeof(double) * nrep + 64);
+  }
   double *he = (double *)ctx->sync_host;
   int *hf = (int *)((char *)ctx->sync_host + ebytes);
   double *e = ctx->sync_e.as<double>();
@@ -2724,12 +2765,24 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
   TMD_TRY(tmdhip_compute_nonbonded(ctx, TMDHIP_ALL_REPLICAS, pos_dev, box_host, forces_dev, e,
                                    flags | (forces_dev ? TMDHIP_OVERWRITE_FORCES : 0), stream));
   TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos_dev, box_host, forces_dev, e, flags, stream));
-  TMD_HIP(hipMemcpyAsync(he, e, ebytes, hipMemcpyDeviceToHost, st));
   const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
-  if (lists)
-    for (size_t r = 0; r < nrep; ++r)
-      TMD_HIP(hipMemcpyAsync(hf + r * F_COUNT, ctx->rep[r].flags.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st));
-  TMD_HIP(hipStreamSynchronize(st));  // the one host synchronisation of an energy evaluation
+  if (nrep <= 16) {  // results through host-mapped memory + a sequence word (see observe_publish_kernel)
+    ObsFlagPtrs fp{};
+    for (size_t r = 0; r < nrep; ++r) fp.p[r] = lists ? ctx->rep[r].flags.as<int>() : nullptr;
+    double *hk = (double *)((char *)ctx->sync_host + ebytes + fbytes);
+    volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->sync_host + ebytes + fbytes + sizeof(double) * nrep + 32);
+    if (++ctx->obs_seq == 0) ctx->obs_seq = 1;
+    hipLaunchKernelGGL(observe_publish_kernel, dim3(1), dim3(128), 0, st, (int)nrep, e, (const double *)nullptr, fp, he, hk,
+                       hf, const_cast<unsigned *>(hseq), ctx->obs_seq);
+    TMD_HIP(hipGetLastError());
+    TMD_TRY(wait_observed(hseq, ctx->obs_seq, st));  // the one host synchronisation of an energy evaluation
+  } else {
+    TMD_HIP(hipMemcpyAsync(he, e, ebytes, hipMemcpyDeviceToHost, st));
+    if (lists)
+      for (size_t r = 0; r < nrep; ++r)
+        TMD_HIP(hipMemcpyAsync(hf + r * F_COUNT, ctx->rep[r].flags.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st));
+    TMD_HIP(hipStreamSynchronize(st));  // the one host synchronisation of an energy evaluation
+  }
   int verdict = 0;
   if (lists && ctx->algorithm == TMDHIP_ALGO_CELLLIST)
     for (size_t r = 0; r < nrep; ++r)
@@ -2784,17 +2837,32 @@ int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev
   const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, kbytes = sizeof(double) * nrep;
   const size_t fbytes = sizeof(int) * F_COUNT * nrep;
   TMD_TRY(ctx->obs_ke.ensure(kbytes));
-  if (!ctx->obs_host) TMD_HIP(hipHostMalloc(&ctx->obs_host, ebytes + kbytes + fbytes, hipHostMallocDefault));
+  if (!ctx->obs_host) {
+    TMD_HIP(hipHostMalloc(&ctx->obs_host, ebytes + kbytes + fbytes + 64, hipHostMallocMapped));
+    std::memset(ctx->obs_host, 0, ebytes + kbytes + fbytes + 64);
+  }
   double *he = (double *)ctx->obs_host, *hk = he + TMDHIP_NENERGY * nrep;
   int *hf = (int *)((char *)ctx->obs_host + ebytes + kbytes);
+  volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->obs_host + ebytes + kbytes + fbytes + 32);
   TMD_TRY(tmdhip_kinetic_energy(ctx->d.dtype, (int64_t)nrep, ctx->d.natoms, vel_dev, mass_dev, ctx->obs_ke.as<double>(), stream));
-  if (energies_dev) TMD_HIP(hipMemcpyAsync(he, energies_dev, ebytes, hipMemcpyDeviceToHost, st));
-  TMD_HIP(hipMemcpyAsync(hk, ctx->obs_ke.p, kbytes, hipMemcpyDeviceToHost, st));
   const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
-  if (lists)
-    for (size_t r = 0; r < nrep; ++r)
-      TMD_HIP(hipMemcpyAsync(hf + r * F_COUNT, ctx->rep[r].flags.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st));
-  TMD_HIP(hipStreamSynchronize(st));
+  if (nrep <= 16) {
+    ObsFlagPtrs fp{};
+    for (size_t r = 0; r < nrep; ++r) fp.p[r] = lists ? ctx->rep[r].flags.as<int>() : nullptr;
+    if (++ctx->obs_seq == 0) ctx->obs_seq = 1;
+    hipLaunchKernelGGL(observe_publish_kernel, dim3(1), dim3(128), 0, st, (int)nrep, energies_dev, ctx->obs_ke.as<double>(),
+                       fp, he, hk, hf, const_cast<unsigned *>(hseq), ctx->obs_seq);
+    TMD_HIP(hipGetLastError());
+    TMD_TRY(wait_observed(hseq, ctx->obs_seq, st));
+  } else {
+    if (energies_dev) TMD_HIP(hipMemcpyAsync(he, energies_dev, ebytes, hipMemcpyDeviceToHost, st));
+    else std::memset(he, 0, ebytes);
+    TMD_HIP(hipMemcpyAsync(hk, ctx->obs_ke.p, kbytes, hipMemcpyDeviceToHost, st));
+    if (lists)
+      for (size_t r = 0; r < nrep; ++r)
+        TMD_HIP(hipMemcpyAsync(hf + r * F_COUNT, ctx->rep[r].flags.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st));
+    TMD_HIP(hipStreamSynchronize(st));
+  }
   int verdict = 0;
   if (lists && ctx->algorithm == TMDHIP_ALGO_CELLLIST)
     for (size_t r = 0; r < nrep; ++r)
