@@ -191,7 +191,7 @@ typedef struct tmdhip_md_desc {
   double dt;                            /* time step in internal units (fs / 48.88821)               */
   double gamma;                         /* friction in internal units                                */
   uint64_t seed, step0;                 /* noise stream key and position (step0 + iteration)         */
-  double *energies_dev;                 /* [R*TMDHIP_NENERGY]: += energies of the LAST iteration, or NULL */
+  double *energies_dev;                 /* [R*TMDHIP_NENERGY]: energies of the LAST iteration (overwritten), or NULL */
 } tmdhip_md_desc;
 int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
 /* What Integrator.step returns after its loop (integrator.py:121-125), with ONE read-back and ONE host

@@ -2803,6 +2803,8 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     return fail("tmdhip_md_run: null buffer");
   if (desc->niter == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (desc->energies_dev)
+    TMD_HIP(hipMemsetAsync(desc->energies_dev, 0, sizeof(double) * TMDHIP_NENERGY * ctx->rep.size(), st));
   if (ctx->algorithm == TMDHIP_ALGO_CELLLIST) {
     // state at entry, for tmdhip_md_restore (a truncated list is only detected after the batch)
     const size_t bytes = (size_t)ctx->real_size * 3 * ctx->d.natoms * ctx->rep.size();

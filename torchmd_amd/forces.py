@@ -646,18 +646,23 @@ class Forces:
         eng = self._engine(pos)
         hbox = self._host_box(system.box)
         R = pos.shape[0]
-        boxes = np.ascontiguousarray(np.stack([hbox[min(r, len(hbox) - 1)] for r in range(R)]).astype(np.float64))
-        d = L.MdDesc()
-        d.struct_size = C.sizeof(L.MdDesc)
+        # the descriptor and the per-replica box array are kept between calls (a 20-step call is short enough for
+        # the Python in front of its first launch to show)
+        cache = getattr(eng, "_md_cache", None)
+        if cache is None or cache[0] is not hbox or cache[1] != R:
+            boxes = np.ascontiguousarray(np.stack([hbox[min(r, len(hbox) - 1)] for r in range(R)]).astype(np.float64))
+            d = L.MdDesc()
+            d.struct_size = C.sizeof(L.MdDesc)
+            d.box_host = boxes.ctypes.data_as(C.c_void_p)
+            cache = eng._md_cache = (hbox, R, boxes, d)
+        d = cache[3]
         d.niter = int(niter)
         d.pos_dev, d.vel_dev, d.forces_dev = pos.data_ptr(), system.vel.data_ptr(), system.forces.data_ptr()
         d.mass_dev = masses.data_ptr()
         d.vcoeff_dev = vcoeff.data_ptr() if vcoeff is not None else None
-        d.box_host = boxes.ctypes.data_as(C.c_void_p)
         d.dt, d.gamma = float(dt), float(gamma)
         d.seed, d.step0 = int(seed), int(step0)
-        eng.ebuf.zero_()
-        d.energies_dev = eng.ebuf.data_ptr()
+        d.energies_dev = eng.ebuf.data_ptr()  # zeroed by the library
         stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
         if restore:
             L.check(eng.lib.tmdhip_md_restore(eng.ctx, C.byref(d), stream), "tmdhip_md_restore")
