@@ -582,8 +582,11 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
         aged += f.stats(s.pos)["n_rebuilds"] == r0
         p = s.pos.detach().cpu()
         pairs = orc.candidate_pairs(p[0].double().numpy(), box, 9.3, excl)
-        _, Fo, npairs = orc.compute(par, p, s.box.cpu(), ["lj", "electrostatics"], pairs=pairs, cutoff=9.0, rfa=True)
+        _, Fo, npairs = orc.compute(par, p, s.box.cpu(), terms, pairs=pairs, cutoff=9.0, rfa=True)
         assert n_gpu == npairs[0], (k, n_gpu, npairs)
+        # forces of the MD run's last step (aged list, lean kernel + inline/separate bonded kernels) vs the oracle
+        err = (s.forces.cpu() - Fo).abs().max().item()
+        assert err < 2e-3, (k, err)
     st = f.stats(s.pos)
     assert aged >= 3 and st["chains_skipped"] > 20 and st["overflow"] == 0
     fresh = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist", skin_weights=None)

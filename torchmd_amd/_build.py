@@ -67,6 +67,6 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
 
 
 if __name__ == "__main__":
-    extra = [a for a in sys.argv[1:] if a.startswith("-f") or a.startswith("-m")]
+    extra = [a for a in sys.argv[1:] if a.startswith(("-f", "-m", "-D"))]
     out = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")), None)
     print(build_library(force="--force" in sys.argv, verbose=True, extra_flags=extra, out=out))

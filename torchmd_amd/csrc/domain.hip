@@ -21,7 +21,6 @@
 // library carries no link-time dependency on it and loads without it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstring>
@@ -31,6 +30,27 @@
 #include "rng.h"
 
 using namespace tmd;
+
+// The handful of RCCL declarations this file needs, stated locally (values and signatures of the stable NCCL 2 ABI,
+// rccl.h): librccl is opened with dlopen at run time, so the library must also BUILD on a machine without the RCCL
+// headers — the single-GPU paths do not depend on them at all.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclMax = 2 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char *ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
+                           ncclComm_t comm, hipStream_t stream);
+}
 
 namespace {
 
@@ -278,21 +298,49 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
     TMD_TRY(kick_drift(it == 0 ? d->first_phases : 3, kick_step));
     ++since;
     if (since % d->check_every == 0) {
+      const double limit = 0.5 * d->skin;
       if (c->pending) {
         TMD_HIP(hipEventSynchronize(c->ev[c->cur]));  // recorded check_every steps ago
+        const double moved = std::sqrt((double)c->host_flag[c->cur]);
+        // the extrapolation below is a prediction; what was MEASURED must never have crossed the limit already
+        // (hot atoms, a larger check_every, a changed time step): halo atoms would be missing, forces silently wrong
+        if (moved > limit) {
+          c->pending = false;
+          return fail("tmdhip_dd_run: an atom moved " + std::to_string(moved) + " A since the last migration, beyond the "
+                      "halo's half skin of " + std::to_string(limit) + " A, before a migration was requested: the forces of "
+                      "the last steps are invalid (use a larger halo skin or a smaller check_every)");
+        }
         const double ahead = 1.0 + 2.0 * (double)(since + d->check_every - c->at) / (double)c->at;
-        if (std::sqrt((double)c->host_flag[c->cur]) * ahead > 0.5 * d->skin) {
+        if (moved * ahead > limit) {
           c->pending = false;
           *iters_done = it;
           return 1;  // this iteration has drifted; the caller migrates, evaluates the forces and comes back
         }
       }
+      const bool first_check = !c->pending;  // first boundary after a migration: nothing measured yet
       c->cur ^= 1;
       if (c->world > 1) TMD_NCCL(c, c->api.all_reduce(d->disp2_dev, d->disp2_dev, 1, ncclFloat32, ncclMax, c->comm, st));
       TMD_HIP(hipMemcpyAsync(&c->host_flag[c->cur], d->disp2_dev, sizeof(float), hipMemcpyDeviceToHost, st));
       TMD_HIP(hipEventRecord(c->ev[c->cur], st));
       c->pending = true;
       c->at = since;
+      if (first_check) {
+        // one synchronous look, so that a migration can already be requested now instead of two periods after the
+        // last one (the value is the maximum over all ranks: every rank takes the same decision)
+        TMD_HIP(hipEventSynchronize(c->ev[c->cur]));
+        const double moved = std::sqrt((double)c->host_flag[c->cur]);
+        if (moved > limit) {
+          c->pending = false;
+          return fail("tmdhip_dd_run: an atom moved " + std::to_string(moved) + " A in the first " + std::to_string(since) +
+                      " steps after a migration, beyond the halo's half skin of " + std::to_string(limit) + " A");
+        }
+        const double ahead = 1.0 + 2.0 * (double)d->check_every / (double)since;  // until the next decision
+        if (moved * ahead > limit) {
+          c->pending = false;
+          *iters_done = it;
+          return 1;
+        }
+      }
     }
     TMD_TRY(tmdhip_halo_pack(d->dtype, d->nsend, d->pos_dev, d->send_index_dev, d->send_shift_dev, d->send_buf_dev, stream));
     TMD_TRY(exchange_rows(c, d->dtype, d->send_buf_dev, d->send_counts_host, halo_rows, d->recv_counts_host, 3, st));

@@ -252,7 +252,48 @@ struct ListCheck {
   unsigned seq;
   R near_frac2;
   int skipped;
+  int *ext;  // coordinate extent of everything ever stored into sorted_xyzq (see extent_note)
 };
+
+// Coordinate extent of the positions the pair kernels gather: int keys of {min x, y, z, max x, y, z} (float order
+// = signed int order of the key).  The lean pair kernels fuse the minimum image as fma(-k, box, d), which equals
+// the reference's separately rounded `d - box*round(d/box)` (forces.py:360-365) only while k*box is exact, i.e.
+// |k| <= 2 (or a power of two): guaranteed while every coordinate difference is below 2.5 box edges.  The
+// reference never wraps positions (integrator.py:61-64), so atoms may drift many boxes apart; every kernel that
+// writes sorted_xyzq widens this extent, and a pair kernel that finds it beyond kExtentExactFrac box edges takes
+// its loop copy with the product rounded separately.  The bounds only widen (reset: tmdhip_invalidate_list, a new
+// box); after the first pass no lane is outside them and the cost is six compares per atom.
+constexpr float kExtentExactFrac = 2.4f;
+constexpr int kExtentEmpty[6] = {0x7F800000, 0x7F800000, 0x7F800000,                  // keys of +inf
+                                 (int)0x807FFFFFu, (int)0x807FFFFFu, (int)0x807FFFFFu};  // keys of -inf
+__device__ __forceinline__ int extent_key(float x) {
+  const int i = __float_as_int(x);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float extent_unkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+template <typename R>
+__device__ __forceinline__ void extent_note(int *ext, R x, R y, R z) {
+  if (!ext) return;
+  // (fp64 positions: the float cast moves a bound by half an ulp of fp32 at most, nothing against the 0.1-box slack)
+  const int k[3] = {extent_key((float)x), extent_key((float)y), extent_key((float)z)};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (k[d] < ext[d]) atomicMin(&ext[d], k[d]);
+    if (k[d] > ext[3 + d]) atomicMax(&ext[3 + d], k[d]);
+  }
+}
+// true when some coordinate difference may reach 2.5 box edges (wave-uniform: scalar loads)
+template <typename R>
+__device__ __forceinline__ bool extent_needs_exact_image(const int *__restrict__ ext, const R *box) {
+  if (!ext) return false;
+  bool exact = false;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = extent_unkey(ext[3 + d]) - extent_unkey(ext[d]);  // -inf while nothing was noted
+    exact = exact || ((float)box[d] > 0.f && span > kExtentExactFrac * (float)box[d]);
+  }
+  return exact;
+}
 
 // (rx, ry, rz) = position - reference position of one atom
 template <typename R>
@@ -291,9 +332,10 @@ __global__ void check_displacement_kernel(int n, const R *__restrict__ pos, List
     list_check_clear(k.flags, k.parity);
     if (force) k.flags[F_REBUILD0 + k.parity] = 1;
   }
-  if (i >= n || force) return;
+  if (i >= n || force) return;  // (forced: place_sorted_kernel writes the records and notes the extent)
   const R x = pos[3 * i + 0], y = pos[3 * i + 1], z = pos[3 * i + 2];
   list_check_atom<R>(k, c, i, x, y, z);
+  extent_note<R>(k.ext, x, y, z);
   // callers of a plain evaluation hand in arbitrary new positions: refresh the cell-sorted copy the pair kernel
   // reads in the same pass (on a rebuild place_sorted_kernel rewrites it in the new order; the MD loop's
   // integrator kernel keeps the copy current itself)
@@ -372,7 +414,7 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
                                     typename Vec<R>::T4 *__restrict__ sorted, int *__restrict__ stype,
                                     R *__restrict__ ref, const R *__restrict__ half_skin,
                                     R *__restrict__ sorted_hs, const R *__restrict__ vel, R vs_floor, R vs_time,
-                                    R vs_cap, R *__restrict__ hs2_dyn, const int *flag) {
+                                    R vs_cap, R *__restrict__ hs2_dyn, int *ext, const int *flag) {
   if (*flag == 0) return;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
@@ -390,6 +432,7 @@ __global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, cons
   v.z = pos[3 * me + 2];
   v.w = qs[me];
   sorted[dst] = v;
+  extent_note<R>(ext, v.x, v.y, v.z);
   stype[dst] = types[me];
   if (half_skin) {
     // this list's half skin of the atom: its static share, or — inside an MD run, where the velocity is known —
@@ -839,25 +882,39 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // k = round-half-even(d / box) by the magic-number trick: fma(d, 1/box, 1.5*2^23) - 1.5*2^23 is exact
 // round-to-nearest-even for |d/box| < 2^22 (v_rndne_f32 would be a fourth instruction).  It differs from
-// rndne(fl(d*invbox)) only when d/box lies within one rounding error of a half-integer, i.e. |d| ~ box/2 >=
-// cutoff, where the pair is rejected either way (same argument as for d*invbox vs d/box in pair_math.h).
-// k is -1, 0 or 1 for every listed pair, so box*k is exact and the fused d - box*k equals the reference's
-// separately rounded `d - box*round(d/box)`.
+// rndne(fl(d*invbox)) only when d/box lies within one rounding error of a half-integer, i.e. the wrapped |d| ~
+// box/2 >= cutoff, where the pair is rejected either way (same argument as for d*invbox vs d/box in pair_math.h).
+// EXACT = false fuses the product into the subtraction: identical to the reference's separately rounded
+// `d - box*round(d/box)` (forces.py:360-365) whenever k*box is representable — |k| <= 2 — which the kernel
+// establishes from the coordinate extent (extent_needs_exact_image); EXACT = true rounds the product first
+// (one more instruction per component) and holds for any image offset.
+template <bool EXACT>
 __device__ __forceinline__ float min_image_magic(float d, float box, float invbox) {
 #pragma clang fp contract(off)
   const float magic = 12582912.0f;
   const float t = __builtin_fmaf(d, invbox, magic);
   const float k = t - magic;
+  if (EXACT) {
+    const float p = box * k;
+    return d - p;
+  }
   return __builtin_fmaf(-k, box, d);
 }
 
+using exact_image = std::integral_constant<bool, true>;
+using fused_image = std::integral_constant<bool, false>;
+
+// kernel experiments (A/B builds: python -m torchmd_amd._build -DTMD_EXP=<bits> --out=...; see tools/ab_pair.py)
+#ifndef TMD_EXP
+#define TMD_EXP 0
+#endif
 
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH>
 __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
-    double *__restrict__ energies, unsigned *publish, unsigned publish_value) {
+    double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
   // tells the host (host-mapped word) that everything enqueued before this launch has completed
@@ -923,12 +980,19 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   float fx = 0.f, fy = 0.f, fz = 0.f;
   float e_lj = 0.f, e_el = 0.f;  // per-lane fp32 partial sums (~55 pairs), reduced in fp64
 
-  auto body = [&](unsigned tofs, const v4u &raw, bool valid) {  // one list entry
+  // cutoff test as arithmetic (experiment bit 2, unchecked loop, force-only variants): step = clamp((r2max' - r2) *
+  // 2^100, 0, 1) with r2max' the successor of r2max is exactly 1 for r2 <= r2max and 0 beyond (one v_fma with the
+  // clamp modifier + one v_mul at full rate instead of v_cmp into an SGPR pair, 5.3 cycles, + v_cndmask)
+  const float cut_h = -1.2676506e30f;  // -2^100
+  const float cut_c0 = __int_as_float(__float_as_int(r2max) + 1) * 1.2676506e30f;
+  auto body = [&](auto image, auto unchecked, unsigned tofs, const v4u &raw, bool valid) {  // one list entry
+    constexpr bool EXACT = decltype(image)::value;
+    constexpr bool ARITH_CUT = (TMD_EXP & 2) && decltype(unchecked)::value && !ENERGY;
     const float pjx = __uint_as_float(raw.x), pjy = __uint_as_float(raw.y), pjz = __uint_as_float(raw.z);
     const float pjw = __uint_as_float(raw.w);
-    const float dx = min_image_magic(pi.x - pjx, bx, ibx);
-    const float dy = min_image_magic(pi.y - pjy, by, iby);
-    const float dz = min_image_magic(pi.z - pjz, bz, ibz);
+    const float dx = min_image_magic<EXACT>(pi.x - pjx, bx, ibx);
+    const float dy = min_image_magic<EXACT>(pi.y - pjy, by, iby);
+    const float dz = min_image_magic<EXACT>(pi.z - pjz, bz, ibz);
     const float r2 = norm2(dx, dy, dz);
     const bool hit = valid && (r2 <= r2max);
     const float rinv = __frsqrt_rn(r2);
@@ -969,7 +1033,13 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
       if (ELEC) fs += (pi.w * pjw) * (two_krf - rinv2 * rinv);
     }
     if (ENERGY && ELEC) e_el += hit ? (pi.w * pjw) * (rinv + c.krf * r2 - c.crf) : 0.f;  // krf = crf = 0: plain Coulomb
-    fs = hit ? fs : 0.f;
+    if (ARITH_CUT) {
+      float step;
+      asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(step) : "v"(r2), "v"(cut_h), "s"(cut_c0));
+      fs *= step;  // (every entry of the unchecked loop is a real pair beyond 0.1 A: fs is finite)
+    } else {
+      fs = hit ? fs : 0.f;
+    }
     fx = __builtin_fmaf(-dx, fs, fx);
     fy = __builtin_fmaf(-dy, fs, fy);
     fz = __builtin_fmaf(-dz, fs, fz);
@@ -979,27 +1049,52 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   // index words are fetched two groups (8 entries per lane, 2 KB per wave) ahead of their use
   v4u nxa = row4[0], nxb = row4[64];  // rows are padded: always readable
   int kk0 = 0;
-  for (; kk0 < nfull; kk0 += UNROLL) {  // every lane has real entries here: no validity test
-    const v4u cur = nxa;
-    nxa = nxb;
-    nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
-    const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
-    v4u raw[UNROLL];
+  using checked_t = std::integral_constant<bool, false>;
+  using unchecked_t = std::integral_constant<bool, true>;
+  auto checked_loop = [&](auto image) {  // per-lane validity
+    for (; kk0 < nkk; kk0 += UNROLL) {
+      const v4u cur = nxa;
+      nxa = nxb;
+      nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
+      const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
+      v4u raw[UNROLL];
+#if TMD_EXP & 1
+      // the last group of a wave: iterations nkk .. are empty for every lane (wave-uniform): neither gathered nor evaluated
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+      for (int u = 0; u < UNROLL; ++u)
+        if (kk0 + u < nkk) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) body(entry[u] >> 24, raw[u], true);  // (n <= 2^20: bits 24..27 are zero)
-  }
-  for (; kk0 < nkk; kk0 += UNROLL) {  // tail: per-lane validity
-    const v4u cur = nxa;
-    nxa = nxb;
-    nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
-    const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
-    v4u raw[UNROLL];
+      for (int u = 0; u < UNROLL; ++u)
+        if (kk0 + u < nkk) body(image, checked_t{}, (entry[u] >> 24) & 0xF8u, raw[u], kk0 + u < myiters);
+#else
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+      for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) body((entry[u] >> 24) & 0xF8u, raw[u], kk0 + u < myiters);  // padding words are garbage
+      for (int u = 0; u < UNROLL; ++u) body(image, checked_t{}, (entry[u] >> 24) & 0xF8u, raw[u], kk0 + u < myiters);  // padding words are garbage
+#endif
+    }
+  };
+  if (extent_needs_exact_image(ext, c.box)) {  // wave-uniform, rare: atoms more than 2.4 box edges apart
+    checked_loop(exact_image{});
+  } else {
+    for (; kk0 < nfull; kk0 += UNROLL) {  // every lane has real entries here: no validity test
+      const v4u cur = nxa;
+      nxa = nxb;
+      nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
+      const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
+      v4u raw[UNROLL];
+#if TMD_EXP & 4
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+#if TMD_EXP & 4
+      __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) body(fused_image{}, unchecked_t{}, entry[u] >> 24, raw[u], true);  // (n <= 2^20: bits 24..27 are zero)
+    }
+    checked_loop(fused_image{});  // tail
   }
   float sx = fx, sy = fy, sz = fz;
 #pragma unroll
@@ -1036,11 +1131,16 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
 // 32-byte records (two 16-byte gathers per entry), 16-byte table entries, half-rate arithmetic; 1/r from v_rsq_f64
 // and two Newton steps.  Same entry format, list layout and decision arithmetic (min_image_magic's fp64 overload:
 // magic number 1.5 * 2^52; norm2's fp64 order).
+template <bool EXACT>
 __device__ __forceinline__ double min_image_magic(double d, double box, double invbox) {
 #pragma clang fp contract(off)
   const double magic = 6755399441055744.0;
   const double t = __builtin_fma(d, invbox, magic);
   const double k = t - magic;
+  if (EXACT) {
+    const double p = box * k;
+    return d - p;
+  }
   return __builtin_fma(-k, box, d);
 }
 
@@ -1049,7 +1149,7 @@ __global__ __launch_bounds__(256) void list_pair_lean_f64_kernel(
     int n, const double4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const double2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<double> c, double *__restrict__ forces, int overwrite,
-    double *__restrict__ energies, unsigned *publish, unsigned publish_value) {
+    double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
   // tells the host (host-mapped word) that everything enqueued before this launch has completed
@@ -1110,12 +1210,13 @@ __global__ __launch_bounds__(256) void list_pair_lean_f64_kernel(
   double fx = 0.0, fy = 0.0, fz = 0.0;
   double e_lj = 0.0, e_el = 0.0;
 
-  auto body = [&](unsigned tofs, const v4u &lo, const v4u &hi, bool valid) {  // one list entry
+  auto body = [&](auto image, unsigned tofs, const v4u &lo, const v4u &hi, bool valid) {  // one list entry
+    constexpr bool EXACT = decltype(image)::value;
     const double pjx = __hiloint2double((int)lo.y, (int)lo.x), pjy = __hiloint2double((int)lo.w, (int)lo.z);
     const double pjz = __hiloint2double((int)hi.y, (int)hi.x), pjw = __hiloint2double((int)hi.w, (int)hi.z);
-    const double dx = min_image_magic(pi.x - pjx, bx, ibx);
-    const double dy = min_image_magic(pi.y - pjy, by, iby);
-    const double dz = min_image_magic(pi.z - pjz, bz, ibz);
+    const double dx = min_image_magic<EXACT>(pi.x - pjx, bx, ibx);
+    const double dy = min_image_magic<EXACT>(pi.y - pjy, by, iby);
+    const double dz = min_image_magic<EXACT>(pi.z - pjz, bz, ibz);
     const double r2 = norm2(dx, dy, dz);
     const bool hit = valid && (r2 <= r2max);
     // 1/r: v_rsq_f64 (~2^-26 relative) + two Newton steps; rejected entries may produce inf/NaN, discarded below
@@ -1165,35 +1266,42 @@ __global__ __launch_bounds__(256) void list_pair_lean_f64_kernel(
   // index words are fetched two groups (8 entries per lane, 2 KB per wave) ahead of their use
   v4u nxa = row4[0], nxb = row4[64];  // rows are padded: always readable
   int kk0 = 0;
-  for (; kk0 < nfull; kk0 += UNROLL) {  // every lane has real entries here: no validity test
-    const v4u cur = nxa;
-    nxa = nxb;
-    nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
-    const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
-    v4u lo[UNROLL], hi[UNROLL];
+  auto checked_loop = [&](auto image) {  // per-lane validity
+    for (; kk0 < nkk; kk0 += UNROLL) {
+      const v4u cur = nxa;
+      nxa = nxb;
+      nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
+      const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
+      v4u lo[UNROLL], hi[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {  // 32-byte records: byte offset = 2 x the entry's 16-byte-record offset
-      const unsigned off = (entry[u] & kEntryOffMask) << 1;
-      lo[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
-      hi[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off + 16u, 0, 0);
+      for (int u = 0; u < UNROLL; ++u) {
+        const unsigned off = (entry[u] & kEntryOffMask) << 1;
+        lo[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
+        hi[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off + 16u, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) body(image, (entry[u] >> 23) & 0x1F0u, lo[u], hi[u], kk0 + u < myiters);  // padding words are garbage
     }
+  };
+  if (extent_needs_exact_image(ext, c.box)) {  // wave-uniform, rare: atoms more than 2.4 box edges apart
+    checked_loop(exact_image{});
+  } else {
+    for (; kk0 < nfull; kk0 += UNROLL) {  // every lane has real entries here: no validity test
+      const v4u cur = nxa;
+      nxa = nxb;
+      nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
+      const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
+      v4u lo[UNROLL], hi[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) body((entry[u] >> 23) & 0x1F0u, lo[u], hi[u], true);
-  }
-  for (; kk0 < nkk; kk0 += UNROLL) {  // tail: per-lane validity
-    const v4u cur = nxa;
-    nxa = nxb;
-    nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
-    const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
-    v4u lo[UNROLL], hi[UNROLL];
+      for (int u = 0; u < UNROLL; ++u) {  // 32-byte records: byte offset = 2 x the entry's 16-byte-record offset
+        const unsigned off = (entry[u] & kEntryOffMask) << 1;
+        lo[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
+        hi[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off + 16u, 0, 0);
+      }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const unsigned off = (entry[u] & kEntryOffMask) << 1;
-      lo[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
-      hi[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off + 16u, 0, 0);
+      for (int u = 0; u < UNROLL; ++u) body(fused_image{}, (entry[u] >> 23) & 0x1F0u, lo[u], hi[u], true);
     }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) body((entry[u] >> 23) & 0x1F0u, lo[u], hi[u], kk0 + u < myiters);  // padding words are garbage
+    checked_loop(fused_image{});  // tail
   }
   double sx = fx, sy = fy, sz = fz;
 #pragma unroll
@@ -1325,6 +1433,7 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
       sv.z = p[2];
       sv.w = x.q;
       s.sorted[x.slot] = sv;
+      extent_note<R>(s.chk.ext, p[0], p[1], p[2]);
       list_check_point<R>(s.chk, c, p[0] - x.r[0], p[1] - x.r[1], p[2] - x.r[2], x.h2);
     }
   }
@@ -1512,10 +1621,11 @@ struct Replica {
   int64_t chains_skipped = 0;
   DevBuf pos_alt;  // second position buffer of tmdhip_md_run's double-buffered integrator kernel
   DevBuf flags;  // int[F_COUNT], see the enum
+  DevBuf extent;  // int[6]: keys of the coordinate extent of sorted_xyzq (extent_note)
   DevBuf paircount;  // unsigned long long
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
-                      &nlist, &nneigh, &flags, &paircount, &pos_alt})
+                      &nlist, &nneigh, &flags, &extent, &paircount, &pos_alt})
       b->release();
   }
 };
@@ -1793,6 +1903,7 @@ ListCheck<R> make_check(const tmdhip_ctx *ctx, Replica &rp) {
   k.skipped = 0;
   k.flags = rp.flags.as<int>();
   k.parity = (int)(rp.step & 1);
+  k.ext = rp.extent.as<int>();
   return k;
 }
 
@@ -1834,7 +1945,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   launch_with_events(list_pair_fast_f32_kernel<L, A, B, ENERGY, S>, dim3((blocks + 7) / 8 * 8), dim3(256), shfast, st, e0, e1, n, \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
                      rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,                   \
-                     ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val)
+                     ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>())
 #define TMD_LAUNCH_FAST(L)                  \
   if (lj && el) {                           \
     TMD_LAUNCH_FAST_T(L, true, true);       \
@@ -1873,7 +1984,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   launch_with_events(list_pair_lean_f64_kernel<L, A, B, ENERGY, S>, dim3((blocks + 7) / 8 * 8), dim3(256), shfast, st, e0, e1, n, \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
                      rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,                   \
-                     ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val)
+                     ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>())
 #define TMD_LAUNCH_FAST(L)                  \
   if (lj && el) {                           \
     TMD_LAUNCH_FAST_T(L, true, true);       \
@@ -1983,7 +2094,8 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
                      rp.cell_start.as<int>(), rp.order_tmp.as<int>(), pos, ctx->qs.as<R>(), ctx->types.as<int>(),
                      rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(),
                      ctx->half_skin.as<R>(), rp.sorted_hs.as<R>(), ctx->vskin_time > 0 ? (const R *)rp.skin_vel : nullptr,
-                     (R)ctx->vskin_floor, (R)ctx->vskin_time, (R)ctx->vskin_cap_len, rp.hs2_dyn.as<R>(), flag);
+                     (R)ctx->vskin_floor, (R)ctx->vskin_time, (R)ctx->vskin_cap_len, rp.hs2_dyn.as<R>(), rp.extent.as<int>(),
+                     flag);
   const R rl = (R)ctx->rlist;
   constexpr int kMaxBuildBlocks = 16384;
   const bool wskin = ctx->half_skin.p != nullptr;
@@ -2043,6 +2155,8 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
                   "TMDHIP_ALGO_ALLPAIRS");
     }
     rp.ncell = rp.grid.nc[0] * rp.grid.nc[1] * rp.grid.nc[2];
+    // new list, new extent (the forced rebuild below notes every position again)
+    TMD_HIP(hipMemcpyAsync(rp.extent.p, kExtentEmpty, sizeof(kExtentEmpty), hipMemcpyHostToDevice, st));
     TMD_TRY(rp.count.ensure(sizeof(int) * (size_t)rp.ncell));
     TMD_TRY(rp.cell_start.ensure(sizeof(int) * ((size_t)rp.ncell + 1)));
     TMD_HIP(hipMemsetAsync(rp.count.p, 0, sizeof(int) * (size_t)rp.ncell, st));
@@ -2513,6 +2627,8 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
     (void)hipMemset(rp.flags.p, 0, sizeof(int) * F_COUNT);
     if (rp.paircount.ensure(sizeof(unsigned long long))) return cleanup(-1);
     (void)hipMemset(rp.paircount.p, 0, sizeof(unsigned long long));
+    if (rp.extent.ensure(sizeof(kExtentEmpty))) return cleanup(-1);
+    (void)hipMemcpy(rp.extent.p, kExtentEmpty, sizeof(kExtentEmpty), hipMemcpyHostToDevice);
   }
   // host arrays are not referenced after create
   ctx->d.types_host = nullptr;
@@ -2746,11 +2862,14 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
   if (!ctx || !pos_dev || !box_host || !energies_host) return fail("tmdhip_compute: null argument");
   hipStream_t st = (hipStream_t)stream;
   const size_t nrep = ctx->rep.size();
-  const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, fbytes = sizeof(int) * F_COUNT * nrep;
+  // landing zone: energies | list flags (padded to 8 bytes: the doubles behind them stay aligned) | kinetic-energy
+  // slots | sequence word on a 64-byte line of its own
+  const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, fbytes = (sizeof(int) * F_COUNT * nrep + 7) / 8 * 8;
+  const size_t seq_off = (ebytes + fbytes + sizeof(double) * nrep + 63) / 64 * 64;
   TMD_TRY(ctx->sync_e.ensure(ebytes));
   if (!ctx->sync_host) {
-    TMD_HIP(hipHostMalloc(&ctx->sync_host, ebytes + fbytes + sizeof(double) * nrep + 64, hipHostMallocMapped));
-    std::memset(ctx->sync_host, 0, ebytes + fbytes + sizeof(double) * nrep + 64);
+    TMD_HIP(hipHostMalloc(&ctx->sync_host, seq_off + 64, hipHostMallocMapped));
+    std::memset(ctx->sync_host, 0, seq_off + 64);
   }
   double *he = (double *)ctx->sync_host;
   int *hf = (int *)((char *)ctx->sync_host + ebytes);
@@ -2770,7 +2889,7 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
     ObsFlagPtrs fp{};
     for (size_t r = 0; r < nrep; ++r) fp.p[r] = lists ? ctx->rep[r].flags.as<int>() : nullptr;
     double *hk = (double *)((char *)ctx->sync_host + ebytes + fbytes);
-    volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->sync_host + ebytes + fbytes + sizeof(double) * nrep + 32);
+    volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->sync_host + seq_off);
     if (++ctx->obs_seq == 0) ctx->obs_seq = 1;
     hipLaunchKernelGGL(observe_publish_kernel, dim3(1), dim3(128), 0, st, (int)nrep, e, (const double *)nullptr, fp, he, hk,
                        hf, const_cast<unsigned *>(hseq), ctx->obs_seq);

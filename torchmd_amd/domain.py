@@ -180,16 +180,36 @@ class DistTransport:
         lib = L.load()
         cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = (cand if os.path.exists(cand) else "").encode()
+        # rank 0 draws the id; a failure there (no librccl to open) must not leave the others waiting in the broadcast:
+        # the id travels with a leading success byte and every rank falls back to the torch.distributed transport
         ident = (C.c_ubyte * L.COMM_ID_BYTES)()
+        ok = 1
         if self.rank == 0:
-            L.check(lib.tmdhip_comm_unique_id(path, ident), "tmdhip_comm_unique_id")
-        t = torch.tensor(list(ident), dtype=torch.uint8, device=self._dev)
+            try:
+                L.check(lib.tmdhip_comm_unique_id(path, ident), "tmdhip_comm_unique_id")
+            except RuntimeError:
+                ok = 0
+        t = torch.tensor([ok] + list(ident), dtype=torch.uint8, device=self._dev)
         self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                             group=self.group)
-        ident = (C.c_ubyte * L.COMM_ID_BYTES)(*t.cpu().tolist())
+        got = t.cpu().tolist()
+        if not got[0]:
+            return None
+        ident = (C.c_ubyte * L.COMM_ID_BYTES)(*got[1:])
         handle = C.c_void_p()
+        made = 1
         with torch.cuda.device(self._dev):
-            L.check(lib.tmdhip_comm_create(C.byref(handle), path, ident, self.rank, self.world), "tmdhip_comm_create")
+            try:
+                L.check(lib.tmdhip_comm_create(C.byref(handle), path, ident, self.rank, self.world), "tmdhip_comm_create")
+            except RuntimeError:
+                made = 0
+        # (a communicator only some ranks could create is useless: agree on the minimum)
+        flag = torch.tensor([made], dtype=torch.int32, device=self._dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        if not int(flag.item()):
+            if made:
+                lib.tmdhip_comm_destroy(handle)
+            return None
         self._native = handle
         return handle
 
@@ -457,13 +477,26 @@ class DomainSet:
         if self._since_migration % k:
             return False
         due = False
+        limit = 0.5 * next(iter(self.domains.values())).skin
+
+        def measured(host):
+            """What was measured must never have crossed the limit already (the extrapolation is only a prediction:
+            hot atoms, a larger check_every, a changed time step) — halo atoms would be missing, forces wrong."""
+            moved = float(host.item()) ** 0.5
+            if moved > limit:
+                self._pending = None
+                raise RuntimeError(f"domain decomposition: an atom moved {moved:.3f} A since the last migration, beyond "
+                                   f"the halo's half skin of {limit:.3f} A, before a migration was requested; the forces "
+                                   "of the last steps are invalid (use a larger halo skin or a smaller check_every)")
+            return moved
+
         if self._pending is not None:
             ev, host, at = self._pending
             ev.synchronize()  # recorded check_every steps ago: long done
             ahead = 1.0 + 2.0 * (self._since_migration + k - at) / at
-            skin = next(iter(self.domains.values())).skin
-            due = float(host.item()) ** 0.5 * ahead > 0.5 * skin
+            due = measured(host) * ahead > limit
         if not due:
+            first_check = self._pending is None  # first boundary after a migration: nothing measured yet
             if self.local:
                 t = torch.stack([d.disp2[0] for d in self.domains.values()]).max().reshape(1)
             else:  # reduced in place: the flag becomes the maximum over all ranks, which is what it is used for
@@ -476,6 +509,11 @@ class DomainSet:
             host.copy_(t, non_blocking=True)
             ev.record(torch.cuda.current_stream(self.device))
             self._pending = (ev, host, self._since_migration)
+            if first_check:
+                # one synchronous look, so that a migration can be requested now already instead of two periods
+                # after the last one (the value is the maximum over all ranks: every rank decides alike)
+                ev.synchronize()
+                due = measured(host) * (1.0 + 2.0 * k / self._since_migration) > limit
         return due
 
     def migrate(self):
@@ -542,8 +580,9 @@ class DomainSet:
                 self._exchange(static=False)
             self.compute_forces()
             self._nstep += 1
-        for d in self.domains.values():
-            dd_step(d, 1)
+        if niter > 0:  # (nothing was drifted otherwise: a lone second half kick would be applied twice)
+            for d in self.domains.values():
+                dd_step(d, 1)
 
     def _step_native(self, comm, niter, dt, gamma, vnoise, seed):
         """`niter` iterations enqueued from C (`tmdhip_dd_run`: RCCL send/recv on the compute stream); Python

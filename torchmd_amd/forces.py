@@ -591,7 +591,9 @@ class Forces:
             if toNumpy:
                 return [float(v) for v in tot]
             tot = torch.as_tensor(tot, device=pos.device).to(pos.dtype)
-            if differentiable and (want_forces or scratch is not None) and (not explicit_forces or not want_forces):
+            # whenever a force buffer was filled the potential is differentiable w.r.t. `pos` (in the reference it
+            # always is a torch expression of pos): backward() hands out -F, decoupled from the caller's tensor
+            if differentiable and (want_forces or scratch is not None):
                 fsrc = forces if want_forces else scratch
                 tot = _PotentialWithGrad.apply(pos, tot, fsrc.detach().clone())
             return tot
