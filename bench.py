@@ -30,7 +30,10 @@ TIMESTEP_FS = 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
+PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+FLOP_PER_PAIR = 50.0             # ~50 FLOP + 1 rsqrt per in-cutoff pair
+SIMDS, NOMINAL_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues over 2 cycles per SIMD
 
 
 def timing_stride(steps):
@@ -40,17 +43,20 @@ def timing_stride(steps):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/): counters
-    cannot be collected inside the timed run, so the figure of the same kernel + workload measured with
-    `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` is reported, with its provenance (file and the commit the
-    PMC pass was run on)."""
-    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-        return float(d["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT), d.get("commit")
-    except Exception:
-        return None, None, None
+    """Counter figures of the dominant kernel from the newest committed PMC pass (profiles/): counters cannot be
+    collected inside the timed run, so what `rocprofv3 --pmc` measured for the same kernel + workload is reported
+    with its provenance (file and the commit the pass was run on): HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE,
+    the guide's gfx950 correction) and VALU wave-instructions per launch (SQ_INSTS_VALU)."""
+    for name in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+            return (float(d["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT), d.get("commit"),
+                    d.get("valu_wave_instr_per_launch"))
+        except Exception:
+            continue
+    return None, None, None, None
 
 
 def self_launch(args):
@@ -356,7 +362,15 @@ def main():
     pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
     achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
     step_bytes = 4.0 * pcut + 132.0 * natoms  # whole step incl. integrator
-    traffic, traffic_src, traffic_commit = pmc_traffic() if (args.nside == 32) else (None, None, None)
+    traffic, traffic_src, traffic_commit, valu_instr = pmc_traffic() if (args.nside == 32) else (None, None, None, None)
+    # the other two ceilings of SURVEY 8(d): fp32 vector ALU (50 FLOP per unique in-cutoff pair) and VALU issue
+    # (wave-instructions of the PMC pass x 2 cycles per SIMD at the nominal clock)
+    alu_tflops = FLOP_PER_PAIR * pcut / pair_avg_s / 1e12 if pair_avg_s > 0 else 0.0
+    valu_issue = None
+    if valu_instr and pair_avg_s > 0:
+        cyc = pair_avg_s * NOMINAL_GHZ * 1e9 * SIMDS / valu_instr
+        valu_issue = {"wave_instr_per_launch": valu_instr, "cycles_per_instr_per_simd": cyc,
+                      "frac_of_2cyc_peak": 2.0 / cyc, "clock_ghz_assumed": NOMINAL_GHZ, "source": traffic_src}
 
     out = {
         "metric": "ns/day (aggregate over replicas), 100k-atom TIP3P water box, 9 A cutoff + reaction field",
@@ -398,7 +412,8 @@ def main():
         },
         "roofline": {
             "kernel": "list_pair_fast_f32_kernel<8> (lean scalar fp32, LJ + reaction field)",
-            "bound": "hbm",
+            "bound": "hbm",  # the ceiling `achieved / peak / frac` are quoted against (SURVEY 8(d)'s algorithmic bytes) ...
+            "limited_by": "VALU issue + gather (texture-addresser) rate, not HBM: see `alu`, `valu_issue` and DESIGN.md 6c",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -413,6 +428,9 @@ def main():
                        "launch of the timed region, on the launch stream" + (" (the first 8 of them)" if args.steps < 128 else ""))
             if stride > 1 else "HIP start/stop events attached to the dispatch of every pair-kernel launch of the timed region",
             "step_frac_of_hbm_roofline": (step_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
+            "alu": {"flops_per_launch": FLOP_PER_PAIR * pcut, "achieved_tflops": alu_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": alu_tflops / FP32_VECTOR_PEAK_TFLOPS},
+            "valu_issue": valu_issue,
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -29,6 +29,23 @@ def child(args):
     dev = torch.device("cuda:0")
     mol, par, system, forces, box = build_system(args.nside, dev, torch.float32, seed=1)
     forces.compute(system.pos, system.box, system.forces)
+    if args.static:  # no dynamics (debug builds with wrong results): the pair kernel on the start configuration only
+        from torchmd_amd.forces import Forces
+        forces = Forces(par, terms=["lj", "electrostatics"], cutoff=9.0, rfa=True)  # (no bonded kernel adding into F)
+        F = torch.zeros_like(system.pos)
+        forces._evaluate(system.pos, system.box, F, False, True)
+        forces.enable_timing(system.pos, True, every=1)
+        forces.read_timing(system.pos, reset=True)
+        for _ in range(200):
+            forces._evaluate(system.pos, system.box, F, False, True)
+        ms, n = forces.read_timing(system.pos, reset=True)
+        if args.dump:  # debug builds that store a wave timeline in the force buffer
+            import numpy as np
+            np.save(args.dump, F.detach().cpu().numpy())
+        print("ABRESULT " + json.dumps({"pair_us": ms / max(n, 1) * 1e3, "step_us": 0.0, "eval_us": 0.0, "eval_rebuild_us": 0.0,
+                                        "rebuilds": 0, "entries": int(forces.stats(system.pos)["list_entries"]),
+                                        "chains_skipped": 0, "force_checksum": float(F.double().abs().sum().item())}), flush=True)
+        return
     Integrator(system, forces, 1.0, dev, gamma=10.0, T=300.0).step(args.relax)
     integ = Integrator(system, forces, 1.0, dev, gamma=0.1, T=300.0)
     integ.step(200)
@@ -78,6 +95,8 @@ def main():
     ap.add_argument("--relax", type=int, default=600)
     ap.add_argument("--nside", type=int, default=32)
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--static", action="store_true", help="time the pair kernel on the start configuration, no MD")
+    ap.add_argument("--dump", default=None, help="with --static: save the force buffer of the last evaluation (.npy)")
     ap.add_argument("--env", action="append", default=[], help="NAME=VALUE for every child (repeatable)")
     args = ap.parse_args()
     if args.child:
@@ -91,8 +110,10 @@ def main():
             for kv in args.env:
                 k, v = kv.split("=", 1)
                 env[k] = v
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--steps", str(args.steps), "--relax",
-                                str(args.relax), "--nside", str(args.nside)], env=env, capture_output=True, text=True)
+            p = subprocess.run(["timeout", "90", sys.executable, os.path.abspath(__file__), "--child", "--steps", str(args.steps), "--relax",
+                                str(args.relax), "--nside", str(args.nside)] + (["--static"] if args.static else [])
+                               + (["--dump", args.dump] if args.dump else []),
+                               env=env, capture_output=True, text=True)
             line = next((l for l in p.stdout.splitlines() if l.startswith("ABRESULT ")), None)
             if line is None:
                 print(f"{lib}: FAILED rc={p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}", flush=True)

@@ -909,8 +909,23 @@ using fused_image = std::integral_constant<bool, false>;
 #define TMD_EXP 0
 #endif
 
+// What the loop below is shaped by (gfx950, tools/ubench/valu_detail.hip + body_bisect.hip, 6 waves per SIMD; cycles
+// per wave-instruction per SIMD at 2.4 GHz):
+//   plain fp32 / integer VALU with VGPR, inline-constant or 32-bit-literal operands     2.1 - 2.35
+//   ANY SGPR operand (VOP2 src0, VOP3 src0/src2: v_fma/v_mul/v_sub/v_fmac)              4.05   <- half rate
+//   v_cmp (VCC or SGPR pair) 4.1, v_cndmask with an SGPR/VCC mask 4.1, SDWA forms 4.1, v_mov_b64 4.1,
+//   VOP3-only integer ops (v_perm, v_bfe, v_alignbit, v_and_or, v_lshl_or) 4.1
+//   v_rsq_f32: 8.1 back to back, ~10 in bursts of four, ~19 when it stands alone among plain instructions
+//   VGPR bank conflicts: none measurable (only three sources in ONE bank cost 4.1)
+// The compiler keeps every uniform value (box, 1/box, r2max) in SGPRs — 24 of the 36 v_fma of a 4-entry group read
+// one — rotates the prefetched list words with v_mov_b64, advances the list pointer with a 64-bit VALU add and puts
+// the list load IN FRONT of the gathers, where every wait for a gather (vmcnt retires in order) also waits for the
+// list stream from the Infinity Cache.  Hence: loop constants laundered into VGPRs; the cutoff test as arithmetic
+// (v_fma with clamp + v_mul) where no energy is wanted; the four v_rsq of a group issued back to back; list words
+// through a raw buffer with a SCALAR running offset, requested behind the gathers issued in the same breath; and the
+// unchecked groups software-pipelined over two register sets (gathers of group g+1 in flight while g is evaluated).
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH>
-__global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
+__global__ __launch_bounds__(256, 5) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
@@ -921,6 +936,38 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   if (publish && blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __shared__ __align__(16) float2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
+  const int lane = threadIdx.x & 63;
+  // XCD-aware block order: consecutive block ids go to the 8 XCDs round-robin, so block b works on
+  // chunk (b % 8) * gridDim.x/8 + b / 8 — every XCD (own L2) gets a contiguous eighth of the cell-sorted
+  // atoms and gathers neighbours from that region only.  gridDim.x is a multiple of 8; the surplus
+  // blocks of the last eighths have nothing to do.
+  const int blk = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  if (blk * (int)(blockDim.x >> 6) * APW >= n) return;  // (block-uniform: nobody is left waiting at the barrier below)
+  const int wave = __builtin_amdgcn_readfirstlane(blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+  const int a = wave * APW + lane / LPA;
+  const int sub = lane % LPA;
+  const bool active = a < n;
+
+  // ---- prologue: every load a wave needs before its first gather is requested HERE, in one batch, and only then
+  // is the LJ table staged (a wave's life used to begin with three dependent memory round trips — table, then
+  // atom record / list length, then the first list word — 5 500 of its ~40 000 cycles)
+  // list words of this wave: group G (iterations 4G .. 4G+3 of all 64 lanes) is the 1 KB at byte G * 1024; rows are
+  // padded, and reads past the buffer's end return 0
+  const unsigned *wrow = nlist + (size_t)wave * maxn * APW;
+  const __amdgpu_buffer_rsrc_t lrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(wrow), 0, maxn * APW * 4 + 4096, 0x00020000);
+  const unsigned lvoff = (unsigned)lane * 16u;
+  auto list_word = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * 1024, 0); };
+  v4u word = list_word(0);  // list word of the next group to be gathered (in flight)
+  float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+  int nn = 0, oi = 0;
+  unsigned trow = 0;  // byte offset of this atom's row of the LDS table
+  if (active) {
+    pi = sorted[a];
+    nn = nneigh[a];
+    trow = (unsigned)stype[a] << 8;
+    oi = order[a];
+  }
   // (only the rows of existing classes are ever read: ntypes x 32 entries instead of 32 x 32 — at 10^6 LJ atoms
   // with 64 atoms per block the full table was 15 625 x 8 KB of staging)
   for (int t = threadIdx.x; t < ntypes * kEntryTypes; t += blockDim.x) {
@@ -931,25 +978,6 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63;
-  // XCD-aware block order: consecutive block ids go to the 8 XCDs round-robin, so block b works on
-  // chunk (b % 8) * gridDim.x/8 + b / 8 — every XCD (own L2) gets a contiguous eighth of the cell-sorted
-  // atoms and gathers neighbours from that region only.  gridDim.x is a multiple of 8; the surplus
-  // blocks of the last eighths have nothing to do.
-  const int blk = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-  if (blk * 4 * APW >= n) return;
-  const int wave = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int a = wave * APW + lane / LPA;
-  const int sub = lane % LPA;
-  const bool active = a < n;
-  float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-  int nn = 0;
-  unsigned trow = 0;  // byte offset of this atom's row of the LDS table
-  if (active) {
-    pi = sorted[a];
-    nn = nneigh[a];
-    trow = (unsigned)stype[a] << 8;
-  }
   const int myiters = (nn - sub + LPA - 1) / LPA;  // entries kk < myiters are real for this lane
   int itmax = myiters, itmin = myiters;
 #pragma unroll
@@ -962,8 +990,6 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   // the slot's bits 20..22 to be zero: systems of more than 2^20 atoms run all their iterations in the checked
   // loop, which masks the offset
   const int nfull = n > (1 << 20) ? 0 : __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL;
-  // a lane's entries of iterations 4G .. 4G+3 are one 16-byte word at row4[G * 64]
-  const v4u *row4 = reinterpret_cast<const v4u *>(nlist + (size_t)wave * maxn * APW) + lane;
   // bounds-checked raw buffer over sorted_xyzq: lanes past the end of their list read whatever the
   // (uninitialised) padding entry points at — out-of-range offsets return 0 instead of faulting — and
   // are discarded by `valid`
@@ -973,126 +999,172 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
   const float two_krf = 2.0f * c.krf;
   const float qi2k = pi.w * two_krf;
   const float sw_ir = c.inv_switch_range, sw_t0 = -c.switch_dist * c.inv_switch_range;
-  const float bx = c.box[0], by = c.box[1], bz = c.box[2];
-  const float ibx = c.invbox[0], iby = c.invbox[1], ibz = c.invbox[2];
-  const float r2max = c.r2max;
+  auto in_vgpr = [](float sv) {  // a uniform value the compiler can no longer keep in an SGPR
+    float v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(sv));
+    return v;
+  };
+  const float vbx = in_vgpr(c.box[0]), vby = in_vgpr(c.box[1]), vbz = in_vgpr(c.box[2]);
+  const float vibx = in_vgpr(c.invbox[0]), viby = in_vgpr(c.invbox[1]), vibz = in_vgpr(c.invbox[2]);
+  const float vr2max = in_vgpr(c.r2max);
+  // cutoff test as arithmetic: step = clamp((r2max' - r2) * 2^100, 0, 1) with r2max' the successor of r2max is exactly
+  // 1 for r2 <= r2max and 0 beyond
+  const float cut_h = in_vgpr(-1.2676506e30f);  // -2^100
+  const float cut_c0 = in_vgpr(__int_as_float(__float_as_int(c.r2max) + 1) * 1.2676506e30f);
 
   float fx = 0.f, fy = 0.f, fz = 0.f;
   float e_lj = 0.f, e_el = 0.f;  // per-lane fp32 partial sums (~55 pairs), reduced in fp64
 
-  // cutoff test as arithmetic (experiment bit 2, unchecked loop, force-only variants): step = clamp((r2max' - r2) *
-  // 2^100, 0, 1) with r2max' the successor of r2max is exactly 1 for r2 <= r2max and 0 beyond (one v_fma with the
-  // clamp modifier + one v_mul at full rate instead of v_cmp into an SGPR pair, 5.3 cycles, + v_cndmask)
-  const float cut_h = -1.2676506e30f;  // -2^100
-  const float cut_c0 = __int_as_float(__float_as_int(r2max) + 1) * 1.2676506e30f;
-  auto body = [&](auto image, auto unchecked, unsigned tofs, const v4u &raw, bool valid) {  // one list entry
+  using checked_t = std::integral_constant<bool, false>;
+  using unchecked_t = std::integral_constant<bool, true>;
+  // one group = this lane's 4 entries of iterations kk0 .. kk0+3 (one 16-byte list word) and their 4 gathered records;
+  // tab[u] = byte offset of entry u's {-12 A, 6 B} in the LDS table (row of type i | 8 x type j)
+  auto group = [&](auto image, auto unchecked, const unsigned (&tab)[UNROLL], const v4u (&raw)[UNROLL], int kk0) {
     constexpr bool EXACT = decltype(image)::value;
-    constexpr bool ARITH_CUT = (TMD_EXP & 2) && decltype(unchecked)::value && !ENERGY;
-    const float pjx = __uint_as_float(raw.x), pjy = __uint_as_float(raw.y), pjz = __uint_as_float(raw.z);
-    const float pjw = __uint_as_float(raw.w);
-    const float dx = min_image_magic<EXACT>(pi.x - pjx, bx, ibx);
-    const float dy = min_image_magic<EXACT>(pi.y - pjy, by, iby);
-    const float dz = min_image_magic<EXACT>(pi.z - pjz, bz, ibz);
-    const float r2 = norm2(dx, dy, dz);
-    const bool hit = valid && (r2 <= r2max);
-    const float rinv = __frsqrt_rn(r2);
-    const float rinv2 = rinv * rinv;
-    const float rinv6 = rinv2 * rinv2 * rinv2;
-    float fs;  // (dE/dr) / r; rejected entries may produce inf/NaN here, the select below discards them
-    float2 ab = make_float2(0.f, 0.f);  // (-12 A, 6 B)
-    if (LJ) ab = *reinterpret_cast<const float2 *>(tbase + (trow | tofs));
-    // E_lj = (A r^-6 - B) r^-6 from the force coefficients (energy / switching variants only)
-    auto elj_of = [&](float r6) { return __builtin_fmaf(ab.x * (-1.0f / 12.0f), r6, ab.y * (-1.0f / 6.0f)) * r6; };
-    if (LJ && !SWITCH && ELEC) {
-      const float qq = pi.w * pjw;
-      const float p = __builtin_fmaf(ab.x, rinv6, ab.y) * rinv6;  // (a12 rinv6 + b6) rinv6
-      const float g = __builtin_fmaf(-qq, rinv, p);
-      fs = __builtin_fmaf(rinv2, g, qi2k * pjw);
-      if (ENERGY) e_lj += hit ? elj_of(rinv6) : 0.f;
-    } else {
-      fs = 0.f;
-      float sw = 1.f;  // switching function S(r) of the LJ term (forces.py:402-412), 1 below switch_dist
-      if (LJ) {
-        fs = __builtin_fmaf(ab.x, rinv6, ab.y) * (rinv6 * rinv2);
-        if (SWITCH) {
-          // t = (r - r_s)/(r_c - r_s) clamped at 0: S = 1 + t^3 (-10 + t (15 - 6 t)),
-          // S' = t^2 (-30 + t (60 - 30 t)) / (r_c - r_s);  (dE/dr)/r = S f + E S' x, x = 1/r (exact) or
-          // 1/r^2 (the reference's explicit-force expression divides the switching term by r once more)
-          const float r = r2 * rinv;
-          const float t = fmaxf(__builtin_fmaf(r, sw_ir, sw_t0), 0.f);
-          const float t2 = t * t;
-          const float pp = __builtin_fmaf(t, __builtin_fmaf(t, -6.f, 15.f), -10.f);
-          sw = __builtin_fmaf(t2 * t, pp, 1.f);
-          const float dq = __builtin_fmaf(t, __builtin_fmaf(t, -30.f * sw_ir, 60.f * sw_ir), -30.f * sw_ir);
-          const float elj = elj_of(rinv6);
-          const float x = c.switch_reference_mode ? rinv2 : rinv;
-          fs = __builtin_fmaf(sw, fs, elj * (t2 * dq) * x);
+    constexpr bool UNCHECKED = decltype(unchecked)::value;
+    constexpr bool ARITH_CUT = UNCHECKED && !ENERGY;
+    float dx[UNROLL], dy[UNROLL], dz[UNROLL], r2[UNROLL], rinv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      dx[u] = min_image_magic<EXACT>(pi.x - __uint_as_float(raw[u].x), vbx, vibx);
+      dy[u] = min_image_magic<EXACT>(pi.y - __uint_as_float(raw[u].y), vby, viby);
+      dz[u] = min_image_magic<EXACT>(pi.z - __uint_as_float(raw[u].z), vbz, vibz);
+      r2[u] = norm2(dx[u], dy[u], dz[u]);
+    }
+    asm("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7"
+        : "=&v"(rinv[0]), "=&v"(rinv[1]), "=&v"(rinv[2]), "=&v"(rinv[3])
+        : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]));
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const bool valid = UNCHECKED || (kk0 + u < myiters);  // padding words are garbage
+      const float pjw = __uint_as_float(raw[u].w);
+      const bool hit = valid && (r2[u] <= vr2max);
+      const float rinv2 = rinv[u] * rinv[u];
+      const float rinv6 = rinv2 * rinv2 * rinv2;
+      float fs;  // (dE/dr) / r; rejected entries may produce inf/NaN here, the select below discards them
+      float2 ab = make_float2(0.f, 0.f);  // (-12 A, 6 B)
+      if (LJ) ab = *reinterpret_cast<const float2 *>(tbase + tab[u]);
+      // E_lj = (A r^-6 - B) r^-6 from the force coefficients (energy / switching variants only)
+      auto elj_of = [&](float r6) { return __builtin_fmaf(ab.x * (-1.0f / 12.0f), r6, ab.y * (-1.0f / 6.0f)) * r6; };
+      if (LJ && !SWITCH && ELEC) {
+        const float qq = pi.w * pjw;
+        const float p = __builtin_fmaf(ab.x, rinv6, ab.y) * rinv6;  // (a12 rinv6 + b6) rinv6
+        const float g = __builtin_fmaf(-qq, rinv[u], p);
+        fs = __builtin_fmaf(rinv2, g, qi2k * pjw);
+        if (ENERGY) e_lj += hit ? elj_of(rinv6) : 0.f;
+      } else {
+        fs = 0.f;
+        float sw = 1.f;  // switching function S(r) of the LJ term (forces.py:402-412), 1 below switch_dist
+        if (LJ) {
+          fs = __builtin_fmaf(ab.x, rinv6, ab.y) * (rinv6 * rinv2);
+          if (SWITCH) {
+            // t = (r - r_s)/(r_c - r_s) clamped at 0: S = 1 + t^3 (-10 + t (15 - 6 t)),
+            // S' = t^2 (-30 + t (60 - 30 t)) / (r_c - r_s);  (dE/dr)/r = S f + E S' x, x = 1/r (exact) or
+            // 1/r^2 (the reference's explicit-force expression divides the switching term by r once more)
+            const float r = r2[u] * rinv[u];
+            const float t = fmaxf(__builtin_fmaf(r, sw_ir, sw_t0), 0.f);
+            const float t2 = t * t;
+            const float pp = __builtin_fmaf(t, __builtin_fmaf(t, -6.f, 15.f), -10.f);
+            sw = __builtin_fmaf(t2 * t, pp, 1.f);
+            const float dq = __builtin_fmaf(t, __builtin_fmaf(t, -30.f * sw_ir, 60.f * sw_ir), -30.f * sw_ir);
+            const float elj = elj_of(rinv6);
+            const float x = c.switch_reference_mode ? rinv2 : rinv[u];
+            fs = __builtin_fmaf(sw, fs, elj * (t2 * dq) * x);
+          }
+          if (ENERGY) e_lj += hit ? sw * elj_of(rinv6) : 0.f;
         }
-        if (ENERGY) e_lj += hit ? sw * elj_of(rinv6) : 0.f;
+        if (ELEC) fs += (pi.w * pjw) * (two_krf - rinv2 * rinv[u]);
       }
-      if (ELEC) fs += (pi.w * pjw) * (two_krf - rinv2 * rinv);
+      if (ENERGY && ELEC) e_el += hit ? (pi.w * pjw) * (rinv[u] + c.krf * r2[u] - c.crf) : 0.f;  // krf = crf = 0: plain Coulomb
+      if (ARITH_CUT) {
+        float step;
+        asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(step) : "v"(r2[u]), "v"(cut_h), "v"(cut_c0));
+        fs *= step;  // (every entry of the unchecked loop is a real pair, not a padding word: fs is finite)
+      } else {
+        fs = hit ? fs : 0.f;
+      }
+      fx = __builtin_fmaf(-dx[u], fs, fx);
+      fy = __builtin_fmaf(-dy[u], fs, fy);
+      fz = __builtin_fmaf(-dz[u], fs, fz);
     }
-    if (ENERGY && ELEC) e_el += hit ? (pi.w * pjw) * (rinv + c.krf * r2 - c.crf) : 0.f;  // krf = crf = 0: plain Coulomb
-    if (ARITH_CUT) {
-      float step;
-      asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(step) : "v"(r2), "v"(cut_h), "s"(cut_c0));
-      fs *= step;  // (every entry of the unchecked loop is a real pair beyond 0.1 A: fs is finite)
-    } else {
-      fs = hit ? fs : 0.f;
-    }
-    fx = __builtin_fmaf(-dx, fs, fx);
-    fy = __builtin_fmaf(-dy, fs, fy);
-    fz = __builtin_fmaf(-dz, fs, fz);
   };
 
   static_assert(UNROLL == 4, "one dwordx4 of list per lane and group");
-  // index words are fetched two groups (8 entries per lane, 2 KB per wave) ahead of their use
-  v4u nxa = row4[0], nxb = row4[64];  // rows are padded: always readable
-  int kk0 = 0;
-  using checked_t = std::integral_constant<bool, false>;
-  using unchecked_t = std::integral_constant<bool, true>;
-  auto checked_loop = [&](auto image) {  // per-lane validity
-    for (; kk0 < nkk; kk0 += UNROLL) {
-      const v4u cur = nxa;
-      nxa = nxb;
-      nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
-      const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
+  // issue the 4 gathers of the group whose list word is `w` and form its table offsets (unchecked: n <= 2^20, bits
+  // 24..27 of an entry are zero; checked: padding words are garbage, the offset is masked)
+  auto issue = [&](auto unchecked, const v4u &w, v4u (&raw)[UNROLL], unsigned (&tab)[UNROLL]) {
+    const unsigned entry[UNROLL] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) tab[u] = trow | (decltype(unchecked)::value ? entry[u] >> 24 : (entry[u] >> 24) & 0xF8u);
+  };
+  const int gall = (nkk + UNROLL - 1) / UNROLL;  // groups of this wave
+  int g = 0;                                     // next group to evaluate; `word` = its list word
+  // A list word is requested AFTER the gathers issued in the same breath (see the head comment); sched_barrier pins
+  // that order against the compiler's preference.
+  auto checked_loop = [&](auto image) {  // per-lane validity; not pipelined (the tail is short)
+    for (; g < gall; ++g) {
       v4u raw[UNROLL];
-#if TMD_EXP & 1
-      // the last group of a wave: iterations nkk .. are empty for every lane (wave-uniform): neither gathered nor evaluated
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-        if (kk0 + u < nkk) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-        if (kk0 + u < nkk) body(image, checked_t{}, (entry[u] >> 24) & 0xF8u, raw[u], kk0 + u < myiters);
-#else
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) body(image, checked_t{}, (entry[u] >> 24) & 0xF8u, raw[u], kk0 + u < myiters);  // padding words are garbage
-#endif
+      unsigned tab[UNROLL];
+      issue(checked_t{}, word, raw, tab);
+      __builtin_amdgcn_sched_barrier(0);
+      word = list_word(g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      group(image, checked_t{}, tab, raw, g * UNROLL);
     }
   };
   if (extent_needs_exact_image(ext, c.box)) {  // wave-uniform, rare: atoms more than 2.4 box edges apart
     checked_loop(exact_image{});
   } else {
-    for (; kk0 < nfull; kk0 += UNROLL) {  // every lane has real entries here: no validity test
-      const v4u cur = nxa;
-      nxa = nxb;
-      nxb = row4[(size_t)((kk0 >> 2) + 2) * 64];
-      const unsigned entry[UNROLL] = {cur.x, cur.y, cur.z, cur.w};
-      v4u raw[UNROLL];
-#if TMD_EXP & 4
-      __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
-#if TMD_EXP & 4
-      __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) body(fused_image{}, unchecked_t{}, entry[u] >> 24, raw[u], true);  // (n <= 2^20: bits 24..27 are zero)
+    const int gfull = nfull / UNROLL;  // groups in which every lane has real entries: no validity test
+    // Software pipeline over the unchecked groups: the gathers of group g+1 (and the list word of g+2) are requested
+    // before group g is evaluated, into the other register set; a wave then waits for memory once per group, for
+    // requests it made a whole group's arithmetic earlier (counters of the unpipelined loop: 44 % of a wave's cycles
+    // in s_waitcnt, 27 % issuing — at the ~5 cycles per instruction a wave can issue by itself, six such waves do
+    // not fill the VALU pipe).  94 VGPRs: five waves per SIMD.
+    if constexpr (ENERGY || SWITCH) {  // (the variants with more live values keep the plain loop: no spills at 5 waves)
+      for (; g < gfull; ++g) {
+        v4u raw[UNROLL];
+        unsigned tab[UNROLL];
+        issue(unchecked_t{}, word, raw, tab);
+        __builtin_amdgcn_sched_barrier(0);
+        word = list_word(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, tab, raw, g * UNROLL);
+      }
+    } else if (gfull > 0) {
+      v4u ra[UNROLL], rb[UNROLL];
+      unsigned ta[UNROLL], tb[UNROLL];
+      issue(unchecked_t{}, word, ra, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      word = list_word(1);
+      __builtin_amdgcn_sched_barrier(0);
+      while (true) {
+        if (g + 1 >= gfull) {
+          group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
+          g += 1;
+          break;
+        }
+        issue(unchecked_t{}, word, rb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        word = list_word(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 >= gfull) {
+          group(fused_image{}, unchecked_t{}, tb, rb, (g + 1) * UNROLL);
+          g += 2;
+          break;
+        }
+        issue(unchecked_t{}, word, ra, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        word = list_word(g + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, tb, rb, (g + 1) * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
+        g += 2;
+      }
     }
     checked_loop(fused_image{});  // tail
   }
@@ -1104,7 +1176,6 @@ __global__ __launch_bounds__(256) void list_pair_fast_f32_kernel(
     sz += __shfl_xor(sz, o, 64);
   }
   if (active && sub == 0 && forces) {
-    const int oi = order[a];
     if (overwrite) {
       forces[3 * oi + 0] = sx;
       forces[3 * oi + 1] = sy;
