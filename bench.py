@@ -150,14 +150,26 @@ def run_c5(args, rank, world, local_rank, device, launched):
         alg_bytes = 4.0 * pcut + 28.0 * natoms
         pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
         achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
+        c5_traffic, c5_traffic_src = None, None
+        try:  # HBM bytes per launch from the committed PMC pass of this configuration (profiles/)
+            with open(os.path.join(ROOT, "profiles", "r03_c5_pmc_traffic.json")) as fh:
+                c5_traffic = float(json.load(fh)["hbm_bytes_per_launch"])
+                c5_traffic_src = "profiles/r03_c5_pmc_traffic.json"
+        except Exception:
+            pass
         extra["roofline"] = {
             "kernel": "list_pair_fast_f32_kernel (fp32, LJ)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": c5_traffic, "traffic_source": c5_traffic_src,
+            "algorithmic_bytes_per_launch": alg_bytes,
             "avg_kernel_us": pair_avg_s * 1e6, "launches_timed": int(pair_launches),
+            "alu": {"flops_per_launch": 30.0 * pcut, "achieved_tflops": 30.0 * pcut / pair_avg_s / 1e12 if pair_avg_s > 0 else 0.0,
+                    "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "note": "~30 FLOP per LJ-only pair"},
         }
         extra["list"] = {"rebuilds_in_timed_region": int(st1["n_rebuilds"] - st0["n_rebuilds"]),
                          "entries": int(st1["list_entries"]), "ncell": list(st1["ncell"]), "skin": st1["skin"]}
         extra["temperature_K"] = [float(temp[0])]
+        if not args.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline_c5(natoms)
         f.close()
     else:
         from torchmd_amd.domain import DistTransport, DomainSet
@@ -203,6 +215,48 @@ def run_c5(args, rank, world, local_rank, device, launched):
     if launched:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+
+
+def cpu_baseline_c5(natoms_full, nside_sample=50, budget_s=15.0):
+    """Reference arithmetic on the host cores for config C5, on a BOUNDED sample: the oracle's md_step (same torch
+    CPU ops as the reference, sparse candidate pair list) on a 50^3 = 125 000-atom argon box at the same density,
+    cutoff and thermostat; the cost of the reference's pair arithmetic is linear in the number of atoms at fixed
+    density, so the figure for the 10^6-atom box is the sample's divided by the atom ratio (stated in `sample`)."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import argon_forcefield, lj_box
+    from torchmd_amd.integrator import maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+
+    mol, pos, box = lj_box(nside_sample, seed=0)
+    par = Parameters(argon_forcefield(mol), mol, ["lj"], precision=torch.float32)
+    p = torch.tensor(pos, dtype=torch.float32)[None].contiguous()
+    cbox = torch.zeros(1, 3, 3)
+    for k in range(3):
+        cbox[0, k, k] = float(box[k])
+    torch.manual_seed(1)
+    vel = maxwell_boltzmann(par.masses, 85.0, 1).to(torch.float32)
+    frc = torch.zeros_like(p)
+    masses = par.masses.to(torch.float32).view(-1, 1)
+    pairs = orc.candidate_pairs(pos, box, CUTOFF + 0.6, None)
+    dt, gamma, vcoeff = orc.integrator_constants(TIMESTEP_FS, 1.0, 85.0, masses)
+    kw = dict(cutoff=CUTOFF, pairs=pairs)
+    orc.md_step(par, p, vel, frc, cbox, masses, dt, ["lj"], gamma, vcoeff, **kw)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.md_step(par, p, vel, frc, cbox, masses, dt, ["lj"], gamma, vcoeff, **kw)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    ratio = mol.numAtoms / float(natoms_full)
+    return {
+        "value": ns_per_day(n, el) * ratio, "unit": "ns/day", "cores": torch.get_num_threads(), "kind": "port",
+        "s_per_step_sample": el / n,
+        "source": "oracle (pinned port of the reference arithmetic; /root/reference does not exist on the GPU box)",
+        "sample": f"{n} MD steps of a {mol.numAtoms}-atom argon box at the same density (oracle md_step, {len(pairs)} candidate "
+        f"pairs, list build excluded); value = the sample's ns/day x {ratio:.4f} (atom ratio to the {natoms_full}-atom box: the "
+        "reference's pair arithmetic is linear in N at fixed density)",
+    }
 
 
 def ns_per_day(steps, seconds, timestep_fs=TIMESTEP_FS):

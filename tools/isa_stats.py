@@ -12,16 +12,22 @@ import re
 import sys
 
 
-def cost(m):
-    if m.startswith("v_pk_") or m.startswith("v_lshl") or m.startswith("v_lshr") or m.startswith("v_ashr") or "u24" in m or "i24" in m:
-        return 4.3
-    if m.startswith("v_cmp"):
-        return 5.3
+def cost(m, line=""):
+    """Issue cost in cycles per wave-instruction per SIMD (tools/ubench/valu_detail.hip, valu_rates.hip; gfx950, 6-8 waves
+    per SIMD, 2.4 GHz): plain VALU 2.2; ANY SGPR source operand, v_cmp, v_cndmask with an SGPR/VCC mask, SDWA, v_mov_b64,
+    shifts / mul24 / packed fp32 and the VOP3-only integer ops 4.1; transcendentals ~10 (8.1 back to back, 19 alone)."""
+    if not m.startswith("v_"):
+        return 0.0
     if m.startswith(("v_rsq", "v_rcp", "v_sqrt", "v_exp", "v_log", "v_sin", "v_cos")):
-        return 8.2
-    if m.startswith("v_"):
-        return 2.3
-    return 0.0
+        return 10.0
+    half = (m.startswith(("v_pk_", "v_lshl", "v_lshr", "v_ashr", "v_cmp", "v_cndmask", "v_mov_b64", "v_perm", "v_bfe", "v_alignbit",
+                          "v_and_or", "v_mbcnt", "v_readlane", "v_writelane", "v_readfirstlane", "v_mad_u", "v_mad_i", "v_mul_lo",
+                          "v_mul_hi", "v_lshl_add", "v_add_lshl", "v_mul_f64", "v_fma_f64", "v_add_f64"))
+            or "u24" in m or "i24" in m or "sdwa" in m)
+    ops = line.split(None, 1)[1] if " " in line.strip() else ""
+    srcs = ops.split(",")[1:]
+    sgpr_src = any(re.match(r"\s*-?\|?(s\d+|s\[\d+:\d+\]|vcc|exec)", o) for o in srcs)
+    return 4.1 if (half or sgpr_src) else 2.2
 
 
 def main():
@@ -54,7 +60,7 @@ def main():
             if not t or t[0].startswith((".", ";")) or t[0].endswith(":"):
                 continue
             hist[t[0]] += 1
-            cyc += cost(t[0])
+            cyc += cost(t[0], l.strip())
         nv = sum(v for m, v in hist.items() if m.startswith("v_"))
         print(f"--- loop {k}: lines {a}..{b}: {sum(hist.values())} instr, {nv} VALU, est. {cyc:.0f} VALU cycles")
         print("   " + ", ".join(f"{m} {v}" for m, v in sorted(hist.items(), key=lambda kv: -kv[1])))
