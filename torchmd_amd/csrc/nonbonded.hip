@@ -490,9 +490,13 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
-    int ncell, int nactive, int type_in_entry) {
+    int ncell, int nactive, int type_in_entry, unsigned long long *dbg) {
   if (*flag == 0) return;
+  const unsigned long long dbg_t0 = dbg ? __builtin_readcyclecounter() : 0ull;  // TMDHIP_DEBUG_TIMELINE (tools/build_timeline.py)
   using R4 = typename Vec<R>::T4;
+  // the whole list as a bounds-checked buffer (< 2^30 entries): an out-of-range store is dropped
+  const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      nlist, 0, (int)((((size_t)n + lg.apw - 1) / lg.apw) * (size_t)lg.maxn * lg.apw * 4u), 0x00020000);
   __shared__ int seg_start[128];
   __shared__ int seg_prefix[129];
   __shared__ int seg_code[128];  // periodic image of the stencil cell: 2 bits per axis, 0:-L 1:0 2:+L
@@ -590,7 +594,8 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   constexpr int EXS = 3;
   __shared__ R4 s_rec0[64];
   __shared__ int4 s_rec1[64];
-  __shared__ int s_eb[64], s_more[64], s_cnt[64];
+  __shared__ int s_eb[64], s_more[64];
+  __shared__ __align__(16) int s_cnt[64];
   const int apw_shift = 6 - lg.lpa_shift;
   const unsigned kmask = (unsigned)lg.lpa - 1u;
   for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
@@ -621,6 +626,13 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       ex.w = (int)rowoff;
       s_rec1[lane] = ex;
       long_rows = ne > EXS - 1;
+    } else {
+      // dummy atoms that pad the last batch of four: parked out of reach (never a hit, never a store)
+      R4 p;
+      p.x = (R)-1e18;
+      p.y = p.z = p.w = R(0);
+      s_rec0[lane] = p;
+      s_rec1[lane] = make_int4(-1, -1, -1, 0);
     }
     const bool any_long = __ballot(long_rows) != 0ull;
     __syncthreads();
@@ -706,7 +718,40 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       unsigned recoff;
       asm volatile("v_mov_b32 %0, 0" : "=v"(recoff));
       int t = 0;
-      for (; t + 4 <= ni; t += 4, recoff += 64u) {
+      // Batches of four atoms with ONE branch (any hit at all?) and none inside: a taken scalar branch costs more than
+      // the arithmetic it skips (the per-block timeline gives ~150 cycles per (atom, chunk) combination against ~70
+      // of VALU work).  The four hit counters travel as one 16-byte LDS word each way, and a lane without a hit
+      // stores to an out-of-range offset of a bounds-checked buffer (dropped by the hardware) instead of leaving
+      // exec.  Atoms with long exclusion rows (proteins) keep the branching path.
+      // The last batch is padded with parked dummy atoms (staged above), so there is no scalar remainder loop.
+      if (!any_long) {
+        for (; t < ni; t += 4, recoff += 64u) {
+          const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
+          unsigned long long m[4] = {in_range(p0), in_range(p1), in_range(p2), in_range(p3)};
+          if (!(m[0] | m[1] | m[2] | m[3])) continue;
+          const int4 base4 = *reinterpret_cast<const int4 *>(&s_cnt[t]);
+          const int base[4] = {base4.x, base4.y, base4.z, base4.w};
+          int cnt[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff + 16u * u);
+            m[u] &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) | __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
+                      __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32));
+            const unsigned k = (unsigned)base[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
+            const unsigned kk = k >> lg.lpa_shift;
+            const unsigned pos = (unsigned)ex.w + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u);
+            // lanes that store: hit and below the row's capacity; everybody else gets the out-of-range offset -4
+            const unsigned long long stm = m[u] & __builtin_amdgcn_uicmp(k, (unsigned)lg.maxn, 36 /* ult */);
+            unsigned off;
+            asm("v_cndmask_b32_e64 %0, -4, %1, %2" : "=v"(off) : "v"(pos * 4u), "s"(stm));
+            __builtin_amdgcn_raw_buffer_store_b32(entry, nrsrc, off, 0, 0);
+            cnt[u] = base[u] + (int)__popcll(m[u]);
+          }
+          *reinterpret_cast<int4 *>(&s_cnt[t]) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);  // every lane writes the same values
+        }
+      }
+      for (; t + 4 <= ni; t += 4, recoff += 64u) {  // (cells with long exclusion rows: the branching path)
         const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
         const unsigned long long m0 = in_range(p0), m1 = in_range(p1), m2 = in_range(p2), m3 = in_range(p3);
         if (m0) handle(t, recoff, p0, m0);
@@ -726,6 +771,13 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     wmax = max(wmax, lane < ni ? mycnt : 0);
   }
   } while (LOOP && (cell += gridDim.x) < ncell);
+  if (dbg && lane == 0) {  // per block: entry / exit cycle counters, XCC id, candidates x atoms of its (last) cell
+    unsigned long long *o = dbg + 4 * (size_t)blockIdx.x;
+    o[0] = dbg_t0;
+    o[1] = __builtin_readcyclecounter();
+    o[2] = __builtin_amdgcn_s_getreg((6 << 11) | 20);
+    o[3] = (unsigned long long)wmax;
+  }
   // flags[2] = largest neighbour count ever seen; > maxn means a list was truncated (overflow)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
@@ -924,8 +976,15 @@ using fused_image = std::integral_constant<bool, false>;
 // (v_fma with clamp + v_mul) where no energy is wanted; the four v_rsq of a group issued back to back; list words
 // through a raw buffer with a SCALAR running offset, requested behind the gathers issued in the same breath; and the
 // unchecked groups software-pipelined over two register sets (gathers of group g+1 in flight while g is evaluated).
+#if TMD_EXP & 16  // (bit 64: the pipeline in half-word stages, see below: 72 registers at 7 waves, 64 + spills at 8)
+#define TMD_FAST_WAVES 7
+#elif TMD_EXP & 32
+#define TMD_FAST_WAVES 8
+#else
+#define TMD_FAST_WAVES 5
+#endif
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH>
-__global__ __launch_bounds__(256, 5) void list_pair_fast_f32_kernel(
+__global__ __launch_bounds__(256, TMD_FAST_WAVES) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
@@ -1019,23 +1078,30 @@ __global__ __launch_bounds__(256, 5) void list_pair_fast_f32_kernel(
   using unchecked_t = std::integral_constant<bool, true>;
   // one group = this lane's 4 entries of iterations kk0 .. kk0+3 (one 16-byte list word) and their 4 gathered records;
   // tab[u] = byte offset of entry u's {-12 A, 6 B} in the LDS table (row of type i | 8 x type j)
-  auto group = [&](auto image, auto unchecked, const unsigned (&tab)[UNROLL], const v4u (&raw)[UNROLL], int kk0) {
+  // (a stage = NU entries of a lane: 4 = one whole list word, 2 = half of one)
+  auto group = [&](auto image, auto unchecked, const auto &tab, const auto &raw, int kk0) {
     constexpr bool EXACT = decltype(image)::value;
     constexpr bool UNCHECKED = decltype(unchecked)::value;
     constexpr bool ARITH_CUT = UNCHECKED && !ENERGY;
-    float dx[UNROLL], dy[UNROLL], dz[UNROLL], r2[UNROLL], rinv[UNROLL];
+    constexpr int NU = (int)std::extent<std::remove_reference_t<decltype(tab)>>::value;
+    static_assert(NU == 4 || NU == 2, "stage size");
+    float dx[NU], dy[NU], dz[NU], r2[NU], rinv[NU];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < NU; ++u) {
       dx[u] = min_image_magic<EXACT>(pi.x - __uint_as_float(raw[u].x), vbx, vibx);
       dy[u] = min_image_magic<EXACT>(pi.y - __uint_as_float(raw[u].y), vby, viby);
       dz[u] = min_image_magic<EXACT>(pi.z - __uint_as_float(raw[u].z), vbz, vibz);
       r2[u] = norm2(dx[u], dy[u], dz[u]);
     }
-    asm("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7"
-        : "=&v"(rinv[0]), "=&v"(rinv[1]), "=&v"(rinv[2]), "=&v"(rinv[3])
-        : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]));
+    if constexpr (NU == 4) {
+      asm("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7"
+          : "=&v"(rinv[0]), "=&v"(rinv[1]), "=&v"(rinv[2]), "=&v"(rinv[3])
+          : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]));
+    } else {
+      asm("v_rsq_f32 %0, %2\n\tv_rsq_f32 %1, %3" : "=&v"(rinv[0]), "=&v"(rinv[1]) : "v"(r2[0]), "v"(r2[1]));
+    }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const bool valid = UNCHECKED || (kk0 + u < myiters);  // padding words are garbage
       const float pjw = __uint_as_float(raw[u].w);
       const bool hit = valid && (r2[u] <= vr2max);
@@ -1133,7 +1199,42 @@ __global__ __launch_bounds__(256, 5) void list_pair_fast_f32_kernel(
         __builtin_amdgcn_sched_barrier(0);
         group(fused_image{}, unchecked_t{}, tab, raw, g * UNROLL);
       }
-    } else if (gfull > 0) {
+    }
+#if TMD_EXP & 64
+    // EXPERIMENT (measured, not the default): the pipeline in stages of TWO entries (half a list word) keeps the two
+    // register sets + temporaries within 72 registers — seven waves per SIMD instead of five — and is SLOWER: 46.2 us
+    // against 43.7 at C3 (eight waves, 64 registers + spills: 54 us).  More resident waves mean more neighbourhoods
+    // competing for the 32 KB L1 of the CU, not more hidden latency.
+    else if (gfull > 0) {
+      auto issue2 = [&](unsigned e0, unsigned e1, v4u (&raw)[2], unsigned (&tab)[2]) {
+        raw[0] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, e0 & kEntryOffMask, 0, 0);
+        raw[1] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, e1 & kEntryOffMask, 0, 0);
+        tab[0] = trow | (e0 >> 24);
+        tab[1] = trow | (e1 >> 24);
+      };
+      v4u ra[2], rb[2];
+      unsigned ta[2], tb[2];
+      // `word` = list word g (arrives first), w1 = word g+1, w2 = word g+2 (requested in iteration g)
+      v4u w1 = list_word(1), w2;
+      issue2(word.x, word.y, ra, ta);
+      for (; g < gfull; ++g) {
+        issue2(word.z, word.w, rb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        w2 = list_word(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < gfull) issue2(w1.x, w1.y, ra, ta);  // (wave-uniform)
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, tb, rb, g * UNROLL + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        word = w1;
+        w1 = w2;
+      }
+      // `word` = list word gfull for the tail; w1 (word gfull + 1) is requested again there
+    }
+#else
+    else if (gfull > 0) {
       v4u ra[UNROLL], rb[UNROLL];
       unsigned ta[UNROLL], tb[UNROLL];
       issue(unchecked_t{}, word, ra, ta);
@@ -1166,6 +1267,7 @@ __global__ __launch_bounds__(256, 5) void list_pair_fast_f32_kernel(
         g += 2;
       }
     }
+#endif
     checked_loop(fused_image{});  // tail
   }
   float sx = fx, sy = fy, sz = fz;
@@ -2141,6 +2243,18 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   return 0;
 }
 
+// TMDHIP_DEBUG_TIMELINE=1: every block of the list build records its entry / exit cycle counters (4 x u64 per block),
+// read back with tmdhip_debug_build_timeline (tools/build_timeline.py).  Null otherwise: the kernel stores nothing.
+static DevBuf g_dbg_timeline;
+static size_t g_dbg_blocks = 0;
+unsigned long long *debug_timeline_buffer(int blocks) {
+  static const bool on = std::getenv("TMDHIP_DEBUG_TIMELINE") != nullptr;
+  if (!on) return nullptr;
+  if (g_dbg_timeline.ensure(sizeof(unsigned long long) * 4 * (size_t)blocks)) return nullptr;
+  g_dbg_blocks = (size_t)blocks;
+  return g_dbg_timeline.as<unsigned long long>();
+}
+
 // Enqueue: displacement check -> conditional rebuild chain -> gather.  `force` forces a rebuild.
 // `prechecked`: the fused MD-step kernel already ran the displacement test of this step.
 template <typename R>
@@ -2174,7 +2288,8 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, n, rp.sorted.as<R4>(), rp.sorted_hs.as<R>(),
                        rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
                        (R)ctx->d.cutoff, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
-                       rp.nneigh.as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes);
+                       rp.nneigh.as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes,
+                       debug_timeline_buffer(blocks));
   };
   if (rp.ncell <= kMaxBuildBlocks) {
     if (wskin) launch_build(build_list_kernel<R, false, true>, rp.ncell);
@@ -3084,6 +3199,15 @@ int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream)
   for (auto &rp : ctx->rep) rp.box[0] = -1;  // re-plan + rebuild from the restored positions
   ctx->no_chain_skip_once = true;            // and no chain is left out while the batch is repeated
   return 0;
+}
+
+// debug only (not part of the ABI in include/tmdhip.h): copies the last list build's per-block timeline, returns blocks
+int tmdhip_debug_build_timeline(void *out, size_t max_bytes) {
+  if (!g_dbg_timeline.p || !out) return 0;
+  const size_t bytes = std::min(max_bytes, sizeof(unsigned long long) * 4 * g_dbg_blocks);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(out, g_dbg_timeline.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)g_dbg_blocks;
 }
 
 int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica) {
