@@ -976,15 +976,26 @@ using fused_image = std::integral_constant<bool, false>;
 // (v_fma with clamp + v_mul) where no energy is wanted; the four v_rsq of a group issued back to back; list words
 // through a raw buffer with a SCALAR running offset, requested behind the gathers issued in the same breath; and the
 // unchecked groups software-pipelined over two register sets (gathers of group g+1 in flight while g is evaluated).
-#if TMD_EXP & 16  // (bit 64: the pipeline in half-word stages, see below: 72 registers at 7 waves, 64 + spills at 8)
+#if TMD_EXP & 4
+#define TMD_FAST_WAVES 6
+#elif TMD_EXP & 512
+#define TMD_FAST_WAVES 4
+#elif TMD_EXP & 16  // (bit 64: the pipeline in half-word stages, see below: 72 registers at 7 waves, 64 + spills at 8)
 #define TMD_FAST_WAVES 7
 #elif TMD_EXP & 32
 #define TMD_FAST_WAVES 8
 #else
 #define TMD_FAST_WAVES 5
 #endif
+#if TMD_EXP & 1024
+#define TMD_FAST_THREADS 768
+#elif TMD_EXP & 2048
+#define TMD_FAST_THREADS 512
+#else
+#define TMD_FAST_THREADS 256
+#endif
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH>
-__global__ __launch_bounds__(256, TMD_FAST_WAVES) void list_pair_fast_f32_kernel(
+__global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
@@ -1003,7 +1014,12 @@ __global__ __launch_bounds__(256, TMD_FAST_WAVES) void list_pair_fast_f32_kernel
   const int blk = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
   if (blk * (int)(blockDim.x >> 6) * APW >= n) return;  // (block-uniform: nobody is left waiting at the barrier below)
   const int wave = __builtin_amdgcn_readfirstlane(blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+#if TMD_EXP & 512  // DEBUG (wrong results, timing only): i-pairs — a lane group evaluates the list of atom 2p for atoms 2p, 2p+1
+  const int a = (wave * APW + lane / LPA) * 2;
+  if (wave * APW * 2 >= n) return;
+#else
   const int a = wave * APW + lane / LPA;
+#endif
   const int sub = lane % LPA;
   const bool active = a < n;
 
@@ -1012,11 +1028,23 @@ __global__ __launch_bounds__(256, TMD_FAST_WAVES) void list_pair_fast_f32_kernel
   // atom record / list length, then the first list word — 5 500 of its ~40 000 cycles)
   // list words of this wave: group G (iterations 4G .. 4G+3 of all 64 lanes) is the 1 KB at byte G * 1024; rows are
   // padded, and reads past the buffer's end return 0
+#if TMD_EXP & 512
+  const unsigned *wrow = nlist + (size_t)(2 * wave) * maxn * APW;
+  const __amdgpu_buffer_rsrc_t lrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(wrow), 0, 2 * maxn * APW * 4 + 4096, 0x00020000);
+  const unsigned lvoff = (unsigned)((lane / LPA) / (APW / 2)) * (unsigned)(maxn * APW * 4) +
+                         (unsigned)((((lane / LPA) * 2) % APW) * LPA + sub) * 16u;
+#else
   const unsigned *wrow = nlist + (size_t)wave * maxn * APW;
   const __amdgpu_buffer_rsrc_t lrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(wrow), 0, maxn * APW * 4 + 4096, 0x00020000);
   const unsigned lvoff = (unsigned)lane * 16u;
+#endif
+#if TMD_EXP & 8192  // DEBUG (wrong results, timing only): the list stream from a 4 KB window per wave (cache resident)
+  auto list_word = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, (g & 3) * 1024, 0); };
+#else
   auto list_word = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * 1024, 0); };
+#endif
   v4u word = list_word(0);  // list word of the next group to be gathered (in flight)
   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
   int nn = 0, oi = 0;
@@ -1027,6 +1055,12 @@ __global__ __launch_bounds__(256, TMD_FAST_WAVES) void list_pair_fast_f32_kernel
     trow = (unsigned)stype[a] << 8;
     oi = order[a];
   }
+#if TMD_EXP & 512
+  float4 pi2 = active ? sorted[a + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned trow2 = active ? (unsigned)stype[a + 1] << 8 : 0u;
+  const int oi2 = active ? order[a + 1] : 0;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+#endif
   // (only the rows of existing classes are ever read: ntypes x 32 entries instead of 32 x 32 — at 10^6 LJ atoms
   // with 64 atoms per block the full table was 15 625 x 8 KB of staging)
   for (int t = threadIdx.x; t < ntypes * kEntryTypes; t += blockDim.x) {
@@ -1153,6 +1187,38 @@ __global__ __launch_bounds__(256, TMD_FAST_WAVES) void list_pair_fast_f32_kernel
       fy = __builtin_fmaf(-dy[u], fs, fy);
       fz = __builtin_fmaf(-dz[u], fs, fz);
     }
+#if TMD_EXP & 512
+    {
+      float ex_[NU], ey_[NU], ez_[NU], q2[NU], qinv[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        ex_[u] = min_image_magic<EXACT>(pi2.x - __uint_as_float(raw[u].x), vbx, vibx);
+        ey_[u] = min_image_magic<EXACT>(pi2.y - __uint_as_float(raw[u].y), vby, viby);
+        ez_[u] = min_image_magic<EXACT>(pi2.z - __uint_as_float(raw[u].z), vbz, vibz);
+        q2[u] = norm2(ex_[u], ey_[u], ez_[u]);
+      }
+      asm("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7"
+          : "=&v"(qinv[0]), "=&v"(qinv[1]), "=&v"(qinv[2]), "=&v"(qinv[3])
+          : "v"(q2[0]), "v"(q2[1]), "v"(q2[2]), "v"(q2[3]));
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const float pjw = __uint_as_float(raw[u].w);
+        const float rinv2 = qinv[u] * qinv[u];
+        const float rinv6 = rinv2 * rinv2 * rinv2;
+        const float2 ab = *reinterpret_cast<const float2 *>(tbase + ((tab[u] & 0xFFu) | trow2));
+        const float qq = pi2.w * pjw;
+        const float p = __builtin_fmaf(ab.x, rinv6, ab.y) * rinv6;
+        const float g2 = __builtin_fmaf(-qq, qinv[u], p);
+        float fs = __builtin_fmaf(rinv2, g2, (pi2.w * two_krf) * pjw);
+        float step;
+        asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(step) : "v"(q2[u]), "v"(cut_h), "v"(cut_c0));
+        fs *= step;
+        gx = __builtin_fmaf(-ex_[u], fs, gx);
+        gy = __builtin_fmaf(-ey_[u], fs, gy);
+        gz = __builtin_fmaf(-ez_[u], fs, gz);
+      }
+    }
+#endif
   };
 
   static_assert(UNROLL == 4, "one dwordx4 of list per lane and group");
@@ -1189,7 +1255,7 @@ __global__ __launch_bounds__(256, TMD_FAST_WAVES) void list_pair_fast_f32_kernel
     // requests it made a whole group's arithmetic earlier (counters of the unpipelined loop: 44 % of a wave's cycles
     // in s_waitcnt, 27 % issuing — at the ~5 cycles per instruction a wave can issue by itself, six such waves do
     // not fill the VALU pipe).  94 VGPRs: five waves per SIMD.
-    if constexpr (ENERGY || SWITCH) {  // (the variants with more live values keep the plain loop: no spills at 5 waves)
+    if constexpr (ENERGY || SWITCH || (TMD_EXP & 4)) {  // (the variants with more live values keep the plain loop: no spills at 5 waves)
       for (; g < gfull; ++g) {
         v4u raw[UNROLL];
         unsigned tab[UNROLL];
@@ -1277,6 +1343,22 @@ __global__ __launch_bounds__(256, TMD_FAST_WAVES) void list_pair_fast_f32_kernel
     sy += __shfl_xor(sy, o, 64);
     sz += __shfl_xor(sz, o, 64);
   }
+#if TMD_EXP & 512
+  {
+    float tx = gx, ty = gy, tz = gz;
+#pragma unroll
+    for (int o = LPA >> 1; o > 0; o >>= 1) {
+      tx += __shfl_xor(tx, o, 64);
+      ty += __shfl_xor(ty, o, 64);
+      tz += __shfl_xor(tz, o, 64);
+    }
+    if (active && sub == 0 && forces) {
+      forces[3 * oi2 + 0] = tx;
+      forces[3 * oi2 + 1] = ty;
+      forces[3 * oi2 + 2] = tz;
+    }
+  }
+#endif
   if (active && sub == 0 && forces) {
     if (overwrite) {
       forces[3 * oi + 0] = sx;
@@ -2115,7 +2197,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
     TMD_LAUNCH_FAST_S(L, A, B, false);  \
   }
 #define TMD_LAUNCH_FAST_S(L, A, B, S)                                                                               \
-  launch_with_events(list_pair_fast_f32_kernel<L, A, B, ENERGY, S>, dim3((blocks + 7) / 8 * 8), dim3(256), shfast, st, e0, e1, n, \
+  launch_with_events(list_pair_fast_f32_kernel<L, A, B, ENERGY, S>, dim3(((waves + TMD_FAST_THREADS / 64 - 1) / (TMD_FAST_THREADS / 64) + 7) / 8 * 8), dim3(TMD_FAST_THREADS), shfast, st, e0, e1, n, \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
                      rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,                   \
                      ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>())
