@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
-    int ncell, int nactive, int type_in_entry, unsigned long long *dbg) {
+    int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split) {
   if (*flag == 0) return;
   const unsigned long long dbg_t0 = dbg ? __builtin_readcyclecounter() : 0ull;  // TMDHIP_DEBUG_TIMELINE (tools/build_timeline.py)
   using R4 = typename Vec<R>::T4;
@@ -505,10 +505,19 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   // LOOP: the grid is capped and a block walks several cells (a launch that returns at once on the steps
   // without a rebuild still costs time proportional to its block count: the 343k cells of the 10^6-atom
   // LJ box = 100 us per step).  Systems with fewer cells keep one cell per block (no loop: faster code).
-  int cell = blockIdx.x;
+  // split > 1 (few cells: the one-wave-per-cell grid would leave most SIMDs idle — 729 cells on 1 024 SIMDs at 12 288
+  // atoms, 109 us per build): `split` blocks share a cell, each builds the lists of its share of the cell's atoms
+  // from the same candidates (never together with LOOP)
+  int cell = LOOP ? (int)blockIdx.x : (int)blockIdx.x / split;
+  const int part = LOOP ? 0 : (int)blockIdx.x % split;
   do {
-  const int cs = cell_start[cell], ce = cell_start[cell + 1];
-  if (cell == 0 && lane == 0) status[1] += 1;  // flags[F_NREBUILD]
+  int cs = cell_start[cell], ce = cell_start[cell + 1];
+  if (cell == 0 && part == 0 && lane == 0) status[1] += 1;  // flags[F_NREBUILD]
+  if (!LOOP && split > 1) {  // this block's atoms of the cell (multiples of 4: whole batches)
+    const int per = ((ce - cs + split - 1) / split + 3) & ~3;
+    cs = min(cs + part * per, ce);
+    ce = min(cs + per, ce);
+  }
   if (cs == ce) continue;
   __syncthreads();  // LDS tables of the previous cell are no longer read
   const int cz = cell % g.nc[2], cy = (cell / g.nc[2]) % g.nc[1], cx = cell / (g.nc[2] * g.nc[1]);
@@ -2366,16 +2375,22 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
   const R rl = (R)ctx->rlist;
   constexpr int kMaxBuildBlocks = 16384;
   const bool wskin = ctx->half_skin.p != nullptr;
+  // few cells: several blocks per cell (see build_list_kernel), so that ~2 000 waves are in flight
+  int split = 1;
+  if (const char *e = std::getenv("TMDHIP_BUILD_SPLIT")) split = std::max(1, std::min(std::atoi(e), 8));
+  else if (rp.ncell <= 1100) split = 2;  // measured (water boxes of 5 184 / 12 288 / 41 472 atoms = 343 / 729 / 2 197 cells, us per
+                                         // MD step at split 1, 2, 4): 29.7 27.7 (28-37) / 37.8 35.5 35.0 / 43.0 44.6 48.3
+  if (rp.ncell > kMaxBuildBlocks) split = 1;
   auto launch_build = [&](auto kernel, int blocks) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, n, rp.sorted.as<R4>(), rp.sorted_hs.as<R>(),
                        rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
                        (R)ctx->d.cutoff, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
                        rp.nneigh.as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes,
-                       debug_timeline_buffer(blocks));
+                       debug_timeline_buffer(blocks), split);
   };
   if (rp.ncell <= kMaxBuildBlocks) {
-    if (wskin) launch_build(build_list_kernel<R, false, true>, rp.ncell);
-    else launch_build(build_list_kernel<R, false, false>, rp.ncell);
+    if (wskin) launch_build(build_list_kernel<R, false, true>, rp.ncell * split);
+    else launch_build(build_list_kernel<R, false, false>, rp.ncell * split);
   } else {
     if (wskin) launch_build(build_list_kernel<R, true, true>, kMaxBuildBlocks);
     else launch_build(build_list_kernel<R, true, false>, kMaxBuildBlocks);
