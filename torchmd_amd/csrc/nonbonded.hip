@@ -604,9 +604,16 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   __shared__ R4 s_rec0[64];
   __shared__ int4 s_rec1[64];
   __shared__ int s_eb[64], s_more[64];
+  __shared__ unsigned s_bm[64];
   __shared__ __align__(16) int s_cnt[64];
   const int apw_shift = 6 - lg.lpa_shift;
   const unsigned kmask = (unsigned)lg.lpa - 1u;
+  // entry k of a row sits at byte ((k / (4 LPA)) << 10) + ((k % LPA) << 4) + (((k / LPA) % 4) << 2)  (list_slot); the
+  // masks live in VGPRs (an SGPR operand halves the VALU rate)
+  unsigned vmask_hi, vmask_lo;
+  asm("v_mov_b32 %0, %1" : "=v"(vmask_hi) : "s"(~((4u << lg.lpa_shift) - 1u)));
+  asm("v_mov_b32 %0, %1" : "=v"(vmask_lo) : "s"(kmask));
+  const unsigned sh_hi = 8u - (unsigned)lg.lpa_shift;  // (k / (4 LPA)) << 10 == (k & ~(4 LPA - 1)) << (10 - 2 - lpa_shift)
   for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
     const int iend = min(ib + 64, ce);
     const int ni = iend - ib;
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       ex.x = oi;
       ex.y = 0 < ne ? excl_idx[eb + 0] : -1;
       ex.z = 1 < ne ? excl_idx[eb + 1] : -1;
-      ex.w = (int)rowoff;
+      ex.w = (int)(rowoff * 4u);  // byte offset of the atom's list row
       s_rec1[lane] = ex;
       long_rows = ne > EXS - 1;
     } else {
@@ -644,9 +651,20 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       s_rec1[lane] = make_int4(-1, -1, -1, 0);
     }
     const bool any_long = __ballot(long_rows) != 0ull;
+    s_bm[lane] = 0u;
     __syncthreads();
     s_cnt[lane] = 0;  // neighbour count of atom ib + lane (lives in LDS: one broadcast read + one
                       // same-value write per iteration instead of cross-lane register traffic)
+    // Bitmap (2 048 bits, key = original index mod 2048) of everything some atom of this block excludes — itself and
+    // its first two excluded partners.  A candidate whose bit is clear is excluded by nobody here: the three index
+    // compares per (atom, chunk) are only made for batches that meet a flagged candidate (for water: the chunks of the
+    // own and the adjacent cells, ~15 %).
+    if (lane < ni) {
+      const int4 ex = s_rec1[lane];
+      atomicOr(&s_bm[((unsigned)ex.x & 2047u) >> 5], 1u << ((unsigned)ex.x & 31u));
+      if (ex.y >= 0) atomicOr(&s_bm[((unsigned)ex.y & 2047u) >> 5], 1u << ((unsigned)ex.y & 31u));
+      if (ex.z >= 0) atomicOr(&s_bm[((unsigned)ex.z & 2047u) >> 5], 1u << ((unsigned)ex.z & 31u));
+    }
     __syncthreads();
     int seg = 0;      // segment of this lane's candidate; q grows by 64 per chunk so it only moves forward
     // candidate stream, software-pipelined: the three global loads of chunk q0 + 64 are issued before
@@ -703,7 +721,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
         const unsigned k = (unsigned)base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
-          const unsigned rowoff = (unsigned)ex.w;
+          const unsigned rowoff = (unsigned)ex.w >> 2;
           const unsigned kk = k >> lg.lpa_shift;
           nlist[rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u)] = entry;
         }
@@ -734,26 +752,39 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       // exec.  Atoms with long exclusion rows (proteins) keep the branching path.
       // The last batch is padded with parked dummy atoms (staged above), so there is no scalar remainder loop.
       if (!any_long) {
+        // candidates that somebody in this block excludes (see s_bm); lanes past the end never hit anyway
+        const unsigned bmw = s_bm[(oj & 2047u) >> 5];
+        const unsigned long long special = __builtin_amdgcn_uicmp((bmw >> (oj & 31u)) & 1u, 0u, 33 /* ne */);
         for (; t < ni; t += 4, recoff += 64u) {
           const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
           unsigned long long m[4] = {in_range(p0), in_range(p1), in_range(p2), in_range(p3)};
-          if (!(m[0] | m[1] | m[2] | m[3])) continue;
+          const unsigned long long any = m[0] | m[1] | m[2] | m[3];
+          if (!any) continue;
           const int4 base4 = *reinterpret_cast<const int4 *>(&s_cnt[t]);
           const int base[4] = {base4.x, base4.y, base4.z, base4.w};
+          int4 ex[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            ex[u] = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff + 16u * u);
+          if (any & special) {  // rare: a flagged candidate is in range of one of the four
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              m[u] &= ~(__builtin_amdgcn_uicmp((unsigned)ex[u].x, oj, 32 /* eq */) | __builtin_amdgcn_uicmp((unsigned)ex[u].y, oj, 32) |
+                        __builtin_amdgcn_uicmp((unsigned)ex[u].z, oj, 32));
+          }
           int cnt[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff + 16u * u);
-            m[u] &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) | __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
-                      __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32));
             const unsigned k = (unsigned)base[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
-            const unsigned kk = k >> lg.lpa_shift;
-            const unsigned pos = (unsigned)ex.w + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u);
+            // byte offset of entry k in the row: iteration kk = k / LPA, lane part k % LPA (list_slot's layout)
+            unsigned posb = (unsigned)ex[u].w + ((k & vmask_hi) << sh_hi);
+            posb += (k & vmask_lo) << 4;
+            posb += __builtin_amdgcn_ubfe(k, (unsigned)lg.lpa_shift, 2u) << 2;
             // lanes that store: hit and below the row's capacity; everybody else gets the out-of-range offset -4
             const unsigned long long stm = m[u] & __builtin_amdgcn_uicmp(k, (unsigned)lg.maxn, 36 /* ult */);
             unsigned off;
-            asm("v_cndmask_b32_e64 %0, -4, %1, %2" : "=v"(off) : "v"(pos * 4u), "s"(stm));
+            asm("v_cndmask_b32_e64 %0, -4, %1, %2" : "=v"(off) : "v"(posb), "s"(stm));
             __builtin_amdgcn_raw_buffer_store_b32(entry, nrsrc, off, 0, 0);
             cnt[u] = base[u] + (int)__popcll(m[u]);
           }
