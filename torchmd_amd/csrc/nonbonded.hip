@@ -613,6 +613,8 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   unsigned vmask_hi, vmask_lo;
   asm("v_mov_b32 %0, %1" : "=v"(vmask_hi) : "s"(~((4u << lg.lpa_shift) - 1u)));
   asm("v_mov_b32 %0, %1" : "=v"(vmask_lo) : "s"(kmask));
+  unsigned vmaxn1;
+  asm("v_mov_b32 %0, %1" : "=v"(vmaxn1) : "s"((unsigned)lg.maxn - 1u));
   const unsigned sh_hi = 8u - (unsigned)lg.lpa_shift;  // (k / (4 LPA)) << 10 == (k & ~(4 LPA - 1)) << (10 - 2 - lpa_shift)
   for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
     const int iend = min(ib + 64, ce);
@@ -775,17 +777,19 @@ __global__ __launch_bounds__(64) void build_list_kernel(
           int cnt[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const unsigned k = (unsigned)base[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
-                                                                            __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
+            // slot of this lane's hit, clamped to the row's last one: a row that overflows is reported through F_MAXN
+            // and its list thrown away (the caller grows the capacity and rebuilds), so what lands there is never used
+            const unsigned k = min((unsigned)base[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u)),
+                                   vmaxn1);
             // byte offset of entry k in the row: iteration kk = k / LPA, lane part k % LPA (list_slot's layout)
             unsigned posb = (unsigned)ex[u].w + ((k & vmask_hi) << sh_hi);
             posb += (k & vmask_lo) << 4;
             posb += __builtin_amdgcn_ubfe(k, (unsigned)lg.lpa_shift, 2u) << 2;
-            // lanes that store: hit and below the row's capacity; everybody else gets the out-of-range offset -4
-            const unsigned long long stm = m[u] & __builtin_amdgcn_uicmp(k, (unsigned)lg.maxn, 36 /* ult */);
-            unsigned off;
-            asm("v_cndmask_b32_e64 %0, -4, %1, %2" : "=v"(off) : "v"(posb), "s"(stm));
-            __builtin_amdgcn_raw_buffer_store_b32(entry, nrsrc, off, 0, 0);
+            // only the lanes with a hit store: exec = the hit mask for the one instruction (every lane of the block is
+            // active here); a v_cndmask on an out-of-range offset would cost a half-rate VALU slot instead
+            asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_dword %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
+                         :: "v"(entry), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
             cnt[u] = base[u] + (int)__popcll(m[u]);
           }
           *reinterpret_cast<int4 *>(&s_cnt[t]) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);  // every lane writes the same values
