@@ -1163,6 +1163,13 @@ __global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fa
     constexpr bool ARITH_CUT = UNCHECKED && !ENERGY;
     constexpr int NU = (int)std::extent<std::remove_reference_t<decltype(tab)>>::value;
     static_assert(NU == 4 || NU == 2, "stage size");
+#if TMD_EXP & 65536  // DEBUG (wrong results, timing only): the memory side alone — one add per gathered record
+    if (UNCHECKED) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) fx += __uint_as_float(raw[u].x ^ raw[u].y ^ raw[u].z ^ raw[u].w ^ tab[u]);
+      return;
+    }
+#endif
     float dx[NU], dy[NU], dz[NU], r2[NU], rinv[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -1270,8 +1277,20 @@ __global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fa
   // 24..27 of an entry are zero; checked: padding words are garbage, the offset is masked)
   auto issue = [&](auto unchecked, const v4u &w, v4u (&raw)[UNROLL], unsigned (&tab)[UNROLL]) {
     const unsigned entry[UNROLL] = {w.x, w.y, w.z, w.w};
+#if TMD_EXP & 16384  // DEBUG (wrong results, timing only): no gathers at all, records made up from the entry
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      raw[u] = (v4u){(entry[u] & 0x7F0u) | 0x41000000u, (entry[u] & 0x3F0u) | 0x41100000u, (entry[u] & 0x5F0u) | 0x41200000u, 0x3ECCCCCDu};
+#elif TMD_EXP & 256  // DEBUG (wrong results, timing only): half the gathers, the other records made up from them
+#pragma unroll
+    for (int u = 0; u < UNROLL; u += 2) {
+      raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+      raw[u + 1] = raw[u] ^ (v4u){entry[u + 1] & 0x3000u, entry[u + 1] & 0x5000u, entry[u + 1] & 0x6000u, 0u};
+    }
+#else
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+#endif
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) tab[u] = trow | (decltype(unchecked)::value ? entry[u] >> 24 : (entry[u] >> 24) & 0xF8u);
   };
