@@ -1362,6 +1362,49 @@ __global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fa
       }
       // `word` = list word gfull for the tail; w1 (word gfull + 1) is requested again there
     }
+#elif TMD_EXP & 128
+    // EXPERIMENT (measured, not the default: 44.5 us against 42.6-43.8, 96 registers + 12 bytes of spills).
+    // Software pipeline over the unchecked groups: while group g is evaluated the gathers of g+1 are in flight in the
+    // other register set, and the list words of g+2 AND g+3 behind them.  A list word comes from the Infinity Cache /
+    // HBM: ~1 500 cycles even on a quiet chip (a loop that does nothing but wait for its next list word takes 32 us)
+    // — more than one group's arithmetic (~1 200 cycles), so with the word requested only one group ahead every
+    // iteration ended up waiting for it: 1 985 cycles per group and wave, whatever was done to the gathers or the
+    // arithmetic.  Two groups ahead it has two evaluations to arrive.
+    else if (gfull > 0) {
+      v4u ra[UNROLL], rb[UNROLL];
+      unsigned ta[UNROLL], tb[UNROLL];
+      issue(unchecked_t{}, word, ra, ta);  // G(0)
+      __builtin_amdgcn_sched_barrier(0);
+      v4u w1 = list_word(1), w2 = list_word(2);
+      __builtin_amdgcn_sched_barrier(0);
+      while (true) {  // entry: set a = G(g) in flight, w1 = W(g+1), w2 = W(g+2) in flight
+        if (g + 1 >= gfull) {
+          group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
+          g += 1;
+          break;
+        }
+        issue(unchecked_t{}, w1, rb, tb);  // G(g+1)
+        __builtin_amdgcn_sched_barrier(0);
+        w1 = list_word(g + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 >= gfull) {
+          group(fused_image{}, unchecked_t{}, tb, rb, (g + 1) * UNROLL);
+          g += 2;
+          { const v4u t = w1; w1 = w2; w2 = t; }  // (w2 = W(g) after the increment below is what the tail wants)
+          break;
+        }
+        issue(unchecked_t{}, w2, ra, ta);  // G(g+2)
+        __builtin_amdgcn_sched_barrier(0);
+        w2 = list_word(g + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, tb, rb, (g + 1) * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
+        g += 2;
+      }
+      word = w1;  // list word of group g (requested long ago); the tail requests g+1 again itself
+    }
 #else
     else if (gfull > 0) {
       v4u ra[UNROLL], rb[UNROLL];
