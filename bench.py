@@ -37,9 +37,11 @@ SIMDS, NOMINAL_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; one wave64 VALU instructio
 
 
 def timing_stride(steps):
-    """HIP events time every n-th launch of the pair kernel: n chosen so that any --steps >= 8 yields >= 8 timed
-    launches (20 steps: every 2nd; >= 128: every 16th)."""
-    return max(1, min(16, steps // 8))
+    """HIP events time every n-th launch of the pair kernel: >= 128 steps: every 16th launch over the whole region;
+    shorter runs: the first 8 launches of the region, consecutively (a launch with events attached costs the stream
+    ~7 us when its neighbours are timed too and ~10 us alone among untimed ones — tools/short_call.py — so eight in
+    a row are the cheapest way to >= 8 timed launches in a 20-step region)."""
+    return 16 if steps >= 128 else 1
 
 
 def pmc_traffic():
@@ -136,7 +138,7 @@ def run_c5(args, rank, world, local_rank, device, launched):
         integ = Integrator(s, f, TIMESTEP_FS, device, gamma=1.0, T=85.0)
         integ.step(max(args.warmup, 1))
         stride = timing_stride(args.steps)
-        f.enable_timing(s.pos, True, every=stride)
+        f.enable_timing(s.pos, True, every=stride, limit=8 if args.steps < 128 else 0)
         f.read_timing(s.pos, reset=True)
         st0 = f.stats(s.pos)
         torch.cuda.synchronize()
@@ -480,7 +482,8 @@ def main():
             "launches_timed": int(pair_launches),
             "timing": (f"HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of every {stride}th pair-kernel "
                        "launch of the timed region, on the launch stream" + (" (the first 8 of them)" if args.steps < 128 else ""))
-            if stride > 1 else "HIP start/stop events attached to the dispatch of every pair-kernel launch of the timed region",
+            if stride > 1 else "HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of the first 8 pair-kernel launches "
+            "of the timed region, on the launch stream",
             "step_frac_of_hbm_roofline": (step_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
             "alu": {"flops_per_launch": FLOP_PER_PAIR * pcut, "achieved_tflops": alu_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": alu_tflops / FP32_VECTOR_PEAK_TFLOPS},

@@ -1020,7 +1020,9 @@ using fused_image = std::integral_constant<bool, false>;
 // (v_fma with clamp + v_mul) where no energy is wanted; the four v_rsq of a group issued back to back; list words
 // through a raw buffer with a SCALAR running offset, requested behind the gathers issued in the same breath; and the
 // unchecked groups software-pipelined over two register sets (gathers of group g+1 in flight while g is evaluated).
-#if TMD_EXP & 4
+#if (TMD_EXP & 4) && (TMD_EXP & 32)
+#define TMD_FAST_WAVES 8
+#elif TMD_EXP & 4
 #define TMD_FAST_WAVES 6
 #elif TMD_EXP & 512
 #define TMD_FAST_WAVES 4
