@@ -645,3 +645,17 @@ def test_skin_weight_rules():
     par1 = GoldenParameters(load("water291"), torch.float32)
     par1.masses = torch.full_like(par1.masses, 12.0)
     assert Forces(par1, terms=["lj"], cutoff=7.3)._skin_weight_array() is None
+
+
+def test_bench_cpu_baseline_c5_sample_and_pmc_provenance():
+    """`bench.py`'s CPU-baseline leg of config C5 runs the oracle on a bounded sample and scales by the atom ratio
+    (stated in `sample`); the counter figures the bench line quotes come from a committed PMC file with its commit."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    r = bench.cpu_baseline_c5(1_000_000, nside_sample=8, budget_s=1.0)
+    assert r["kind"] == "port" and r["unit"] == "ns/day" and r["cores"] >= 1
+    assert 0 < r["value"] < 10 and "512-atom" in r["sample"] and "atom ratio" in r["sample"]
+    traffic, src, commit, valu = bench.pmc_traffic()
+    assert traffic and traffic > 5e7 and src.startswith("profiles/") and commit and valu and valu > 1e6
+    assert bench.timing_stride(20) == 1 and bench.timing_stride(2000) == 16

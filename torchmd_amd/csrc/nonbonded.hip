@@ -407,50 +407,133 @@ __global__ void fill_cells_kernel(int n, const int *__restrict__ cell_of, const 
 // cell-sorted copies the pair kernel reads: {x, y, z, q*sqrt(k)}, type, inverse permutation, and the
 // reference positions of the displacement test
 template <typename R>
-__global__ void place_sorted_kernel(int n, const int *__restrict__ cell_of, const int *__restrict__ cell_start,
-                                    const int *__restrict__ order_tmp, const R *__restrict__ pos,
-                                    const R *__restrict__ qs, const int *__restrict__ types,
-                                    int *__restrict__ order, int *__restrict__ inv,
-                                    typename Vec<R>::T4 *__restrict__ sorted, int *__restrict__ stype,
-                                    R *__restrict__ ref, const R *__restrict__ half_skin,
-                                    R *__restrict__ sorted_hs, const R *__restrict__ vel, R vs_floor, R vs_time,
-                                    R vs_cap, R *__restrict__ hs2_dyn, int *ext, const int *flag) {
-  if (*flag == 0) return;
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= n) return;
-  const int me = order_tmp[a];
-  const int cidx = cell_of[me];
-  const int s = cell_start[cidx], e = cell_start[cidx + 1];
+struct PlaceArgs {
+  const int *cell_of, *cell_start, *order_tmp;
+  const R *pos, *qs;
+  const int *types;
+  int *order, *inv;
+  typename Vec<R>::T4 *sorted;
+  int *stype;
+  R *ref;
+  const R *half_skin;
+  R *sorted_hs;
+  const R *vel;
+  R vs_floor, vs_time, vs_cap;
+  R *hs2_dyn;
+  int *ext;
+};
+
+// atom at position `a` of the unsorted cell order -> its final slot (rank by original index inside the cell) and every
+// per-slot copy the pair kernels read
+template <typename R>
+__device__ __forceinline__ void place_atom(const PlaceArgs<R> &P, int a) {
+  const int me = P.order_tmp[a];
+  const int cidx = P.cell_of[me];
+  const int s = P.cell_start[cidx], e = P.cell_start[cidx + 1];
   int rank = 0;
-  for (int k = s; k < e; ++k) rank += order_tmp[k] < me;
+  for (int k = s; k < e; ++k) rank += P.order_tmp[k] < me;
   const int dst = s + rank;
-  order[dst] = me;
-  inv[me] = dst;
+  P.order[dst] = me;
+  P.inv[me] = dst;
   typename Vec<R>::T4 v;
-  v.x = pos[3 * me + 0];
-  v.y = pos[3 * me + 1];
-  v.z = pos[3 * me + 2];
-  v.w = qs[me];
-  sorted[dst] = v;
-  extent_note<R>(ext, v.x, v.y, v.z);
-  stype[dst] = types[me];
-  if (half_skin) {
+  v.x = P.pos[3 * me + 0];
+  v.y = P.pos[3 * me + 1];
+  v.z = P.pos[3 * me + 2];
+  v.w = P.qs[me];
+  P.sorted[dst] = v;
+  extent_note<R>(P.ext, v.x, v.y, v.z);
+  P.stype[dst] = P.types[me];
+  if (P.half_skin) {
     // this list's half skin of the atom: its static share, or — inside an MD run, where the velocity is known —
     // a reduced floor plus the distance it covers in `vs_time` at its present speed, capped at vs_cap times the
     // largest static share (the cells are sized for that).  Any choice is safe: the displacement test uses the
     // same number (hs2_dyn); a good choice lets fast atoms go further before they force a rebuild while slow
     // ones keep short lists.
-    R h = half_skin[me];
-    if (vel) {
-      const R vx = vel[3 * me + 0], vy = vel[3 * me + 1], vz = vel[3 * me + 2];
-      h = min(vs_floor * h + vs_time * sqrt(vx * vx + vy * vy + vz * vz), vs_cap);
+    R h = P.half_skin[me];
+    if (P.vel) {
+      const R vx = P.vel[3 * me + 0], vy = P.vel[3 * me + 1], vz = P.vel[3 * me + 2];
+      h = min(P.vs_floor * h + P.vs_time * sqrt(vx * vx + vy * vy + vz * vz), P.vs_cap);
     }
-    sorted_hs[dst] = h;
-    if (hs2_dyn) hs2_dyn[me] = h * h;
+    P.sorted_hs[dst] = h;
+    if (P.hs2_dyn) P.hs2_dyn[me] = h * h;
   }
-  ref[3 * me + 0] = v.x;
-  ref[3 * me + 1] = v.y;
-  ref[3 * me + 2] = v.z;
+  P.ref[3 * me + 0] = v.x;
+  P.ref[3 * me + 1] = v.y;
+  P.ref[3 * me + 2] = v.z;
+}
+
+template <typename R>
+__global__ void place_sorted_kernel(int n, PlaceArgs<R> P, const int *flag) {
+  if (*flag == 0) return;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  place_atom<R>(P, a);
+}
+
+// Binning of a small system in ONE launch of one block: count (LDS atomics), scan, fill and place — the work of
+// bin_count / scan_cells / fill_cells / place_sorted.  On the ~10 of 11 steps without a rebuild the chain then costs
+// two early-exit launches instead of five (~1.7 us each).  A rebuild on one CU is slower than the four parallel
+// launches, which sets the size limit — measured, water boxes, us per MD step without / with: 5 184 atoms 27.2 / 23.8,
+// 12 288 atoms 34.6 / 36.1, 41 472 atoms 41.8 / 67.1.
+constexpr int kPrepSmallMaxCells = 4096;
+constexpr int kPrepSmallMaxAtoms = 8192;
+template <typename R>
+__global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__restrict__ pos, Grid g, int ncell,
+                                                          int *__restrict__ cell_of, int *__restrict__ slot,
+                                                          int *__restrict__ cell_start, int *__restrict__ order_tmp,
+                                                          PlaceArgs<R> P, const int *flag) {
+  if (*flag == 0) return;
+  __shared__ int s_count[kPrepSmallMaxCells];
+  __shared__ int s_start[kPrepSmallMaxCells + 1];
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int c = t; c < ncell; c += 1024) s_count[c] = 0;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) {
+    const int cx = cell_coord(pos[3 * i + 0], g, 0);
+    const int cy = cell_coord(pos[3 * i + 1], g, 1);
+    const int cz = cell_coord(pos[3 * i + 2], g, 2);
+    const int cidx = (cx * g.nc[1] + cy) * g.nc[2] + cz;
+    cell_of[i] = cidx;
+    slot[i] = atomicAdd(&s_count[cidx], 1);
+  }
+  __syncthreads();
+  // exclusive scan: thread t owns cells 4t .. 4t+3
+  int v[4], mine = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * t + k;
+    v[k] = c < ncell ? s_count[c] : 0;
+    mine += v[k];
+  }
+  int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int run = inc - mine;
+  for (int k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * t + k;
+    if (c < ncell) {
+      s_start[c] = run;
+      cell_start[c] = run;
+    }
+    run += v[k];
+  }
+  if (t == 0) {
+    s_start[ncell] = n;
+    cell_start[ncell] = n;
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) order_tmp[s_start[cell_of[i]] + slot[i]] = i;
+  __threadfence_block();
+  __syncthreads();  // order_tmp and cell_start are complete for the whole block
+  for (int a = t; a < n; a += 1024) place_atom<R>(P, a);
 }
 
 // list entry = type_j << 27 | j << 4 (j = cell-sorted slot, 23 bits): `entry & kEntryOffMask` is the byte offset
@@ -2459,18 +2542,39 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
   if (!prechecked)
     hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, make_check<R>(ctx, rp), c,
                        force, rp.inv.as<int>(), ctx->qs.as<R>(), rp.sorted.as<R4>());
-  hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, rp.cell_of.as<int>(),
-                     rp.slot.as<int>(), rp.count.as<int>(), flag);
-  hipLaunchKernelGGL(scan_cells_kernel, dim3(1), dim3(1024), 0, st, rp.ncell, rp.count.as<int>(),
-                     rp.cell_start.as<int>(), flag);
-  hipLaunchKernelGGL(fill_cells_kernel, dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(), rp.slot.as<int>(),
-                     rp.cell_start.as<int>(), rp.order_tmp.as<int>(), flag);
-  hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(),
-                     rp.cell_start.as<int>(), rp.order_tmp.as<int>(), pos, ctx->qs.as<R>(), ctx->types.as<int>(),
-                     rp.order.as<int>(), rp.inv.as<int>(), rp.sorted.as<R4>(), rp.stype.as<int>(), rp.ref.as<R>(),
-                     ctx->half_skin.as<R>(), rp.sorted_hs.as<R>(), ctx->vskin_time > 0 ? (const R *)rp.skin_vel : nullptr,
-                     (R)ctx->vskin_floor, (R)ctx->vskin_time, (R)ctx->vskin_cap_len, rp.hs2_dyn.as<R>(), rp.extent.as<int>(),
-                     flag);
+  PlaceArgs<R> P;
+  P.cell_of = rp.cell_of.as<int>();
+  P.cell_start = rp.cell_start.as<int>();
+  P.order_tmp = rp.order_tmp.as<int>();
+  P.pos = pos;
+  P.qs = ctx->qs.as<R>();
+  P.types = ctx->types.as<int>();
+  P.order = rp.order.as<int>();
+  P.inv = rp.inv.as<int>();
+  P.sorted = rp.sorted.as<R4>();
+  P.stype = rp.stype.as<int>();
+  P.ref = rp.ref.as<R>();
+  P.half_skin = ctx->half_skin.as<R>();
+  P.sorted_hs = rp.sorted_hs.as<R>();
+  P.vel = ctx->vskin_time > 0 ? (const R *)rp.skin_vel : nullptr;
+  P.vs_floor = (R)ctx->vskin_floor;
+  P.vs_time = (R)ctx->vskin_time;
+  P.vs_cap = (R)ctx->vskin_cap_len;
+  P.hs2_dyn = rp.hs2_dyn.as<R>();
+  P.ext = rp.extent.as<int>();
+  static const bool prep_small_on = !(std::getenv("TMDHIP_PREP_SMALL") && std::atoi(std::getenv("TMDHIP_PREP_SMALL")) == 0);
+  if (prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells) {
+    hipLaunchKernelGGL((prep_small_kernel<R>), dim3(1), dim3(1024), 0, st, n, pos, rp.grid, rp.ncell, rp.cell_of.as<int>(),
+                       rp.slot.as<int>(), rp.cell_start.as<int>(), rp.order_tmp.as<int>(), P, flag);
+  } else {
+    hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, rp.cell_of.as<int>(),
+                       rp.slot.as<int>(), rp.count.as<int>(), flag);
+    hipLaunchKernelGGL(scan_cells_kernel, dim3(1), dim3(1024), 0, st, rp.ncell, rp.count.as<int>(),
+                       rp.cell_start.as<int>(), flag);
+    hipLaunchKernelGGL(fill_cells_kernel, dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(), rp.slot.as<int>(),
+                       rp.cell_start.as<int>(), rp.order_tmp.as<int>(), flag);
+    hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, P, flag);
+  }
   const R rl = (R)ctx->rlist;
   constexpr int kMaxBuildBlocks = 16384;
   const bool wskin = ctx->half_skin.p != nullptr;
