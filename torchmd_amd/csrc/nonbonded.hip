@@ -2769,7 +2769,10 @@ void launch_md_step_bonded(const MdStepArgs<R> &a, const PairConsts<R> &c, const
 }
 
 // ---- chain skipping (ListCheck) --------------------------------------------------------------------
-constexpr int64_t kChainSkipMinEntries = 20'000'000;  // list slots below which the pair kernel is too short to hide the host
+constexpr int64_t kChainSkipMinEntries = 1'000'000;  // list slots from which the host paces itself behind the device.  (Round 2 gated this
+                                                    // at 2e7 "because shorter pair kernels cannot hide the host"; measured in round 3 with the gate
+                                                    // open, water boxes, us per MD step: 5 184 atoms 23.9 -> 22.6, 12 288 atoms 34.6 -> 28.6,
+                                                    // 24 000 atoms 42.4 -> 36.8, bit-identical trajectories.)
 constexpr double kChainSkipNear = 0.75;  // "near": beyond this fraction of the displacement limit (0.15 A of room at
                                          // skin 1.2: 2.2 x the largest per-step move seen in the water box, 9.5
                                          // standard deviations of a hydrogen's thermal velocity at 300 K)
