@@ -1171,6 +1171,8 @@ __global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fa
 #endif
 #if TMD_EXP & 8192  // DEBUG (wrong results, timing only): the list stream from a 4 KB window per wave (cache resident)
   auto list_word = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, (g & 3) * 1024, 0); };
+#elif TMD_EXP & 262144  // EXPERIMENT: list stream with the nt (slc) hint, so that it does not displace sorted_xyzq from L2
+  auto list_word = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * 1024, 2); };
 #else
   auto list_word = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * 1024, 0); };
 #endif
