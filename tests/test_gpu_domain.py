@@ -161,6 +161,34 @@ def test_native_exchange_and_step_loop_single_rank():
     assert mig0 == mig and torch.equal(P, P0) and torch.equal(V, V0) and torch.equal(F, F0)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_native_loop_over_rccl_ranks(world):
+    """`tmdhip_comm_exchange` and `tmdhip_dd_run` between REAL ranks, one GPU each (tests/_dd_ranks.py under
+    torch.distributed.run): the library's grouped RCCL send/recv equals torch's all_to_all_single, and 40 NVE steps
+    with migrations equal the single-domain integrator.  World sizes the box has no GPUs for are skipped (the
+    1-GPU pool runs world = 1: the brick exchanges its periodic images with itself over RCCL)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("TMDHIP_DD_NATIVE", None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(here, "_dd_ranks.py")],
+                         capture_output=True, text=True, timeout=550, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert f"DD-RANKS OK world={world}" in res.stdout, res.stdout[-1500:]
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 @pytest.mark.parametrize("langevin", [False, True])
 def test_dd_step_equals_the_separate_integrator_kernels(dt, langevin):
