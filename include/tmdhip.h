@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TMDHIP_ABI_VERSION 3
+#define TMDHIP_ABI_VERSION 4
 
 /* dtype */
 #define TMDHIP_F32 0
@@ -133,6 +133,7 @@ typedef struct tmdhip_stats {
   int32_t ncell[3];
   double skin;              /* Verlet skin in use (Angstrom)                                */
   int64_t chains_skipped;   /* MD steps whose rebuild chain the host left out (tmdhip_md_run)  */
+  int64_t steps_in_pair_launch; /* MD steps made by step blocks of the pair launch instead of an integrator launch (ABI 4) */
 } tmdhip_stats;
 
 int tmdhip_abi_version(void);

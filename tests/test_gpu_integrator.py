@@ -593,3 +593,66 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
     F2 = torch.zeros_like(s.pos)
     fresh.compute(s.pos, s.box, F2)
     assert (F2 - s.forces).abs().max().item() < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin"])
+def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
+    """Interior steps of tmdhip_md_run on the lean fp32 pair kernel are made by the pair launch itself ("step blocks"
+    behind the pair blocks wait for the pair waves of their atoms: FusedStep in nonbonded.hip) instead of by an
+    integrator launch.  Same device functions in the same order: positions, velocities, forces and energies equal
+    those of the separate kernels (TMDHIP_FUSED_STEP=0) bit for bit — with velocity-dependent skins, rebuilds inside
+    the window and chain skipping active (size gate opened).  Water = 8 lanes per atom (two pair blocks per step
+    block) + inline bonded records + reaction field; the LJ box = 4 lanes per atom, no bonded terms."""
+    from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    nrep = 2 if case == "water_two_replicas" else 1
+    if case.startswith("water"):
+        mol, pos, box = tip3p_box(14, seed=4)  # 8 232 atoms
+        terms = ["lj", "electrostatics", "bonds", "angles"]
+        par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+        kw = dict(cutoff=9.0, rfa=True)
+    else:
+        mol, pos, box = lj_box(22, seed=4)  # 10 648 atoms
+        terms = ["lj"]
+        par = Parameters(argon_forcefield(mol), mol, terms, precision=dt)
+        kw = dict(cutoff=9.0)
+    gamma = None if case == "water_nve" else 1.0
+    monkeypatch.setenv("TMDHIP_LPA", "8" if case.startswith("water") else "4")
+    torch.manual_seed(3)
+    vel0 = maxwell_boltzmann(par.masses, 300.0, nrep)
+
+    def run(fused):
+        monkeypatch.setenv("TMDHIP_FUSED_STEP", "1" if fused else "0")
+        s = System(mol.numAtoms, nrep, dt, dev)
+        s.set_positions(np.repeat(pos[:, :, None], nrep, axis=2))
+        s.set_box(box)
+        s.set_velocities(vel0)
+        f = Forces(par, terms=terms, algorithm="celllist", **kw)
+        f.compute(s.pos, s.box, s.forces)
+        torch.manual_seed(9)  # (the noise stream's seed is drawn at construction)
+        integ = Integrator(s, f, 1.0, dev, gamma=gamma, T=300.0 if gamma else None)
+        res = [integ.step(2), integ.step(41), integ.step(1), integ.step(37)]
+        return s.pos.cpu(), s.vel.cpu(), s.forces.cpu(), res, [f.stats(s.pos, r) for r in range(nrep)]
+
+    p1, v1, f1, r1, st1 = run(True)
+    p0, v0, f0, r0, st0 = run(False)
+    for st in st1:
+        assert st["algorithm"] == "celllist" and st["overflow"] == 0
+        # every interior step: (2 - 1) + (41 - 1) + 0 + (37 - 1)
+        assert st["steps_in_pair_launch"] == 77, st
+        assert st["n_rebuilds"] >= 2 and st["chains_skipped"] > 20, st
+    for st, su in zip(st1, st0):
+        assert su["steps_in_pair_launch"] == 0
+        assert st["n_rebuilds"] == su["n_rebuilds"] and st["chains_skipped"] == su["chains_skipped"]
+    assert torch.isfinite(p1).all()
+    assert torch.equal(p1, p0) and torch.equal(v1, v0) and torch.equal(f1, f0)
+    for a, b in zip(r1, r0):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y))

@@ -1123,24 +1123,81 @@ using fused_image = std::integral_constant<bool, false>;
 #else
 #define TMD_FAST_THREADS 256
 #endif
-template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH>
+// ---- the MD step inside the pair launch (FUSED variants; tmdhip_md_run, interior steps) -----------------------
+// Between two force evaluations an MD step is per-atom work on the force just computed: second half kick of step
+// `it` (+ thermostat), first half kick and drift of step it+1, the displacement test, the new record of the
+// cell-sorted copy.  As a kernel of its own that is 8.8 us at C3 (22 us at 10^6 atoms): a chain of memory round
+// trips (order -> bonded records -> partner positions -> update) with one wave per SIMD and nothing to hide it behind.
+// A FUSED launch appends "step blocks" to the grid.  Workgroups are dispatched in order, so a step block starts when
+// every pair block has been dispatched — in the slots the launch's last, partial round of pair blocks leaves idle —
+// and does everything that does not need the new forces (bonded records of its 64 atoms, noise, loads) while the
+// last pair blocks are still gathering; then it waits for the pair blocks of ITS atoms (one flag per pair wave,
+// stored with release behind the wave's forces), reads their forces and updates.  Behind the last pair block only
+// one load-update-store round remains, and the stored force array, its reload and one launch per step go away.
+// Pair blocks never wait for anything, so the flags cannot deadlock; the wait is bounded all the same.
+// Other blocks still read the positions of this launch, so the new ones go to the OTHER position buffer and the
+// OTHER cell-sorted copy (the host swaps the two after every fused launch).  Same device functions in the same
+// order as md_step_bonded_kernel / md_step_kernel: trajectories are bit-identical to the separate kernels.
+struct FusedStatic;  // what does not change from launch to launch (device memory; defined with the MD-step kernels)
+struct FusedStep {   // what does (kernel argument)
+  const float *pos_in;  // positions of this launch's forces, original atom order (partners of the bonded terms)
+  float *pos_out;       // drifted positions
+  float4 *sorted_out;   // their cell-sorted records
+  float4 *fsort;        // pair forces of this launch, cell-sorted order (pair blocks write, step blocks read)
+  unsigned *done;       // [pair blocks][waves]: launch number `gen` once the wave's forces are in fsort
+  unsigned gen;
+  int nstep_blocks;     // step blocks at the end of the grid (a multiple of 8, like the pair blocks)
+  uint64_t noise_step;
+  unsigned *near_host;  // chain skipping: report words of the NEXT step's displacement test (null: none)
+  unsigned seq;
+  int parity;           // of the next step
+};
+template <bool LANGEVIN, int APB>
+__device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict__ fst, const FusedStep &fs,
+                                                  const PairConsts<float> &c, int n, const float4 *__restrict__ sorted,
+                                                  const int *__restrict__ order, int j, int npair, float *s_lds);
+
+constexpr int kAuxDeviceScope = 16;  // sc1 of a gfx942/950 buffer access: coherent across the XCDs' L2s
+// lmode bits (list bookkeeping duties of the launch's first thread)
+constexpr int kLmViolation = 1;  // the chain of this step was left out and its displacement test ran in the previous
+                                 // launch's epilogue, which could not know that: a rebuild request found now = F_VIOLATION
+constexpr int kLmParity = 2;     // parity of this step
+
+template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
 __global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
-    double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext) {
+    double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext,
+    int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
-  // tells the host (host-mapped word) that everything enqueued before this launch has completed
-  if (publish && blockIdx.x == 0 && threadIdx.x == 0)
-    __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  static_assert(!(FUSED && ENERGY), "the fused step is for interior steps");
+  static_assert(!FUSED || TMD_FAST_THREADS == 256, "step blocks are four waves");
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // tells the host (host-mapped word) that everything enqueued before this launch has completed
+    if (publish) __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lflags) {
+      const int parity = (lmode & kLmParity) ? 1 : 0;
+      if ((lmode & kLmViolation) && lflags[F_REBUILD0 + parity] != 0) lflags[F_VIOLATION] = 1;
+      // the epilogue's test (parity ^ 1) is the next step's: this step's request is history (list_check_clear)
+      if (FUSED) lflags[F_REBUILD0 + parity] = 0;
+    }
+  }
   __shared__ __align__(16) float2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
   const int lane = threadIdx.x & 63;
+  // pair blocks of the launch (FUSED: step blocks follow them)
+  const unsigned npair = FUSED ? gridDim.x - (unsigned)fstep.nstep_blocks : gridDim.x;
+  if (FUSED && blockIdx.x >= npair) {
+    fused_step_blocks<FUSED == 2, TMD_FAST_THREADS / LPA>(fst, fstep, c, n, sorted, order, (int)(blockIdx.x - npair),
+                                                          (int)npair, reinterpret_cast<float *>(stab));
+    return;
+  }
   // XCD-aware block order: consecutive block ids go to the 8 XCDs round-robin, so block b works on
-  // chunk (b % 8) * gridDim.x/8 + b / 8 — every XCD (own L2) gets a contiguous eighth of the cell-sorted
-  // atoms and gathers neighbours from that region only.  gridDim.x is a multiple of 8; the surplus
+  // chunk (b % 8) * npair/8 + b / 8 — every XCD (own L2) gets a contiguous eighth of the cell-sorted
+  // atoms and gathers neighbours from that region only.  npair is a multiple of 8; the surplus
   // blocks of the last eighths have nothing to do.
-  const int blk = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  const int blk = (int)((blockIdx.x & 7u) * (npair >> 3) + (blockIdx.x >> 3));
   if (blk * (int)(blockDim.x >> 6) * APW >= n) return;  // (block-uniform: nobody is left waiting at the barrier below)
   const int wave = __builtin_amdgcn_readfirstlane(blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
 #if TMD_EXP & 512  // DEBUG (wrong results, timing only): i-pairs — a lane group evaluates the list of atom 2p for atoms 2p, 2p+1
@@ -1552,6 +1609,21 @@ __global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fa
     }
   }
 #endif
+  if constexpr (FUSED != 0) {
+    // Forces to the cell-sorted array the step blocks read, then this wave's flag.  Both are written through to
+    // device scope (sc1) and the flag is issued once the force stores have been acknowledged (vmcnt 0) — an
+    // agent-scope release would do the same with buffer_wbl2, a write-back of the whole L2 per wave: 365 us per launch.
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fstep.fsort, 0, n * 16, 0x00020000);
+    if (active && sub == 0)
+      __builtin_amdgcn_raw_buffer_store_b128((v4u){__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(sz), 0u}, frsrc,
+                                             a * 16, 0, kAuxDeviceScope);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (compiler ordering; no cache maintenance)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_store(fstep.done + (size_t)blk * (TMD_FAST_THREADS / 64) + (threadIdx.x >> 6), fstep.gen, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   if (active && sub == 0 && forces) {
     if (overwrite) {
       forces[3 * oi + 0] = sx;
@@ -1836,7 +1908,8 @@ __device__ __forceinline__ AtomIn<R> md_load_atom(const MdStepArgs<R> &s, int i,
 // by the mass exactly like the separate bonded kernel's `forces[i] += fb`
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
 __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairConsts<R> &c, int i, size_t off,
-                                             uint64_t row0, const AtomIn<R> &x, const R (&fb)[3], bool add_fb) {
+                                             uint64_t row0, const AtomIn<R> &x, const R (&fb)[3], bool add_fb,
+                                             const R *noise = nullptr) {  // noise: normal3 of this atom, drawn earlier
 #pragma clang fp contract(off)
   R *pos_out = s.pos_out + off, *vel = s.vel + off;
   const R m = x.m;
@@ -1857,7 +1930,11 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
     if (LANGEVIN) {
       const R vc = x.vc;
       R g[3];
-      normal3<R>(s.seed, s.noise_step, row0 + (uint64_t)i, g[0], g[1], g[2]);
+      if (noise) {
+        g[0] = noise[0], g[1] = noise[1], g[2] = noise[2];
+      } else {
+        normal3<R>(s.seed, s.noise_step, row0 + (uint64_t)i, g[0], g[1], g[2]);
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) v[k] += -s.gamma * v[k] * s.dt + g[k] * vc;
     }
@@ -1887,6 +1964,103 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) vel[3 * i + k] = v[k];
+}
+
+// ---- the step in the lean fp32 pair kernel's epilogue (see FusedStep above the kernel) -------------------------
+struct FusedStatic {
+  MdStepArgs<float> s;  // per-launch fields (pos_in/out, sorted, noise_step, chk.near_host/seq/parity) come from FusedStep
+  BondedArgs<float> A;
+  int has_bonded;  // light topology: the atoms' bonded records are evaluated here (md_step_bonded_kernel's job)
+};
+
+// Step block j of a FUSED pair launch (four waves, 64 atoms): the atoms of the 64 / APB pair blocks that run on the
+// same XCD (block ids congruent mod 8) and are neighbours in the cell-sorted order.  Like md_step_bonded_kernel, wave w
+// evaluates bonded record slots w, w + 4, ... of all 64 atoms (lane = atom), the partial forces meet in LDS as
+// (p0 + p1) + (p2 + p3), and the first wave updates — after it has waited for the pair waves of its atoms.
+template <bool LANGEVIN, int APB>
+__device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict__ fst, const FusedStep &fs,
+                                                  const PairConsts<float> &c, int n, const float4 *__restrict__ sorted,
+                                                  const int *__restrict__ order, int j, int npair, float *s_lds) {
+  constexpr int K = 64 / APB;            // pair blocks per step block
+  constexpr int WPB = TMD_FAST_THREADS / 64;  // waves of a pair block
+  float(*s_part)[3][64] = reinterpret_cast<float(*)[3][64]>(s_lds);  // [kQuad][3][64], the pair role's LJ table space
+  const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int xcd = j & 7, q = j >> 3, g8 = npair >> 3;
+  const int kc = K * q + lane / APB;  // this lane's pair block within the XCD's eighth
+  const int a = (xcd * g8 + kc) * APB + lane % APB;
+  const bool exists = kc < g8 && a < n;
+  const int o = exists ? order[a] : 0;
+  MdStepArgs<float> s = fst->s;
+  s.pos_in = fs.pos_in;
+  s.pos_out = fs.pos_out;
+  s.sorted = fs.sorted_out;
+  s.noise_step = fs.noise_step;
+  s.f_zero = nullptr;
+  s.chk.near_host = fs.near_host;
+  s.chk.seq = fs.seq;
+  s.chk.parity = fs.parity;
+  s.chk.skipped = 0;  // (unknown here: the next launch's first thread looks, kLmViolation)
+  const bool integrates = w == 0 && exists;
+  AtomIn<float> x{};
+  if (integrates) {  // every load of the update but the force, in flight during the bonded part
+    x.m = s.mass[o];
+    x.vc = LANGEVIN ? s.vcoeff[o] : 0.f;
+    const float4 p = sorted[a];  // x, y, z, scaled charge: exactly what the position buffer holds
+    x.p[0] = p.x, x.p[1] = p.y, x.p[2] = p.z;
+    x.q = p.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      x.v[k] = s.vel[3 * o + k];
+      x.r[k] = s.chk.ref[3 * o + k];
+    }
+    x.h2 = list_check_limit(s.chk, o);
+    x.slot = a;
+  }
+  const bool bonded = fst->has_bonded != 0;  // (launch-uniform)
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  if (bonded && exists) {
+    const BondedArgs<float> A = fst->A;
+    double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
+    const AtomRec<float> *rec = A.arec + (size_t)o * A.arec_stride;
+    for (int k = w; k < A.arec_stride; k += kQuad) {
+      const AtomRec<float> r = rec[k];
+      if (r.ent == kNoRec) break;  // records are packed from the front
+      eval_rec<float>(A, s.pos_in, o, r, fx, fy, fz, e);
+    }
+  }
+  s_part[w][0][lane] = fx;
+  s_part[w][1][lane] = fy;
+  s_part[w][2][lane] = fz;
+  float g[3] = {0.f, 0.f, 0.f};
+  if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
+  __syncthreads();
+  if (w != 0) return;
+  float fb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
+  // wait for the pair waves of these atoms: lane l watches wave l % WPB of pair block K q + l / WPB.  (They were
+  // dispatched before this block and wait for nothing; the bound only keeps a broken assumption from hanging the GPU.)
+  if (lane < K * WPB) {
+    const int kb = K * q + lane / WPB;
+    const int blk = xcd * g8 + kb;
+    if (kb < g8 && blk * APB < n) {
+      const unsigned *flag = fs.done + (size_t)blk * WPB + lane % WPB;
+      unsigned spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fs.gen) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 22)) {
+          s.chk.flags[F_VIOLATION] = 1;  // the caller rewinds and repeats the batch
+          break;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (ordering only; the load below goes to device scope itself)
+  if (!integrates) return;
+  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fs.fsort, 0, n * 16, 0x00020000);
+  const v4u f = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope);
+  x.f[0] = __uint_as_float(f.x), x.f[1] = __uint_as_float(f.y), x.f[2] = __uint_as_float(f.z);
+  md_step_atom<float, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, bonded, LANGEVIN ? g : nullptr);
 }
 
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
@@ -2067,13 +2241,21 @@ struct Replica {
   unsigned *pub_ptr = nullptr;
   unsigned pub_val = 0;
   int64_t chains_skipped = 0;
+  int64_t steps_in_pair_launch = 0;
   DevBuf pos_alt;  // second position buffer of tmdhip_md_run's double-buffered integrator kernel
+  // the MD step in the pair kernel's epilogue (FusedStep): the second cell-sorted copy (`sorted` is always the current
+  // one: the two are swapped after every fused launch) and the static arguments, on the device and as last uploaded
+  DevBuf sorted_alt, fused_dev;
+  FusedStatic fused_host;
+  bool fused_host_valid = false;
+  DevBuf fsort, done;     // pair forces in cell-sorted order and the pair waves' flags of a fused launch
+  unsigned fused_gen = 0;  // number of the last fused launch (what its flags hold)
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf extent;  // int[6]: keys of the coordinate extent of sorted_xyzq (extent_note)
   DevBuf paircount;  // unsigned long long
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
-                      &nlist, &nneigh, &flags, &extent, &paircount, &pos_alt})
+                      &nlist, &nneigh, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &done})
       b->release();
   }
 };
@@ -2365,9 +2547,17 @@ inline void launch_with_events(K kernel, dim3 grid, dim3 block, unsigned shmem, 
   else hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
 }
 
+// a FUSED launch of the lean fp32 pair kernel (see FusedStep): device copy of the static part, this launch's part
+struct FusedLaunch {
+  const FusedStatic *fst;
+  FusedStep step;
+  bool langevin;
+};
+
 template <typename R, bool ENERGY>
 int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, int overwrite, double *energies,
-                     unsigned long long *paircount, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+                     unsigned long long *paircount, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                     int lmode = 0, const FusedLaunch *fl = nullptr) {
   using R4 = typename Vec<R>::T4;
   using R2 = typename Vec<R>::T2;
   const int n = ctx->d.natoms;
@@ -2380,34 +2570,74 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
   const bool fast = only_lj_el;  // (switching, if any, acts on the LJ term and is a kernel variant)
   if constexpr (std::is_same<R, float>::value) {
     // lean fp32 kernel: the entry's type field holds 32 LJ classes (n > 2^20: every iteration in its checked loop)
-    if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= kEntryTypes) {
+    if (fast && !paircount && (f || ENERGY || fl) && ctx->d.ntypes <= kEntryTypes) {
       const unsigned shfast = 0;
       const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
-#define TMD_LAUNCH_FAST_T(L, A, B)       \
-  if (c.switch_on && A) {               \
-    TMD_LAUNCH_FAST_S(L, A, B, true);   \
-  } else {                              \
-    TMD_LAUNCH_FAST_S(L, A, B, false);  \
+#define TMD_LAUNCH_FAST_T(L, A, B, F)       \
+  if (c.switch_on && A) {                  \
+    TMD_LAUNCH_FAST_S(L, A, B, true, F);   \
+  } else {                                 \
+    TMD_LAUNCH_FAST_S(L, A, B, false, F);  \
   }
-#define TMD_LAUNCH_FAST_S(L, A, B, S)                                                                               \
-  launch_with_events(list_pair_fast_f32_kernel<L, A, B, ENERGY, S>, dim3(((waves + TMD_FAST_THREADS / 64 - 1) / (TMD_FAST_THREADS / 64) + 7) / 8 * 8), dim3(TMD_FAST_THREADS), shfast, st, e0, e1, n, \
+#define TMD_LAUNCH_FAST_S(L, A, B, S, F)                                                                            \
+  launch_with_events(list_pair_fast_f32_kernel<L, A, B, ENERGY, S, F>, dim3(npair8 + (F ? fstep.nstep_blocks : 0)), dim3(TMD_FAST_THREADS), shfast, st, e0, e1, n, \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<R2>(), \
                      rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,                   \
-                     ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>())
-#define TMD_LAUNCH_FAST(L)                  \
+                     ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>(), rp.flags.as<int>(), \
+                     lmode, F ? fl->fst : nullptr, fstep)
+#define TMD_LAUNCH_FAST(L, F)               \
   if (lj && el) {                           \
-    TMD_LAUNCH_FAST_T(L, true, true);       \
+    TMD_LAUNCH_FAST_T(L, true, true, F);    \
   } else if (lj) {                          \
-    TMD_LAUNCH_FAST_T(L, true, false);      \
+    TMD_LAUNCH_FAST_T(L, true, false, F);   \
   } else {                                  \
-    TMD_LAUNCH_FAST_T(L, false, true);      \
+    TMD_LAUNCH_FAST_T(L, false, true, F);   \
   }
-      switch (rp.lg.lpa) {  // (pick_lpa never returns less than 4)
-        case 4: TMD_LAUNCH_FAST(4); break;
-        case 8: TMD_LAUNCH_FAST(8); break;
-        case 16: TMD_LAUNCH_FAST(16); break;
-        case 32: TMD_LAUNCH_FAST(32); break;
-        default: TMD_LAUNCH_FAST(64); break;
+      constexpr int wpb = TMD_FAST_THREADS / 64;
+      const int npair8 = ((waves + wpb - 1) / wpb + 7) / 8 * 8;
+      FusedStep fstep{};
+      if (fl) {
+        // step blocks behind the pair blocks (interior steps of tmdhip_md_run; fused_step_possible() has been asked):
+        // one per 64 / (atoms of a pair block) pair blocks of an XCD's eighth
+        fstep = fl->step;
+        const int k = rp.lg.lpa * 64 / TMD_FAST_THREADS, g8 = npair8 / 8;
+        fstep.nstep_blocks = 8 * ((g8 + k - 1) / k);
+        const size_t flag_bytes = sizeof(unsigned) * (size_t)npair8 * wpb;
+        if (rp.done.bytes < flag_bytes) {
+          TMD_TRY(rp.done.ensure(flag_bytes));
+          TMD_HIP(hipMemsetAsync(rp.done.p, 0, rp.done.bytes, st));
+          rp.fused_gen = 0;
+        }
+        TMD_TRY(rp.fsort.ensure(sizeof(R4) * (size_t)n));
+        if (++rp.fused_gen == 0) rp.fused_gen = 1;  // (0 = never written)
+        fstep.done = rp.done.as<unsigned>();
+        fstep.gen = rp.fused_gen;
+        fstep.fsort = rp.fsort.as<float4>();
+        if constexpr (!ENERGY) {
+#define TMD_LAUNCH_FUSED(L)    \
+  if (fl->langevin) {          \
+    TMD_LAUNCH_FAST(L, 2);     \
+  } else {                     \
+    TMD_LAUNCH_FAST(L, 1);     \
+  }
+          switch (rp.lg.lpa) {
+            case 4: TMD_LAUNCH_FUSED(4); break;
+            case 8: TMD_LAUNCH_FUSED(8); break;
+            case 16: TMD_LAUNCH_FUSED(16); break;
+            default: return fail("fused MD step: unsupported lanes-per-atom");
+          }
+#undef TMD_LAUNCH_FUSED
+        } else {
+          return fail("fused MD step with energies");
+        }
+      } else {
+        switch (rp.lg.lpa) {  // (pick_lpa never returns less than 4)
+          case 4: TMD_LAUNCH_FAST(4, 0); break;
+          case 8: TMD_LAUNCH_FAST(8, 0); break;
+          case 16: TMD_LAUNCH_FAST(16, 0); break;
+          case 32: TMD_LAUNCH_FAST(32, 0); break;
+          default: TMD_LAUNCH_FAST(64, 0); break;
+        }
       }
 #undef TMD_LAUNCH_FAST
 #undef TMD_LAUNCH_FAST_T
@@ -2417,6 +2647,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
       return 0;
     }
   }
+  if (fl) return fail("fused MD step: the context does not run the lean fp32 pair kernel");
   if constexpr (std::is_same<R, double>::value) {
     // lean fp64 kernel (same conditions as the fp32 one)
     if (fast && !paircount && (f || ENERGY) && ctx->d.ntypes <= kEntryTypes) {
@@ -2496,6 +2727,7 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.order.ensure(sizeof(int) * n));
   TMD_TRY(rp.inv.ensure(sizeof(int) * n));
   TMD_TRY(rp.sorted.ensure(sizeof(R4) * n));
+  TMD_TRY(rp.sorted_alt.ensure(sizeof(R4) * n));
   TMD_TRY(rp.stype.ensure(sizeof(int) * n));
   if (ctx->half_skin.p) {
     TMD_TRY(rp.sorted_hs.ensure(ctx->real_size * (size_t)n));
@@ -2606,11 +2838,13 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
 
 constexpr int kPrechecked = 1 << 16;  // internal compute flag: displacement test already enqueued
 constexpr int kSkipChain = 1 << 18;   // internal compute flag: the host leaves the rebuild chain out for this step
+constexpr int kViolationCheck = 1 << 19;  // internal compute flag: ... and the step's displacement test (epilogue of the
+                                          // previous pair launch) did not know that: the pair launch looks itself
 constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
 
 template <typename R>
 int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces,
-                 double *energies, int flags, hipStream_t st) {
+                 double *energies, int flags, hipStream_t st, const FusedLaunch *fused = nullptr) {
   const int n = ctx->d.natoms;
   const R *pos = (const R *)pos_v;
   const PairConsts<R> c = make_consts<R>(ctx, box);
@@ -2715,10 +2949,17 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     ctx->events_used++;
   }
   const int overwrite = (flags & TMDHIP_OVERWRITE_FORCES) ? 1 : 0;
+  // list duties of the pair launch's first thread: rp.step counts the NEXT step by now
+  const int lmode = ((flags & kViolationCheck) ? kLmViolation : 0) | (((rp.step - 1) & 1) ? kLmParity : 0);
+  FusedLaunch fl{};
+  if (fused) {
+    fl = *fused;
+    fl.step.parity = (int)(rp.step & 1);
+  }
   if (flags & TMDHIP_WANT_ENERGY)
-    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1)));
+    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1, lmode)));
   else
-    TMD_TRY((launch_list_pair<R, false>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1)));
+    TMD_TRY((launch_list_pair<R, false>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1, lmode, fused ? &fl : nullptr)));
   if (pc) hipLaunchKernelGGL(halve_count_kernel, dim3(1), dim3(1), 0, st, pc);
   return 0;
 }
@@ -2790,6 +3031,23 @@ bool wait_published(volatile unsigned *hp, unsigned target) {
   }
 }
 
+// the static arguments of the fused step travel as a kernel argument (stream-ordered, no pinned staging, no host wait)
+__global__ void fused_upload_kernel(FusedStatic v, FusedStatic *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+
+// can the pair launch of this replica integrate the next step itself?  (lean fp32 kernel, 4 / 8 / 16 lanes per atom:
+// one wave holds the atoms of a block)
+template <typename R>
+bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairConsts<R> &c) {
+  if (!std::is_same<R, float>::value) return false;
+  const char *e = std::getenv("TMDHIP_FUSED_STEP");  // (read per call: tests switch it within a process)
+  if (e && std::atoi(e) == 0) return false;
+  const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
+  return only_lj_el && ctx->d.ntypes <= kEntryTypes && (rp.lg.lpa == 4 || rp.lg.lpa == 8 || rp.lg.lpa == 16) &&
+         TMD_FAST_THREADS / rp.lg.lpa <= 64;
+}
+
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   using R4 = typename Vec<R>::T4;
@@ -2820,6 +3078,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   // last evaluation is still owed to `forces`
   std::vector<R *> cur(nrep);
   std::vector<char> owed(nrep, 0);
+  std::vector<char> stepped(nrep, 0);  // the previous pair launch of the replica has made this iteration's step (FusedStep)
   for (int r = 0; r < nrep; ++r) cur[r] = (R *)d->pos_dev + r * stride;
   // the same for the replica-batched all-pairs mode (all replicas move together)
   R *const home_all = (R *)d->pos_dev;
@@ -2957,7 +3216,13 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       a.inv = rp.inv.as<int>();
       a.pos_in = a.pos_out = cur[r];
       BondedArgs<R> A;
-      if (owed[r]) {
+      std::memset(&A, 0, sizeof(A));
+      const bool was_stepped = stepped[r] != 0;
+      stepped[r] = 0;
+      if (was_stepped) {
+        // kicks, drift, displacement test and cell-sorted records of this iteration: done by the previous pair
+        // launch's epilogue (cur[r] and rp.sorted already point at its output)
+      } else if (owed[r]) {
         // second && first always holds here: the bonded force of step it-1 is evaluated from the
         // undrifted positions in cur[r], the drifted ones go to the other buffer
         if (tmd::bonded_inline_args(ctx, box, A) != 1) return fail("tmdhip_md_run: inline bonded state lost");
@@ -2988,10 +3253,69 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       if (ctx->d.terms != 0) {
         rp.n_compute++;
         if (list) {
+          // interior step on the lean fp32 kernel: the pair launch makes the next step itself (FusedStep)
+          FusedLaunch fl{};
+          bool fuse = false;
+          if constexpr (std::is_same<R, float>::value) {
+            const int bm = (check && it + 1 < d->niter && !en && fused_step_possible<R>(ctx, rp, c))
+                               ? tmd::bonded_inline_args(ctx, box, A) : 2;
+            if (bm != 2) {
+              FusedStatic now;
+              std::memset(&now, 0, sizeof(now));
+              now.s.n = n;
+              now.s.vel = a.vel;
+              now.s.mass = a.mass;
+              now.s.vcoeff = a.vcoeff;
+              now.s.dt = a.dt;
+              now.s.half_dt = a.half_dt;
+              now.s.gamma = a.gamma;
+              now.s.seed = a.seed;
+              now.s.row0 = a.row0;
+              now.s.qs = a.qs;
+              now.s.inv = a.inv;
+              now.s.chk.ref = a.chk.ref;
+              now.s.chk.hard2 = a.chk.hard2;
+              now.s.chk.hs2 = a.chk.hs2;
+              now.s.chk.flags = a.chk.flags;
+              now.s.chk.near_frac2 = (R)(chain_near * chain_near);
+              now.s.chk.ext = a.chk.ext;
+              if (bm == 1) std::memcpy(&now.A, &A, sizeof(A));
+              now.has_bonded = bm == 1;
+              TMD_TRY(rp.fused_dev.ensure(sizeof(FusedStatic)));
+              TMD_TRY(rp.pos_alt.ensure(sizeof(R) * stride));
+              if (!rp.fused_host_valid || std::memcmp(&rp.fused_host, &now, sizeof(now)) != 0) {
+                hipLaunchKernelGGL(fused_upload_kernel, dim3(1), dim3(64), 0, st, now, rp.fused_dev.as<FusedStatic>());
+                std::memcpy(&rp.fused_host, &now, sizeof(now));
+                rp.fused_host_valid = true;
+              }
+              fl.fst = rp.fused_dev.as<FusedStatic>();
+              fl.langevin = langevin;
+              fl.step.pos_in = pos;
+              fl.step.pos_out = pos == home ? rp.pos_alt.as<R>() : home;
+              fl.step.sorted_out = rp.sorted_alt.as<R4>();
+              fl.step.noise_step = d->step0 + (uint64_t)it;
+              if (pace) {  // the next iteration's sequence number (see the pacing above)
+                unsigned nseq = rp.seq + 1;
+                if (nseq == 0) nseq = 1;
+                fl.step.seq = nseq;
+                fl.step.near_host = rp.hostpub + 1 + (nseq & 1u);
+              }
+              fuse = true;
+            }
+          }
           const int rc = compute_list<R>(ctx, rp, pos, box, f, en,
                                          flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0) |
-                                             (skip_chain ? kSkipChain : 0), st);
+                                             (skip_chain ? kSkipChain : 0) |
+                                             (skip_chain && was_stepped ? kViolationCheck : 0), st,
+                                         fuse ? &fl : nullptr);
           rp.pub_ptr = nullptr;
+          if (fuse && rc == 0) {
+            if constexpr (std::is_same<R, float>::value) cur[r] = fl.step.pos_out;
+            std::swap(rp.sorted, rp.sorted_alt);
+            stepped[r] = 1;
+            rp.steps_in_pair_launch++;
+            continue;  // forces of this step never reach `forces`: the last step of the call is never fused
+          }
           if (rc == kFallbackAllPairs) {
             ctx->algorithm = TMDHIP_ALGO_ALLPAIRS;
             list = false;
@@ -3300,6 +3624,7 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   out->n_rebuilds = h[F_NREBUILD];
   out->skin = ctx->skin;
   out->chains_skipped = rp.chains_skipped;
+  out->steps_in_pair_launch = rp.steps_in_pair_launch;
   out->pairs_in_cutoff = (int64_t)pc;
   out->algorithm = ctx->algorithm;
   out->max_neighbours = rp.lg.maxn;

@@ -702,6 +702,7 @@ class Forces:
             "ncell": tuple(st.ncell),
             "skin": st.skin,
             "chains_skipped": int(st.chains_skipped),
+            "steps_in_pair_launch": int(st.steps_in_pair_launch),
         }
 
     def enable_timing(self, pos, on=True, every=1, limit=0):
