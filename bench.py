@@ -30,7 +30,7 @@ TIMESTEP_FS = 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
+PMC_TRAFFIC_FILES = ("r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 FLOP_PER_PAIR = 50.0             # ~50 FLOP + 1 rsqrt per in-cutoff pair
 SIMDS, NOMINAL_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues over 2 cycles per SIMD
@@ -412,12 +412,17 @@ def main():
     value = ns_per_day(args.steps, elapsed) * world
     rebuilds = st1["n_rebuilds"] - st0["n_rebuilds"]
 
-    # roofline of the dominant kernel (list pair kernel): algorithmic bytes per launch =
-    # 4 B per unique in-cutoff pair (one int32 neighbour index) + 28 B per atom (16 B xyzq read, 12 B force write)
-    alg_bytes = 4.0 * pcut + 28.0 * natoms
+    # roofline of the dominant kernel.  Algorithmic bytes of the pair part per launch = 4 B per unique in-cutoff pair
+    # (one int32 neighbour index) + 28 B per atom (16 B xyzq read, 12 B force write); since round 3 the timed
+    # launches of an MD run also make the step (step blocks behind the pair blocks: kicks, drift, displacement test,
+    # inline bonded terms), i.e. SURVEY.md 8(d)'s whole-step figure 4 B per pair + 132 B per atom.
+    fused_steps = st1["steps_in_pair_launch"] - st0["steps_in_pair_launch"]
+    fused = fused_steps >= args.steps - 2
+    pair_bytes = 4.0 * pcut + 28.0 * natoms
+    step_bytes = 4.0 * pcut + 132.0 * natoms  # whole step incl. integrator (SURVEY.md §8(d))
+    alg_bytes = step_bytes if fused else pair_bytes
     pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
     achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
-    step_bytes = 4.0 * pcut + 132.0 * natoms  # whole step incl. integrator (SURVEY.md §8(d))
     traffic, traffic_src, traffic_commit, valu_instr = pmc_traffic() if (args.nside == 32) else (None, None, None, None)
     # the other two ceilings of SURVEY 8(d): fp32 vector ALU (50 FLOP per unique in-cutoff pair) and VALU issue
     # (wave-instructions of the PMC pass x 2 cycles per SIMD at the nominal clock)
@@ -467,7 +472,8 @@ def main():
             "ncell": list(st2["ncell"]),
         },
         "roofline": {
-            "kernel": "list_pair_fast_f32_kernel<8> (lean scalar fp32, LJ + reaction field)",
+            "kernel": "list_pair_fast_f32_kernel<8> (lean scalar fp32, LJ + reaction field)"
+            + (" with the MD step in the same launch (step blocks: integrator + inline bonded terms)" if fused else ""),
             "bound": "hbm",  # the ceiling `achieved / peak / frac` are quoted against (SURVEY 8(d)'s algorithmic bytes) ...
             "limited_by": "VALU issue + gather (texture-addresser) rate, not HBM: see `alu`, `valu_issue` and DESIGN.md 6c",
             "achieved": achieved,
@@ -478,6 +484,10 @@ def main():
             "traffic_source": traffic_src,
             "traffic_commit": traffic_commit,
             "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes": ("whole step, 4 B x pairs + 132 B x atoms (SURVEY 8(d)): the launch computes the pair forces AND "
+                                  "makes the MD step" if fused else "pair part, 4 B x pairs + 28 B x atoms"),
+            "frac_pair_bytes_only": (pair_bytes / pair_avg_s / 1e9 / HBM_PEAK_GBS) if pair_avg_s > 0 else 0.0,
+            "steps_made_by_the_pair_launch": int(fused_steps),
             "avg_kernel_us": pair_avg_s * 1e6,
             "launches_timed": int(pair_launches),
             "timing": (f"HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of every {stride}th pair-kernel "

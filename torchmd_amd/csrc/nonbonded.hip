@@ -1131,10 +1131,10 @@ using fused_image = std::integral_constant<bool, false>;
 // A FUSED launch appends "step blocks" to the grid.  Workgroups are dispatched in order, so a step block starts when
 // every pair block has been dispatched — in the slots the launch's last, partial round of pair blocks leaves idle —
 // and does everything that does not need the new forces (bonded records of its 64 atoms, noise, loads) while the
-// last pair blocks are still gathering; then it waits for the pair blocks of ITS atoms (one flag per pair wave,
-// stored with release behind the wave's forces), reads their forces and updates.  Behind the last pair block only
-// one load-update-store round remains, and the stored force array, its reload and one launch per step go away.
-// Pair blocks never wait for anything, so the flags cannot deadlock; the wait is bounded all the same.
+// last pair blocks are still gathering; then every lane waits for the force record of ITS atom (the pair wave stores
+// {force, launch number} as one 16-byte word) and updates.  Behind the last pair block only one load-update-store
+// round remains, and the stored force array, its reload and one launch per step go away.
+// Pair blocks never wait for anything, so the wait cannot deadlock; it is bounded all the same.
 // Other blocks still read the positions of this launch, so the new ones go to the OTHER position buffer and the
 // OTHER cell-sorted copy (the host swaps the two after every fused launch).  Same device functions in the same
 // order as md_step_bonded_kernel / md_step_kernel: trajectories are bit-identical to the separate kernels.
@@ -1143,9 +1143,9 @@ struct FusedStep {   // what does (kernel argument)
   const float *pos_in;  // positions of this launch's forces, original atom order (partners of the bonded terms)
   float *pos_out;       // drifted positions
   float4 *sorted_out;   // their cell-sorted records
-  float4 *fsort;        // pair forces of this launch, cell-sorted order (pair blocks write, step blocks read)
-  unsigned *done;       // [pair blocks][waves]: launch number `gen` once the wave's forces are in fsort
-  unsigned gen;
+  float4 *fsort;        // {pair force, launch number} per atom, cell-sorted order (pair blocks write, step blocks watch)
+  unsigned gen;         // number of this launch (never 0)
+  int bonded;           // the atoms have bonded records (FusedStatic::has_bonded)
   int nstep_blocks;     // step blocks at the end of the grid (a multiple of 8, like the pair blocks)
   uint64_t noise_step;
   unsigned *near_host;  // chain skipping: report words of the NEXT step's displacement test (null: none)
@@ -1157,6 +1157,11 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
                                                   const PairConsts<float> &c, int n, const float4 *__restrict__ sorted,
                                                   const int *__restrict__ order, int j, int npair, float *s_lds);
 
+#if TMD_EXP & (1 << 21)
+#define TMD_STEP_POLL_SLEEP 16
+#else
+#define TMD_STEP_POLL_SLEEP 4
+#endif
 constexpr int kAuxDeviceScope = 16;  // sc1 of a gfx942/950 buffer access: coherent across the XCDs' L2s
 // lmode bits (list bookkeeping duties of the launch's first thread)
 constexpr int kLmViolation = 1;  // the chain of this step was left out and its displacement test ran in the previous
@@ -1199,6 +1204,9 @@ __global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fa
   // blocks of the last eighths have nothing to do.
   const int blk = (int)((blockIdx.x & 7u) * (npair >> 3) + (blockIdx.x >> 3));
   if (blk * (int)(blockDim.x >> 6) * APW >= n) return;  // (block-uniform: nobody is left waiting at the barrier below)
+#if TMD_EXP & (1 << 20)  // EXPERIMENT: pair waves issue ahead of step-block waves
+  if (FUSED) __builtin_amdgcn_s_setprio(2);
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
 #if TMD_EXP & 512  // DEBUG (wrong results, timing only): i-pairs — a lane group evaluates the list of atom 2p for atoms 2p, 2p+1
   const int a = (wave * APW + lane / LPA) * 2;
@@ -1610,18 +1618,14 @@ __global__ __launch_bounds__(TMD_FAST_THREADS, TMD_FAST_WAVES) void list_pair_fa
   }
 #endif
   if constexpr (FUSED != 0) {
-    // Forces to the cell-sorted array the step blocks read, then this wave's flag.  Both are written through to
-    // device scope (sc1) and the flag is issued once the force stores have been acknowledged (vmcnt 0) — an
-    // agent-scope release would do the same with buffer_wbl2, a write-back of the whole L2 per wave: 365 us per launch.
+    // The force record {fx, fy, fz, launch number} goes to the cell-sorted array the step blocks watch, as ONE 16-byte
+    // store written through to device scope (sc1): the number in .w says the force beside it is this launch's.
+    // (A flag per wave behind the stores cost a memory round trip more at the end of the launch; an agent-scope
+    // release does it with buffer_wbl2, a write-back of the whole L2 per wave: 365 us per launch.)
     const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fstep.fsort, 0, n * 16, 0x00020000);
     if (active && sub == 0)
-      __builtin_amdgcn_raw_buffer_store_b128((v4u){__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(sz), 0u}, frsrc,
-                                             a * 16, 0, kAuxDeviceScope);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (compiler ordering; no cache maintenance)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-      __hip_atomic_store(fstep.done + (size_t)blk * (TMD_FAST_THREADS / 64) + (threadIdx.x >> 6), fstep.gen, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_raw_buffer_store_b128((v4u){__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(sz), fstep.gen},
+                                             frsrc, a * 16, 0, kAuxDeviceScope);
     return;
   }
   if (active && sub == 0 && forces) {
@@ -1981,11 +1985,13 @@ template <bool LANGEVIN, int APB>
 __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict__ fst, const FusedStep &fs,
                                                   const PairConsts<float> &c, int n, const float4 *__restrict__ sorted,
                                                   const int *__restrict__ order, int j, int npair, float *s_lds) {
-  constexpr int K = 64 / APB;            // pair blocks per step block
-  constexpr int WPB = TMD_FAST_THREADS / 64;  // waves of a pair block
+  constexpr int K = 64 / APB;  // pair blocks per 64 atoms
   float(*s_part)[3][64] = reinterpret_cast<float(*)[3][64]>(s_lds);  // [kQuad][3][64], the pair role's LJ table space
   const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-  const int xcd = j & 7, q = j >> 3, g8 = npair >> 3;
+  // With bonded records a step block is 64 atoms (its four waves share their records); without, every wave is a unit
+  // of 64 atoms of its own (four waves of which three only met at the barrier doubled the waves of a 10^6-atom LJ launch).
+  const bool bonded = fs.bonded != 0;  // (launch-uniform)
+  const int xcd = j & 7, q = bonded ? (j >> 3) : (j >> 3) * kQuad + w, g8 = npair >> 3;
   const int kc = K * q + lane / APB;  // this lane's pair block within the XCD's eighth
   const int a = (xcd * g8 + kc) * APB + lane % APB;
   const bool exists = kc < g8 && a < n;
@@ -2000,7 +2006,7 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
   s.chk.seq = fs.seq;
   s.chk.parity = fs.parity;
   s.chk.skipped = 0;  // (unknown here: the next launch's first thread looks, kLmViolation)
-  const bool integrates = w == 0 && exists;
+  const bool integrates = (w == 0 || !bonded) && exists;
   AtomIn<float> x{};
   if (integrates) {  // every load of the update but the force, in flight during the bonded part
     x.m = s.mass[o];
@@ -2016,49 +2022,49 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
     x.h2 = list_check_limit(s.chk, o);
     x.slot = a;
   }
-  const bool bonded = fst->has_bonded != 0;  // (launch-uniform)
-  float fx = 0.f, fy = 0.f, fz = 0.f;
-  if (bonded && exists) {
-    const BondedArgs<float> A = fst->A;
-    double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
-    const AtomRec<float> *rec = A.arec + (size_t)o * A.arec_stride;
-    for (int k = w; k < A.arec_stride; k += kQuad) {
-      const AtomRec<float> r = rec[k];
-      if (r.ent == kNoRec) break;  // records are packed from the front
-      eval_rec<float>(A, s.pos_in, o, r, fx, fy, fz, e);
-    }
-  }
-  s_part[w][0][lane] = fx;
-  s_part[w][1][lane] = fy;
-  s_part[w][2][lane] = fz;
+  float fb[3] = {0.f, 0.f, 0.f};
   float g[3] = {0.f, 0.f, 0.f};
-  if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
-  __syncthreads();
-  if (w != 0) return;
-  float fb[3];
+  if (bonded) {
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (exists) {
+      const BondedArgs<float> A = fst->A;
+      double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
+      const AtomRec<float> *rec = A.arec + (size_t)o * A.arec_stride;
+      for (int k = w; k < A.arec_stride; k += kQuad) {
+        const AtomRec<float> r = rec[k];
+        if (r.ent == kNoRec) break;  // records are packed from the front
+        eval_rec<float>(A, s.pos_in, o, r, fx, fy, fz, e);
+      }
+    }
+    s_part[w][0][lane] = fx;
+    s_part[w][1][lane] = fy;
+    s_part[w][2][lane] = fz;
+    if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
+    __syncthreads();
+    if (w != 0) return;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
-  // wait for the pair waves of these atoms: lane l watches wave l % WPB of pair block K q + l / WPB.  (They were
-  // dispatched before this block and wait for nothing; the bound only keeps a broken assumption from hanging the GPU.)
-  if (lane < K * WPB) {
-    const int kb = K * q + lane / WPB;
-    const int blk = xcd * g8 + kb;
-    if (kb < g8 && blk * APB < n) {
-      const unsigned *flag = fs.done + (size_t)blk * WPB + lane % WPB;
-      unsigned spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fs.gen) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 22)) {
-          s.chk.flags[F_VIOLATION] = 1;  // the caller rewinds and repeats the batch
-          break;
-        }
+    for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
+  } else {
+    if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
+  }
+  // Wait for this atom's force record of THIS launch (.w = launch number; a 16-byte access is one request at the L2).
+  // Its pair block was dispatched before this block and waits for nothing; the bound only keeps a broken assumption
+  // from hanging the GPU.
+  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fs.fsort, 0, n * 16, 0x00020000);
+  v4u f = (v4u){0u, 0u, 0u, fs.gen};
+  if (integrates) {
+    unsigned spins = 0;
+    while (true) {
+      f = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope);
+      if (f.w == fs.gen) break;
+      __builtin_amdgcn_s_sleep(TMD_STEP_POLL_SLEEP);
+      if (++spins > (1u << 22)) {
+        s.chk.flags[F_VIOLATION] = 1;  // the caller rewinds and repeats the batch
+        break;
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (ordering only; the load below goes to device scope itself)
   if (!integrates) return;
-  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fs.fsort, 0, n * 16, 0x00020000);
-  const v4u f = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope);
   x.f[0] = __uint_as_float(f.x), x.f[1] = __uint_as_float(f.y), x.f[2] = __uint_as_float(f.z);
   md_step_atom<float, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, bonded, LANGEVIN ? g : nullptr);
 }
@@ -2175,8 +2181,10 @@ int wait_observed(volatile unsigned *hseq, unsigned seq, hipStream_t st) {
 
 // state at the entry of an MD batch (positions, velocities, forces) in one launch; n4 = 16-byte words per array
 __global__ void snapshot3_kernel(size_t n4, const uint4 *__restrict__ a, const uint4 *__restrict__ b,
-                                 const uint4 *__restrict__ c, uint4 *__restrict__ out) {
+                                 const uint4 *__restrict__ c, uint4 *__restrict__ out, double *__restrict__ zero,
+                                 int nzero) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero && i < (size_t)nzero) zero[i] = 0.0;  // the call's energy buffer (one fill launch less per call)
   if (i >= n4) return;
   out[i] = a[i];
   out[n4 + i] = b[i];
@@ -2248,14 +2256,14 @@ struct Replica {
   DevBuf sorted_alt, fused_dev;
   FusedStatic fused_host;
   bool fused_host_valid = false;
-  DevBuf fsort, done;     // pair forces in cell-sorted order and the pair waves' flags of a fused launch
-  unsigned fused_gen = 0;  // number of the last fused launch (what its flags hold)
+  DevBuf fsort;            // {pair force, launch number} per atom in cell-sorted order (fused launches)
+  unsigned fused_gen = 0;  // number of the last fused launch
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf extent;  // int[6]: keys of the coordinate extent of sorted_xyzq (extent_note)
   DevBuf paircount;  // unsigned long long
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
-                      &nlist, &nneigh, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &done})
+                      &nlist, &nneigh, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort})
       b->release();
   }
 };
@@ -2557,7 +2565,7 @@ struct FusedLaunch {
 template <typename R, bool ENERGY>
 int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, int overwrite, double *energies,
                      unsigned long long *paircount, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
-                     int lmode = 0, const FusedLaunch *fl = nullptr) {
+                     int lmode = 0, const FusedLaunch *fl = nullptr, bool fold = true) {
   using R4 = typename Vec<R>::T4;
   using R2 = typename Vec<R>::T2;
   const int n = ctx->d.natoms;
@@ -2601,16 +2609,14 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
         // one per 64 / (atoms of a pair block) pair blocks of an XCD's eighth
         fstep = fl->step;
         const int k = rp.lg.lpa * 64 / TMD_FAST_THREADS, g8 = npair8 / 8;
-        fstep.nstep_blocks = 8 * ((g8 + k - 1) / k);
-        const size_t flag_bytes = sizeof(unsigned) * (size_t)npair8 * wpb;
-        if (rp.done.bytes < flag_bytes) {
-          TMD_TRY(rp.done.ensure(flag_bytes));
-          TMD_HIP(hipMemsetAsync(rp.done.p, 0, rp.done.bytes, st));
+        const int units = (g8 + k - 1) / k;  // 64-atom units per XCD's eighth: a block with bonded records, a wave without
+        fstep.nstep_blocks = 8 * (fstep.bonded ? units : (units + 3) / 4);
+        if (rp.fsort.bytes < sizeof(R4) * (size_t)n) {
+          TMD_TRY(rp.fsort.ensure(sizeof(R4) * (size_t)n));
+          TMD_HIP(hipMemsetAsync(rp.fsort.p, 0, rp.fsort.bytes, st));  // launch number 0 = never written
           rp.fused_gen = 0;
         }
-        TMD_TRY(rp.fsort.ensure(sizeof(R4) * (size_t)n));
-        if (++rp.fused_gen == 0) rp.fused_gen = 1;  // (0 = never written)
-        fstep.done = rp.done.as<unsigned>();
+        if (++rp.fused_gen == 0) rp.fused_gen = 1;
         fstep.gen = rp.fused_gen;
         fstep.fsort = rp.fsort.as<float4>();
         if constexpr (!ENERGY) {
@@ -2643,7 +2649,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
 #undef TMD_LAUNCH_FAST_T
 #undef TMD_LAUNCH_FAST_S
       TMD_HIP(hipGetLastError());
-      if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
+      if (ENERGY && fold) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
       return 0;
     }
   }
@@ -2683,7 +2689,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
 #undef TMD_LAUNCH_FAST_T
 #undef TMD_LAUNCH_FAST_S
       TMD_HIP(hipGetLastError());
-      if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
+      if (ENERGY && fold) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
       return 0;
     }
   }
@@ -2713,7 +2719,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
 #undef TMD_LAUNCH_LPA
 #undef TMD_LAUNCH
   TMD_HIP(hipGetLastError());
-  if (ENERGY) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
+  if (ENERGY && fold) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
   return 0;
 }
 
@@ -2838,6 +2844,7 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
 
 constexpr int kPrechecked = 1 << 16;  // internal compute flag: displacement test already enqueued
 constexpr int kSkipChain = 1 << 18;   // internal compute flag: the host leaves the rebuild chain out for this step
+constexpr int kDeferFold = 1 << 20;  // internal compute flag: a bonded evaluation with energies follows and folds the scratch rows
 constexpr int kViolationCheck = 1 << 19;  // internal compute flag: ... and the step's displacement test (epilogue of the
                                           // previous pair launch) did not know that: the pair launch looks itself
 constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
@@ -2957,7 +2964,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     fl.step.parity = (int)(rp.step & 1);
   }
   if (flags & TMDHIP_WANT_ENERGY)
-    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1, lmode)));
+    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1, lmode, nullptr, !(flags & kDeferFold))));
   else
     TMD_TRY((launch_list_pair<R, false>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1, lmode, fused ? &fl : nullptr)));
   if (pc) hipLaunchKernelGGL(halve_count_kernel, dim3(1), dim3(1), 0, st, pc);
@@ -3235,6 +3242,15 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         if (langevin) launch_md_step<R, true, true, true>(a, c, check, st);
         else launch_md_step<R, true, false, true>(a, c, check, st);
       } else if (first) {
+        // Every fused step moves the positions to the other buffer; with an odd number of them ahead (all interior
+        // steps of the call, if the first one can be fused) the drift of this first step goes to the second buffer,
+        // so that the call ends in the caller's tensor without a copy.
+        if (check && list && cur[r] == home && d->niter >= 2 && ((d->niter - 1) & 1) && fused_step_possible<R>(ctx, rp, c) &&
+            tmd::bonded_inline_args(ctx, box, A) != 2) {
+          TMD_TRY(rp.pos_alt.ensure(sizeof(R) * stride));
+          a.pos_out = rp.pos_alt.as<R>();
+          cur[r] = a.pos_out;
+        }
         launch_md_step<R, false, false, true>(a, c, check, st);
       } else {
         if (langevin) launch_md_step<R, true, true, false>(a, c, check, st);
@@ -3294,6 +3310,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               fl.step.pos_out = pos == home ? rp.pos_alt.as<R>() : home;
               fl.step.sorted_out = rp.sorted_alt.as<R4>();
               fl.step.noise_step = d->step0 + (uint64_t)it;
+              fl.step.bonded = bm == 1;
               if (pace) {  // the next iteration's sequence number (see the pacing above)
                 unsigned nseq = rp.seq + 1;
                 if (nseq == 0) nseq = 1;
@@ -3306,8 +3323,9 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
           const int rc = compute_list<R>(ctx, rp, pos, box, f, en,
                                          flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0) |
                                              (skip_chain ? kSkipChain : 0) |
-                                             (skip_chain && was_stepped ? kViolationCheck : 0), st,
-                                         fuse ? &fl : nullptr);
+                                             (skip_chain && was_stepped ? kViolationCheck : 0) |
+                                             (en && !fuse && rp.have_list && tmd::bonded_inline_args(ctx, box, A) != 0 ? kDeferFold : 0),
+                                         st, fuse ? &fl : nullptr);
           rp.pub_ptr = nullptr;
           if (fuse && rc == 0) {
             if constexpr (std::is_same<R, float>::value) cur[r] = fl.step.pos_out;
@@ -3738,8 +3756,8 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     return fail("tmdhip_md_run: null buffer");
   if (desc->niter == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (desc->energies_dev)
-    TMD_HIP(hipMemsetAsync(desc->energies_dev, 0, sizeof(double) * TMDHIP_NENERGY * ctx->rep.size(), st));
+  const int nzero = (int)(TMDHIP_NENERGY * ctx->rep.size());
+  bool zeroed = desc->energies_dev == nullptr;
   if (ctx->algorithm == TMDHIP_ALGO_CELLLIST) {
     // state at entry, for tmdhip_md_restore (a truncated list is only detected after the batch)
     const size_t bytes = (size_t)ctx->real_size * 3 * ctx->d.natoms * ctx->rep.size();
@@ -3750,10 +3768,12 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
                          bytes % 16 == 0;
     if (aligned) {
       const size_t n4 = bytes / 16;
+      const bool fits = (size_t)nzero <= n4;
       hipLaunchKernelGGL(snapshot3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4,
                          (const uint4 *)desc->pos_dev, (const uint4 *)desc->vel_dev, (const uint4 *)desc->forces_dev,
-                         (uint4 *)sn);
+                         (uint4 *)sn, fits ? desc->energies_dev : nullptr, nzero);
       TMD_HIP(hipGetLastError());
+      zeroed = zeroed || fits;
     } else {
       TMD_HIP(hipMemcpyAsync(sn, desc->pos_dev, bytes, hipMemcpyDeviceToDevice, st));
       TMD_HIP(hipMemcpyAsync(sn + padded, desc->vel_dev, bytes, hipMemcpyDeviceToDevice, st));
@@ -3761,6 +3781,7 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     }
     ctx->snap_bytes = bytes;
   }
+  if (!zeroed) TMD_HIP(hipMemsetAsync(desc->energies_dev, 0, sizeof(double) * nzero, st));
   const int rc = ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
   for (auto &rp : ctx->rep) rp.skin_vel = nullptr;  // rebuilds outside an MD run know no velocities: static skins
   return rc;
