@@ -36,11 +36,15 @@ FLOP_PER_PAIR = 50.0             # ~50 FLOP + 1 rsqrt per in-cut
 SIMDS, NOMINAL_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues over 2 cycles per SIMD
 
 
+SHORT_TIMED = 4  # timed launches of a run shorter than 128 steps
+
+
 def timing_stride(steps):
     """HIP events time every n-th launch of the pair kernel: >= 128 steps: every 16th launch over the whole region;
-    shorter runs: the first 8 launches of the region, consecutively (a launch with events attached costs the stream
-    ~7 us when its neighbours are timed too and ~10 us alone among untimed ones — tools/short_call.py — so eight in
-    a row are the cheapest way to >= 8 timed launches in a 20-step region)."""
+    shorter runs: launches 2-5 of the region, consecutively (a launch with events attached costs the stream ~7 us when
+    its neighbours are timed too and ~10 us alone among untimed ones — tools/short_call.py; eight of them were 56 us of
+    a 1 500-us region, i.e. 4 % of the figure being measured.  The first launch of a step() call is passed over: it is
+    the one launch of the call that does not make the next step itself)."""
     return 16 if steps >= 128 else 1
 
 
@@ -138,7 +142,7 @@ def run_c5(args, rank, world, local_rank, device, launched):
         integ = Integrator(s, f, TIMESTEP_FS, device, gamma=1.0, T=85.0)
         integ.step(max(args.warmup, 1))
         stride = timing_stride(args.steps)
-        f.enable_timing(s.pos, True, every=stride, limit=8 if args.steps < 128 else 0)
+        f.enable_timing(s.pos, True, every=stride, limit=SHORT_TIMED if args.steps < 128 else 0, skip=1 if args.steps < 128 else 0)
         f.read_timing(s.pos, reset=True)
         st0 = f.stats(s.pos)
         torch.cuda.synchronize()
@@ -390,8 +394,8 @@ def main():
     # HIP events on every 16th launch of the pair kernel, spread over the whole timed region (attached to the
     # dispatch itself since round 2: events recorded in front of and behind a launch cost 6.6 us of stream time each pair)
     stride = timing_stride(args.steps)
-    # short runs: exactly 8 timed launches (every event pair costs stream time that the step loop pays)
-    forces.enable_timing(system.pos, True, every=stride, limit=8 if args.steps < 128 else 0)
+    # short runs: exactly SHORT_TIMED timed launches (every event pair costs stream time that the step loop pays)
+    forces.enable_timing(system.pos, True, every=stride, limit=SHORT_TIMED if args.steps < 128 else 0, skip=1 if args.steps < 128 else 0)
     forces.read_timing(system.pos, reset=True)
     fan.barrier()
     torch.cuda.synchronize()
@@ -491,8 +495,8 @@ def main():
             "avg_kernel_us": pair_avg_s * 1e6,
             "launches_timed": int(pair_launches),
             "timing": (f"HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of every {stride}th pair-kernel "
-                       "launch of the timed region, on the launch stream" + (" (the first 8 of them)" if args.steps < 128 else ""))
-            if stride > 1 else "HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of the first 8 pair-kernel launches "
+                       "launch of the timed region, on the launch stream")
+            if stride > 1 else f"HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of pair-kernel launches 2-{1 + SHORT_TIMED} "
             "of the timed region, on the launch stream",
             "step_frac_of_hbm_roofline": (step_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
             "alu": {"flops_per_launch": FLOP_PER_PAIR * pcut, "achieved_tflops": alu_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,

@@ -193,6 +193,10 @@ typedef struct tmdhip_md_desc {
   double gamma;                         /* friction in internal units                                */
   uint64_t seed, step0;                 /* noise stream key and position (step0 + iteration)         */
   double *energies_dev;                 /* [R*TMDHIP_NENERGY]: energies of the LAST iteration (overwritten), or NULL */
+  int32_t continuation;                 /* != 0: positions and box are what the previous tmdhip_md_run of this context
+                                         * left (a hint: the first step may then leave its rebuild chain out like any
+                                         * other; a wrong hint costs a rewind, never a wrong result) (ABI 4) */
+  int32_t reserved;
 } tmdhip_md_desc;
 int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
 /* What Integrator.step returns after its loop (integrator.py:121-125), with ONE read-back and ONE host
@@ -233,7 +237,8 @@ int tmdhip_invalidate_list(tmdhip_ctx *ctx, int replica);
 int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out);
 
 /* HIP-event timing of the dominant (pair) kernel, recorded on the launch stream.  on = 0: off; low 16 bits = n:
- * every n-th launch (1: every launch); bits 16 and up = stop after that many timed launches (0: no limit).  The
+ * every n-th launch (1: every launch); bits 16..27 = stop after that many timed launches (0: no limit); bits 28..30 =
+ * launches passed over before the first timed one.  The
  * start / stop events are attached to the kernel's own dispatch (hipExtLaunchKernel), not recorded around it. */
 int tmdhip_timing_enable(tmdhip_ctx *ctx, int on);
 int tmdhip_timing_read(tmdhip_ctx *ctx, double *pair_kernel_ms, int64_t *launches, int reset);

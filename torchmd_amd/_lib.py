@@ -108,6 +108,8 @@ class MdDesc(C.Structure):
         ("seed", C.c_uint64),
         ("step0", C.c_uint64),
         ("energies_dev", C.c_void_p),
+        ("continuation", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -2940,7 +2940,8 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
   hipEvent_t e0 = nullptr, e1 = nullptr;
   // every `timing_stride`-th launch is bracketed by events: an event pair costs ~3 us of stream time,
   // so timing every launch would slow down the very loop being measured
-  const bool timed = ctx->timing && (ctx->timing_seen++ % ctx->timing_stride) == 0 &&
+  const int64_t seen = ctx->timing_seen++;
+  const bool timed = ctx->timing && seen >= 0 && (seen % ctx->timing_stride) == 0 &&
                      (ctx->timing_limit == 0 || ctx->timing_taken < ctx->timing_limit);
   if (timed) ctx->timing_taken++;
   if (timed) {
@@ -3186,8 +3187,9 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       a.chk = make_check<R>(ctx, rp);
       // Chain skipping (ListCheck): on large lists the host stays one step behind the device — it waits until the
       // pair kernel of the previous step has started (45 us of kernel time are then still ahead of it) — and
-      // leaves the rebuild chain out when no atom was near its limit in that step.  Never on the first step of a
-      // call (the caller may have moved atoms in between), nor in the repetition of a rewound batch.
+      // leaves the rebuild chain out when no atom was near its limit in that step.  On the first step of a call only
+      // if the caller says that nothing has moved since the previous one (tmdhip_md_desc::continuation; the report is
+      // then the previous call's last), never in the repetition of a rewound batch.
       bool skip_chain = false;
       const bool pace = check && chain_skip_on && (int64_t)n * rp.lg.maxn >= chain_min_entries;
       if (pace) {
@@ -3198,8 +3200,10 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
           rp.seq_valid = false;
         }
         volatile unsigned *hp = rp.hostpub;
-        if (rp.seq_valid && it > 0 && !pace_timed_out && !wait_published(hp, rp.seq)) pace_timed_out = true;
-        if (rp.seq_valid && it > 0 && !pace_timed_out) {
+        // (the first step of a call: only when the caller vouches that nothing has moved since the previous call)
+        const bool follows = it > 0 || d->continuation != 0;
+        if (rp.seq_valid && follows && !pace_timed_out && !wait_published(hp, rp.seq)) pace_timed_out = true;
+        if (rp.seq_valid && follows && !pace_timed_out) {
           // no chain when nobody was near its limit in the previous step — or when that step rebuilt the list
           // (with its chain in place: every displacement is one step old now)
           const bool near = hp[1 + (rp.seq & 1u)] == rp.seq, rebuilt = hp[3 + (rp.seq & 1u)] == rp.seq;
@@ -3872,8 +3876,9 @@ int tmdhip_timing_enable(tmdhip_ctx *ctx, int on) {
   if (!ctx) return fail("tmdhip_timing_enable: null ctx");
   ctx->timing = on != 0;
   ctx->timing_stride = (on & 0xFFFF) > 1 ? (on & 0xFFFF) : 1;
-  ctx->timing_limit = on >> 16;
-  ctx->timing_seen = ctx->timing_taken = 0;
+  ctx->timing_limit = (on >> 16) & 0xFFF;
+  ctx->timing_taken = 0;
+  ctx->timing_seen = -(int64_t)((on >> 28) & 7);  // the first launches are passed over
   // the events of the first launches are created here, not inside the region being timed (a hipEventCreate
   // costs ~10 us of host time: twenty of them in a 20-step run made the loop enqueue-bound)
   while (ctx->timing && ctx->events.size() < 192) {

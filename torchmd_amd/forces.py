@@ -665,10 +665,15 @@ class Forces:
         d.dt, d.gamma = float(dt), float(gamma)
         d.seed, d.step0 = int(seed), int(step0)
         d.energies_dev = eng.ebuf.data_ptr()  # zeroed by the library
+        # has anybody written the positions through torch since the previous call returned?  (tensor version counters;
+        # the library's own kernels write through raw pointers and do not count.)  Only a hint, see tmdhip_md_desc.
+        key = (pos.data_ptr(), pos._version, id(hbox))
+        d.continuation = 1 if (not restore and getattr(eng, "_md_key", None) == key) else 0
         stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
         if restore:
             L.check(eng.lib.tmdhip_md_restore(eng.ctx, C.byref(d), stream), "tmdhip_md_restore")
         L.check(eng.lib.tmdhip_md_run(eng.ctx, C.byref(d), stream), "tmdhip_md_run")
+        eng._md_key = (pos.data_ptr(), pos._version, id(hbox))
         return eng.ebuf
 
     def energy_columns(self):
@@ -705,11 +710,11 @@ class Forces:
             "steps_in_pair_launch": int(st.steps_in_pair_launch),
         }
 
-    def enable_timing(self, pos, on=True, every=1, limit=0):
+    def enable_timing(self, pos, on=True, every=1, limit=0, skip=0):
         """HIP events around every `every`-th launch of the list pair kernel (an event pair costs 3-6 us of stream
-        time), at most `limit` of them (0: no limit)."""
+        time), at most `limit` of them (0: no limit), after passing over the first `skip` (<= 7) launches."""
         eng = self._engine(pos.detach())
-        code = (min(max(1, int(every)), 0xFFFF) | (max(0, int(limit)) << 16)) if on else 0
+        code = (min(max(1, int(every)), 0xFFFF) | (min(max(0, int(limit)), 0xFFF) << 16) | (min(max(0, int(skip)), 7) << 28)) if on else 0
         L.check(eng.lib.tmdhip_timing_enable(eng.ctx, code))
 
     def read_timing(self, pos, reset=True):
