@@ -585,6 +585,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   __shared__ int seg_code[128];  // periodic image of the stencil cell: 2 bits per axis, 0:-L 1:0 2:+L
   const int lane = threadIdx.x;
   int wmax = 0;
+  unsigned long long dbg_work = 0;  // candidates x atoms over the block's cells (debug timeline only)
   // LOOP: the grid is capped and a block walks several cells (a launch that returns at once on the steps
   // without a rebuild still costs time proportional to its block count: the 343k cells of the 10^6-atom
   // LJ box = 100 us per step).  Systems with fewer cells keep one cell per block (no loop: faster code).
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   seg_prefix[lane] = inc0 - cnt2[0];
   seg_prefix[lane + 64] = tot0 + inc1 - cnt2[1];
   if (lane == 0) seg_prefix[128] = ncand;
+  if (dbg) dbg_work += (unsigned long long)ncand * (unsigned long long)(ce - cs);
   __syncthreads();
 
   // per-atom data of the i block staged in LDS as two 16-byte records that the inner loop reads with
@@ -902,8 +904,10 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     unsigned long long *o = dbg + 4 * (size_t)blockIdx.x;
     o[0] = dbg_t0;
     o[1] = __builtin_readcyclecounter();
-    o[2] = __builtin_amdgcn_s_getreg((6 << 11) | 20);
-    o[3] = (unsigned long long)wmax;
+    // XCC id | HW_ID (wave 0-3, SIMD 4-5, pipe 6-7, CU 8-11, SH 12, SE 13-15) << 8; longest list | work << 32
+    o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((6 << 11) | 20) |
+           ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8);
+    o[3] = (unsigned long long)wmax | (dbg_work << 32);
   }
   // flags[2] = largest neighbour count ever seen; > maxn means a list was truncated (overflow)
 #pragma unroll
