@@ -656,3 +656,49 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     for a, b in zip(r1, r0):
         for x, y in zip(a, b):
             assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.gpu
+def test_wrong_continuation_hint_is_rewound(monkeypatch):
+    """The first step of a step() call leaves its rebuild chain out when the positions tensor has not been written
+    through torch since the previous call (tmdhip_md_desc::continuation, from the tensor's version counter).  The hint
+    can be wrong — here a third of the atoms are moved by 1.5 A through `.data`, which does not bump the counter —
+    and must then cost a rewind, not a wrong result: the displacement test of that first step raises F_VIOLATION, the
+    batch is repeated with every chain in place, and the forces equal those of a fresh evaluation."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    mol, pos, box = tip3p_box(14, seed=6)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    s = System(mol.numAtoms, 1, dt, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    torch.manual_seed(3)
+    s.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
+    f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+    f.compute(s.pos, s.box, s.forces)
+    torch.manual_seed(9)
+    integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+    integ.step(12)
+    integ.step(12)  # (a call whose hint is right: continuation)
+    skipped0 = f.stats(s.pos)["chains_skipped"]
+    version = s.pos._version
+    nmol = mol.numAtoms // 3
+    shift = torch.zeros_like(s.pos)
+    shift[0, : 3 * (nmol // 3), 0] = 1.5  # whole molecules, so that no bond is stretched
+    s.pos.data.add_(shift)
+    assert s.pos._version == version  # the hint will say "nothing has moved"
+    integ.step(8)
+    st = f.stats(s.pos)
+    assert st["overflow"] == 0 and st["chains_skipped"] > skipped0
+    fresh = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+    F2 = torch.zeros_like(s.pos)
+    fresh.compute(s.pos, s.box, F2)
+    assert torch.isfinite(s.forces).all()
+    assert (F2 - s.forces).abs().max().item() < 2e-3
