@@ -596,14 +596,16 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin"])
+@pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin", "water_counter_wraps"])
 def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     """Interior steps of tmdhip_md_run on the lean fp32 pair kernel are made by the pair launch itself ("step blocks"
     behind the pair blocks wait for the pair waves of their atoms: FusedStep in nonbonded.hip) instead of by an
     integrator launch.  Same device functions in the same order: positions, velocities, forces and energies equal
     those of the separate kernels (TMDHIP_FUSED_STEP=0) bit for bit — with velocity-dependent skins, rebuilds inside
     the window and chain skipping active (size gate opened).  Water = 8 lanes per atom (two pair blocks per step
-    block) + inline bonded records + reaction field; the LJ box = 4 lanes per atom, no bonded terms."""
+    block) + inline bonded records + reaction field; the LJ box = 4 lanes per atom, no bonded terms.
+    `water_counter_wraps`: the launch number the force records carry starts at 2^32 - 20 and wraps during the run
+    (0 is skipped: it means "never written")."""
     from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import Integrator, maxwell_boltzmann
@@ -612,6 +614,8 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
 
     dev, dt = _dev(), torch.float32
     monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    if case == "water_counter_wraps":
+        monkeypatch.setenv("TMDHIP_DEBUG_FUSED_GEN0", str(2**32 - 20))
     nrep = 2 if case == "water_two_replicas" else 1
     if case.startswith("water"):
         mol, pos, box = tip3p_box(14, seed=4)  # 8 232 atoms
@@ -662,7 +666,7 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
 def test_wrong_continuation_hint_is_rewound(monkeypatch):
     """The first step of a step() call leaves its rebuild chain out when the positions tensor has not been written
     through torch since the previous call (tmdhip_md_desc::continuation, from the tensor's version counter).  The hint
-    can be wrong — here a third of the atoms are moved by 1.5 A through `.data`, which does not bump the counter —
+    can be wrong — here half of the box is sheared by 0.9 A through `.data`, which does not bump the counter —
     and must then cost a rewind, not a wrong result: the displacement test of that first step raises F_VIOLATION, the
     batch is repeated with every chain in place, and the forces equal those of a fresh evaluation."""
     from torchmd_amd.builders import tip3p_box, water_forcefield
@@ -689,9 +693,12 @@ def test_wrong_continuation_hint_is_rewound(monkeypatch):
     integ.step(12)  # (a call whose hint is right: continuation)
     skipped0 = f.stats(s.pos)["chains_skipped"]
     version = s.pos._version
-    nmol = mol.numAtoms // 3
+    # shear the box by 0.9 A (more than any half skin) along the plane x = L/2: whole molecules move (by their oxygen's
+    # side), so no bond is stretched and nothing overlaps, but pairs across the plane enter and leave the cutoff
+    ox = s.pos[0, 0::3, 0]
+    moved = (ox - torch.floor(ox / float(box[0])) * float(box[0])) > 0.5 * float(box[0])
     shift = torch.zeros_like(s.pos)
-    shift[0, : 3 * (nmol // 3), 0] = 1.5  # whole molecules, so that no bond is stretched
+    shift[0, :, 1] = 0.9 * moved.repeat_interleave(3).to(dt)
     s.pos.data.add_(shift)
     assert s.pos._version == version  # the hint will say "nothing has moved"
     integ.step(8)

@@ -580,6 +580,13 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   // the whole list as a bounds-checked buffer (< 2^30 entries): an out-of-range store is dropped
   const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
       nlist, 0, (int)((((size_t)n + lg.apw - 1) / lg.apw) * (size_t)lg.maxn * lg.apw * 4u), 0x00020000);
+#if TMD_EXP & (1 << 22)  // EXPERIMENT: 8 KB of LDS per block = 20 blocks per CU = 5 waves per SIMD resident, the rest dispatched as waves finish
+  __shared__ int occ_pad[900];
+  if (n < 0) occ_pad[threadIdx.x] = n, nlist[0] = occ_pad[(threadIdx.x + 1) & 63];
+#elif TMD_EXP & (1 << 23)  // EXPERIMENT: 6.6 KB = 24 blocks per CU = 6 waves per SIMD
+  __shared__ int occ_pad[500];
+  if (n < 0) occ_pad[threadIdx.x] = n, nlist[0] = occ_pad[(threadIdx.x + 1) & 63];
+#endif
   __shared__ int seg_start[128];
   __shared__ int seg_prefix[129];
   __shared__ int seg_code[128];  // periodic image of the stencil cell: 2 bits per axis, 0:-L 1:0 2:+L
@@ -2620,7 +2627,9 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
           TMD_HIP(hipMemsetAsync(rp.fsort.p, 0, rp.fsort.bytes, st));  // launch number 0 = never written
           rp.fused_gen = 0;
         }
-        if (++rp.fused_gen == 0) rp.fused_gen = 1;
+        if (rp.fused_gen == 0)  // test knob: start the launch counter just below its wrap-around
+          if (const char *e = std::getenv("TMDHIP_DEBUG_FUSED_GEN0")) rp.fused_gen = (unsigned)std::strtoul(e, nullptr, 0);
+        if (++rp.fused_gen == 0) rp.fused_gen = 1;  // (0 = "never written" in the records)
         fstep.gen = rp.fused_gen;
         fstep.fsort = rp.fsort.as<float4>();
         if constexpr (!ENERGY) {
