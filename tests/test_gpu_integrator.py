@@ -596,7 +596,8 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin", "water_counter_wraps"])
+@pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin", "water_counter_wraps",
+                                  "water_32_lanes", "water_64_lanes"])
 def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     """Interior steps of tmdhip_md_run on the lean fp32 pair kernel are made by the pair launch itself ("step blocks"
     behind the pair blocks wait for the pair waves of their atoms: FusedStep in nonbonded.hip) instead of by an
@@ -628,7 +629,8 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
         par = Parameters(argon_forcefield(mol), mol, terms, precision=dt)
         kw = dict(cutoff=9.0)
     gamma = None if case == "water_nve" else 1.0
-    monkeypatch.setenv("TMDHIP_LPA", "8" if case.startswith("water") else "4")
+    lanes = {"water_32_lanes": "32", "water_64_lanes": "64"}.get(case, "8" if case.startswith("water") else "4")
+    monkeypatch.setenv("TMDHIP_LPA", lanes)  # (32 / 64: what mid-size boxes get; 8 and 16 pair blocks per step block)
     torch.manual_seed(3)
     vel0 = maxwell_boltzmann(par.masses, 300.0, nrep)
 

@@ -2643,6 +2643,8 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
             case 4: TMD_LAUNCH_FUSED(4); break;
             case 8: TMD_LAUNCH_FUSED(8); break;
             case 16: TMD_LAUNCH_FUSED(16); break;
+            case 32: TMD_LAUNCH_FUSED(32); break;
+            case 64: TMD_LAUNCH_FUSED(64); break;
             default: return fail("fused MD step: unsupported lanes-per-atom");
           }
 #undef TMD_LAUNCH_FUSED
@@ -3057,16 +3059,15 @@ __global__ void fused_upload_kernel(FusedStatic v, FusedStatic *dst) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
 }
 
-// can the pair launch of this replica integrate the next step itself?  (lean fp32 kernel, 4 / 8 / 16 lanes per atom:
-// one wave holds the atoms of a block)
+// can the pair launch of this replica integrate the next step itself?  (lean fp32 kernel, 4 .. 64 lanes per atom: a
+// pair block's atoms fit one wave of a step block)
 template <typename R>
 bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairConsts<R> &c) {
   if (!std::is_same<R, float>::value) return false;
   const char *e = std::getenv("TMDHIP_FUSED_STEP");  // (read per call: tests switch it within a process)
   if (e && std::atoi(e) == 0) return false;
   const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
-  return only_lj_el && ctx->d.ntypes <= kEntryTypes && (rp.lg.lpa == 4 || rp.lg.lpa == 8 || rp.lg.lpa == 16) &&
-         TMD_FAST_THREADS / rp.lg.lpa <= 64;
+  return only_lj_el && ctx->d.ntypes <= kEntryTypes && rp.lg.lpa >= 4 && rp.lg.lpa <= 64 && TMD_FAST_THREADS / rp.lg.lpa <= 64;
 }
 
 template <typename R>
