@@ -54,8 +54,9 @@ extern "C" {
 #define TMDHIP_WANT_ENERGY 1 /* accumulate (+=) per-term energies into energies_dev          */
 #define TMDHIP_WANT_FORCES 2 /* accumulate (+=) forces into forces_dev                        */
 #define TMDHIP_COUNT_PAIRS 4 /* also count non-excluded i<j pairs with r <= cutoff (stats)    */
-#define TMDHIP_OVERWRITE_FORCES 8 /* nonbonded: store (=) instead of +=, so the caller need not zero
-                                     forces_dev first (the all-pairs path zero-fills internally)          */
+#define TMDHIP_OVERWRITE_FORCES 8 /* store (=) instead of +=: nonbonded, so that the caller need not zero
+                                     forces_dev first (the all-pairs path zero-fills internally); bonded
+                                     (ABI 4): forces_dev receives the bonded force alone                  */
 
 /* pair-search algorithm */
 #define TMDHIP_ALGO_AUTO 0

@@ -597,7 +597,7 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin", "water_counter_wraps",
-                                  "water_32_lanes", "water_64_lanes"])
+                                  "water_32_lanes", "water_64_lanes", "thrombin"])
 def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     """Interior steps of tmdhip_md_run on the lean fp32 pair kernel are made by the pair launch itself ("step blocks"
     behind the pair blocks wait for the pair waves of their atoms: FusedStep in nonbonded.hip) instead of by an
@@ -606,7 +606,9 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     the window and chain skipping active (size gate opened).  Water = 8 lanes per atom (two pair blocks per step
     block) + inline bonded records + reaction field; the LJ box = 4 lanes per atom, no bonded terms.
     `water_counter_wraps`: the launch number the force records carry starts at 2^32 - 20 and wraps during the run
-    (0 is skipped: it means "never written")."""
+    (0 is skipped: it means "never written").  `thrombin`: a protein (4 676 atoms, all seven terms, open boundaries) —
+    a heavy topology, whose bonded force is evaluated by bonded_wave_kernel in front of the pair launch into a buffer
+    that the step blocks add."""
     from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import Integrator, maxwell_boltzmann
@@ -618,7 +620,13 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     if case == "water_counter_wraps":
         monkeypatch.setenv("TMDHIP_DEBUG_FUSED_GEN0", str(2**32 - 20))
     nrep = 2 if case == "water_two_replicas" else 1
-    if case.startswith("water"):
+    if case == "thrombin":
+        g = load("thrombin")
+        par = GoldenParameters(g, dt)
+        pos, box = np.asarray(g["pos"], dtype=np.float64), np.zeros(3)
+        terms = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+        kw = dict(cutoff=9.0)
+    elif case.startswith("water"):
         mol, pos, box = tip3p_box(14, seed=4)  # 8 232 atoms
         terms = ["lj", "electrostatics", "bonds", "angles"]
         par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
@@ -629,14 +637,14 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
         par = Parameters(argon_forcefield(mol), mol, terms, precision=dt)
         kw = dict(cutoff=9.0)
     gamma = None if case == "water_nve" else 1.0
-    lanes = {"water_32_lanes": "32", "water_64_lanes": "64"}.get(case, "8" if case.startswith("water") else "4")
+    lanes = {"water_32_lanes": "32", "water_64_lanes": "64", "thrombin": "64"}.get(case, "8" if case.startswith("water") else "4")
     monkeypatch.setenv("TMDHIP_LPA", lanes)  # (32 / 64: what mid-size boxes get; 8 and 16 pair blocks per step block)
     torch.manual_seed(3)
     vel0 = maxwell_boltzmann(par.masses, 300.0, nrep)
 
     def run(fused):
         monkeypatch.setenv("TMDHIP_FUSED_STEP", "1" if fused else "0")
-        s = System(mol.numAtoms, nrep, dt, dev)
+        s = System(pos.shape[0], nrep, dt, dev)
         s.set_positions(np.repeat(pos[:, :, None], nrep, axis=2))
         s.set_box(box)
         s.set_velocities(vel0)

@@ -97,11 +97,17 @@ __global__ __launch_bounds__(256) void bonded_atom_kernel(int natoms, BondedArgs
   double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};
   eval_atom_quad<R>(A, pos, a, sub, a < natoms, fx, fy, fz, e);
   if (a < natoms && sub == 0 && forces) {
-    forces[3 * a + 0] += fx;
-    forces[3 * a + 1] += fy;
-    forces[3 * a + 2] += fz;
+    if (want_e & 2) {  // TMDHIP_OVERWRITE_FORCES: the bonded force alone (tmdhip_md_run hands it to the pair launch's step blocks)
+      forces[3 * a + 0] = fx;
+      forces[3 * a + 1] = fy;
+      forces[3 * a + 2] = fz;
+    } else {
+      forces[3 * a + 0] += fx;
+      forces[3 * a + 1] += fy;
+      forces[3 * a + 2] += fz;
+    }
   }
-  if (want_e) flush_energies(e, energies);
+  if (want_e & 1) flush_energies(e, energies);
 }
 
 // (2) heavy topologies (proteins: an atom sits in dozens of torsions; one thread walking them is a chain
@@ -124,11 +130,17 @@ __global__ __launch_bounds__(256) void bonded_wave_kernel(int natoms, BondedArgs
   fy = wave_sum(fy);
   fz = wave_sum(fz);
   if (lane == 0 && a < natoms && forces) {
-    forces[3 * a + 0] += fx;
-    forces[3 * a + 1] += fy;
-    forces[3 * a + 2] += fz;
+    if (want_e & 2) {
+      forces[3 * a + 0] = fx;
+      forces[3 * a + 1] = fy;
+      forces[3 * a + 2] = fz;
+    } else {
+      forces[3 * a + 0] += fx;
+      forces[3 * a + 1] += fy;
+      forces[3 * a + 2] += fz;
+    }
   }
-  if (want_e) flush_energies(e, energies);
+  if (want_e & 1) flush_energies(e, energies);
 }
 
 template <typename R>
@@ -322,7 +334,7 @@ int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box,
   BondedArgs<R> A;
   fill_args<R>(ctx, b, box, A);
   R *forces = (flags & TMDHIP_WANT_FORCES) ? (R *)forces_v : nullptr;
-  const int we = (flags & TMDHIP_WANT_ENERGY) ? 1 : 0;
+  const int we = ((flags & TMDHIP_WANT_ENERGY) ? 1 : 0) | ((flags & TMDHIP_OVERWRITE_FORCES) ? 2 : 0);  // kernel mode bits
   const int n = b->natoms;
   if (b->max_entries_per_atom <= kAtomCentricLimit) {
     hipLaunchKernelGGL((bonded_atom_kernel<R>), dim3((kQuad * n + 255) / 256, nrep), dim3(256), 0, st, n, A,
@@ -332,7 +344,7 @@ int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box,
                        forces, ctx_energy_scratch(ctx), we, boxes);
   }
   TMD_HIP(hipGetLastError());
-  if (we) TMD_TRY(fold_energies(ctx, en, st, nrep));
+  if (we & 1) TMD_TRY(fold_energies(ctx, en, st, nrep));
   return 0;
 }
 

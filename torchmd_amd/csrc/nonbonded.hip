@@ -1156,7 +1156,7 @@ struct FusedStep {   // what does (kernel argument)
   float4 *sorted_out;   // their cell-sorted records
   float4 *fsort;        // {pair force, launch number} per atom, cell-sorted order (pair blocks write, step blocks watch)
   unsigned gen;         // number of this launch (never 0)
-  int bonded;           // the atoms have bonded records (FusedStatic::has_bonded)
+  int bonded;           // FusedStatic::has_bonded (0 none, 1 inline records, 2 from FusedStatic::fbond)
   int nstep_blocks;     // step blocks at the end of the grid (a multiple of 8, like the pair blocks)
   uint64_t noise_step;
   unsigned *near_host;  // chain skipping: report words of the NEXT step's displacement test (null: none)
@@ -1985,7 +1985,10 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
 struct FusedStatic {
   MdStepArgs<float> s;  // per-launch fields (pos_in/out, sorted, noise_step, chk.near_host/seq/parity) come from FusedStep
   BondedArgs<float> A;
-  int has_bonded;  // light topology: the atoms' bonded records are evaluated here (md_step_bonded_kernel's job)
+  int has_bonded;  // 1: light topology, the atoms' bonded records are evaluated here (md_step_bonded_kernel's job);
+                   // 2: heavy topology, the bonded force of this launch's positions is in `fbond` (bonded_wave_kernel
+                   // ran in front of the launch: it depends on the positions only)
+  const float *fbond;  // [3N], original atom order
 };
 
 // Step block j of a FUSED pair launch (four waves, 64 atoms): the atoms of the 64 / APB pair blocks that run on the
@@ -2001,7 +2004,7 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
   const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   // With bonded records a step block is 64 atoms (its four waves share their records); without, every wave is a unit
   // of 64 atoms of its own (four waves of which three only met at the barrier doubled the waves of a 10^6-atom LJ launch).
-  const bool bonded = fs.bonded != 0;  // (launch-uniform)
+  const bool bonded = fs.bonded == 1;  // (launch-uniform; 2 = the bonded force comes from a buffer: waves are units too)
   const int xcd = j & 7, q = bonded ? (j >> 3) : (j >> 3) * kQuad + w, g8 = npair >> 3;
   const int kc = K * q + lane / APB;  // this lane's pair block within the XCD's eighth
   const int a = (xcd * g8 + kc) * APB + lane % APB;
@@ -2056,6 +2059,11 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
 #pragma unroll
     for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
   } else {
+    if (fs.bonded == 2 && integrates) {
+      const float *fbond = fst->fbond;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fb[k] = fbond[3 * o + k];
+    }
     if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
   }
   // Wait for this atom's force record of THIS launch (.w = launch number; a 16-byte access is one request at the L2).
@@ -2077,7 +2085,7 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
   }
   if (!integrates) return;
   x.f[0] = __uint_as_float(f.x), x.f[1] = __uint_as_float(f.y), x.f[2] = __uint_as_float(f.z);
-  md_step_atom<float, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, bonded, LANGEVIN ? g : nullptr);
+  md_step_atom<float, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, fs.bonded != 0, LANGEVIN ? g : nullptr);
 }
 
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
@@ -2268,13 +2276,14 @@ struct Replica {
   FusedStatic fused_host;
   bool fused_host_valid = false;
   DevBuf fsort;            // {pair force, launch number} per atom in cell-sorted order (fused launches)
+  DevBuf fbond;            // bonded force of a fused launch's positions (heavy topologies), original atom order
   unsigned fused_gen = 0;  // number of the last fused launch
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf extent;  // int[6]: keys of the coordinate extent of sorted_xyzq (extent_note)
   DevBuf paircount;  // unsigned long long
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
-                      &nlist, &nneigh, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort})
+                      &nlist, &nneigh, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond})
       b->release();
   }
 };
@@ -2621,7 +2630,7 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
         fstep = fl->step;
         const int k = rp.lg.lpa * 64 / TMD_FAST_THREADS, g8 = npair8 / 8;
         const int units = (g8 + k - 1) / k;  // 64-atom units per XCD's eighth: a block with bonded records, a wave without
-        fstep.nstep_blocks = 8 * (fstep.bonded ? units : (units + 3) / 4);
+        fstep.nstep_blocks = 8 * (fstep.bonded == 1 ? units : (units + 3) / 4);
         if (rp.fsort.bytes < sizeof(R4) * (size_t)n) {
           TMD_TRY(rp.fsort.ensure(sizeof(R4) * (size_t)n));
           TMD_HIP(hipMemsetAsync(rp.fsort.p, 0, rp.fsort.bytes, st));  // launch number 0 = never written
@@ -3263,8 +3272,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         // Every fused step moves the positions to the other buffer; with an odd number of them ahead (all interior
         // steps of the call, if the first one can be fused) the drift of this first step goes to the second buffer,
         // so that the call ends in the caller's tensor without a copy.
-        if (check && list && cur[r] == home && d->niter >= 2 && ((d->niter - 1) & 1) && fused_step_possible<R>(ctx, rp, c) &&
-            tmd::bonded_inline_args(ctx, box, A) != 2) {
+        if (check && list && cur[r] == home && d->niter >= 2 && ((d->niter - 1) & 1) && fused_step_possible<R>(ctx, rp, c)) {
           TMD_TRY(rp.pos_alt.ensure(sizeof(R) * stride));
           a.pos_out = rp.pos_alt.as<R>();
           cur[r] = a.pos_out;
@@ -3292,8 +3300,16 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
           bool fuse = false;
           if constexpr (std::is_same<R, float>::value) {
             const int bm = (check && it + 1 < d->niter && !en && fused_step_possible<R>(ctx, rp, c))
-                               ? tmd::bonded_inline_args(ctx, box, A) : 2;
-            if (bm != 2) {
+                               ? tmd::bonded_inline_args(ctx, box, A) : -1;
+            if (bm >= 0) {
+              if (bm == 2) {
+                // heavy topology: the bonded force depends on the positions only — it is evaluated in front of the
+                // pair launch into a buffer of its own and the step blocks add it (same values, same order as the
+                // separate kernels: pair force stored, bonded force added, divided by the mass)
+                TMD_TRY(rp.fbond.ensure(sizeof(R) * stride));
+                TMD_TRY(tmdhip_compute_bonded(ctx, r, pos, box, rp.fbond.p, nullptr,
+                                              TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES, st));
+              }
               FusedStatic now;
               std::memset(&now, 0, sizeof(now));
               now.s.n = n;
@@ -3314,7 +3330,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               now.s.chk.near_frac2 = (R)(chain_near * chain_near);
               now.s.chk.ext = a.chk.ext;
               if (bm == 1) std::memcpy(&now.A, &A, sizeof(A));
-              now.has_bonded = bm == 1;
+              now.has_bonded = bm;
+              now.fbond = bm == 2 ? rp.fbond.as<float>() : nullptr;
               TMD_TRY(rp.fused_dev.ensure(sizeof(FusedStatic)));
               TMD_TRY(rp.pos_alt.ensure(sizeof(R) * stride));
               if (!rp.fused_host_valid || std::memcmp(&rp.fused_host, &now, sizeof(now)) != 0) {
@@ -3328,7 +3345,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               fl.step.pos_out = pos == home ? rp.pos_alt.as<R>() : home;
               fl.step.sorted_out = rp.sorted_alt.as<R4>();
               fl.step.noise_step = d->step0 + (uint64_t)it;
-              fl.step.bonded = bm == 1;
+              fl.step.bonded = bm;
               if (pace) {  // the next iteration's sequence number (see the pacing above)
                 unsigned nseq = rp.seq + 1;
                 if (nseq == 0) nseq = 1;
