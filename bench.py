@@ -159,12 +159,14 @@ def run_c5(args, rank, world, local_rank, device, launched):
         pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
         achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
         c5_traffic, c5_traffic_src = None, None
-        try:  # HBM bytes per launch from the committed PMC pass of this configuration (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r03_c5_pmc_traffic.json")) as fh:
-                c5_traffic = float(json.load(fh)["hbm_bytes_per_launch"])
-                c5_traffic_src = "profiles/r03_c5_pmc_traffic.json"
-        except Exception:
-            pass
+        for name in ("r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json"):  # newest committed PMC pass of this configuration
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    c5_traffic = float(json.load(fh)["hbm_bytes_per_launch"])
+                    c5_traffic_src = "profiles/" + name
+                break
+            except Exception:
+                continue
         extra["roofline"] = {
             "kernel": "list_pair_fast_f32_kernel (fp32, LJ)" + (" with the MD step in the same launch (step blocks)" if fused else ""),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
