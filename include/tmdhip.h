@@ -346,6 +346,13 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *comm, const tmdhip_dd_desc *desc
 /* Forget the pending displacement read-back (call after every migration). */
 int tmdhip_dd_reset(tmdhip_comm *comm);
 
+/* ---- debug aid (not needed by any caller of the path) ----
+ * With TMDHIP_DEBUG_TIMELINE=1 in the environment every block of the list build records {entry cycle, exit cycle,
+ * hardware id, longest list | candidates x atoms << 32} (4 x uint64 per block); this copies the last build's records
+ * to `out_host` (at most max_bytes) and returns the number of blocks (0: nothing recorded, < 0: error).
+ * tools/build_timeline.py. */
+int tmdhip_debug_build_timeline(void *out_host, size_t max_bytes);
+
 #ifdef __cplusplus
 }
 #endif

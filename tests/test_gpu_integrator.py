@@ -600,7 +600,7 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
                                   "water_32_lanes", "water_64_lanes", "thrombin"])
 def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     """Interior steps of tmdhip_md_run on the lean fp32 pair kernel are made by the pair launch itself ("step blocks"
-    behind the pair blocks wait for the pair waves of their atoms: FusedStep in nonbonded.hip) instead of by an
+    behind the pair blocks wait for the pair waves of their atoms: FusedStep in csrc/engine.h, pair_fast_f32.hip) instead of by an
     integrator launch.  Same device functions in the same order: positions, velocities, forces and energies equal
     those of the separate kernels (TMDHIP_FUSED_STEP=0) bit for bit — with velocity-dependent skins, rebuilds inside
     the window and chain skipping active (size gate opened).  Water = 8 lanes per atom (two pair blocks per step

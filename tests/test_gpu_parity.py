@@ -264,7 +264,7 @@ def test_image_offsets_vs_oracle(case, reach):
     shifted by its own integer box vector in [-reach, reach]^3, so `round(d/box)` of forces.py:360-365 takes
     values up to 2*reach + 1.  The lean kernels fuse `d - box*k` while k*box is exact (|k| <= 2: coordinate extent
     below 2.4 box edges, case reach = 1 with images {0, 1}) and round the product separately beyond (reach = 3);
-    see extent_note in csrc/nonbonded.hip.  Bar: in-cutoff pair count == the oracle's at the SAME shifted tensors
+    see extent_note in csrc/engine.h.  Bar: in-cutoff pair count == the oracle's at the SAME shifted tensors
     (generic kernel), forces within the parity bound (lean kernel: one flipped pair is 0.05 kcal/mol/A with
     reaction field, 25x the fp32 bound)."""
     from oracle import torchmd_oracle as orc

@@ -20,8 +20,8 @@ forces.compute(system.pos, system.box, system.forces)
 Integrator(system, forces, 1.0, dev, gamma=10.0, T=300.0).step(600)
 Integrator(system, forces, 1.0, dev, gamma=0.1, T=300.0).step(100)  # ends with device-side rebuilds in the MD loop
 lib = L.load()
-lib.tmdhip_debug_build_timeline.restype = C.c_int
-lib.tmdhip_debug_build_timeline.argtypes = [C.c_void_p, C.c_size_t]
+
+
 buf = np.zeros(4 * 20000, dtype=np.uint64)
 nb = lib.tmdhip_debug_build_timeline(buf.ctypes.data, buf.nbytes)
 print("blocks", nb)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Instruction histogram of the loops of one kernel in a gfx950 assembly listing.
 
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only torchmd_amd/csrc/nonbonded.hip -o /tmp/nb.s
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only -fno-slp-vectorize torchmd_amd/csrc/pair_fast_f32.hip -o /tmp/nb.s
     python tools/isa_stats.py /tmp/nb.s 'list_pair_fast_f32_kernelILi8ELb1ELb1ELb0ELb0E' [--dump N]
 
 Prints registers/occupancy from the kernel's metadata comment block and, for every backward branch (loop),

@@ -239,6 +239,7 @@ SIGNATURES = {
     ),
     "tmdhip_dd_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(DdDesc), C.POINTER(C.c_int32), C.c_void_p]),
     "tmdhip_dd_reset": (C.c_int, [C.c_void_p]),
+    "tmdhip_debug_build_timeline": (C.c_int, [C.c_void_p, C.c_size_t]),
 }
 
 _lib = None

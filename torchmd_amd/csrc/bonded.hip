@@ -166,7 +166,7 @@ int upload_terms(const int32_t *term_of, const void *prm, int nterms, int ntors,
 }  // namespace
 
 namespace tmd {
-// accessors implemented in nonbonded.hip (the ctx layout is private to that file)
+// accessors implemented in context.hip (the ctx layout is private to the nonbonded engine, engine.h)
 void *&ctx_bonded_slot(tmdhip_ctx *ctx);
 const tmdhip_nonbonded_desc &ctx_desc(const tmdhip_ctx *ctx);
 const void *ctx_scaled_charges(const tmdhip_ctx *ctx);
@@ -351,7 +351,7 @@ int run_bonded(tmdhip_ctx *ctx, Bonded *b, const void *pos_v, const double *box,
 }  // namespace
 
 namespace tmd {
-// Arguments for evaluating the bonded force of an atom inline in the MD-step kernel (nonbonded.hip).
+// Arguments for evaluating the bonded force of an atom inline in the MD-step kernels (md_loop.hip, pair_fast_f32.hip).
 // 0: no bonded terms; 1: light topology (thread per atom, per-atom records); 2: heavy (wave per atom).
 int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A) {
   const Bonded *b = (const Bonded *)ctx_bonded_slot(ctx);

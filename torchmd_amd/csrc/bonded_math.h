@@ -1,5 +1,5 @@
 // Device arithmetic of the bonded terms (forces.py:122-258, 494-605), shared by the bonded kernels
-// (bonded.hip) and by the MD-step kernel of nonbonded.hip, which evaluates an atom's bonded force inline
+// (bonded.hip) and by the MD-step kernels of md_loop.hip / pair_fast_f32.hip, which evaluates an atom's bonded force inline
 // for light topologies.  Everything here is per-translation-unit (anonymous namespace, forceinline).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,0 +1,666 @@
+// K1 + K2 of the nonbonded engine for gfx950 (MI355X): cell binning and the Verlet-list build.
+//
+// The reference has no counterpart that runs (torchmd/neighbourlist.py:4-47 is dead code; its 27-neighbour periodic
+// convention is what the stencil below generalises): the pair set of torchmd/forces.py:348-357 (all i<j minus
+// exclusions) filtered by forces.py:76-81 is produced here by an O(N) cell list + a Verlet list with a skin.  Every
+// kernel of the chain starts with `if (!*flag) return`: the rebuild decision is taken on the device by the
+// displacement test (engine.h: ListCheck) and needs no host round trip.
+#include "engine.h"
+
+namespace tmd {
+
+template <typename R>
+__global__ void check_displacement_kernel(int n, const R *__restrict__ pos, ListCheck<R> k, PairConsts<R> c, int force,
+                                          const int *__restrict__ inv, const R *__restrict__ qs,
+                                          typename Vec<R>::T4 *__restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    list_check_clear(k.flags, k.parity);
+    if (force) k.flags[F_REBUILD0 + k.parity] = 1;
+  }
+  if (i >= n || force) return;  // (forced: place_sorted_kernel writes the records and notes the extent)
+  const R x = pos[3 * i + 0], y = pos[3 * i + 1], z = pos[3 * i + 2];
+  list_check_atom<R>(k, c, i, x, y, z);
+  extent_note<R>(k.ext, x, y, z);
+  // callers of a plain evaluation hand in arbitrary new positions: refresh the cell-sorted copy the pair kernel
+  // reads in the same pass (on a rebuild place_sorted_kernel rewrites it in the new order; the MD loop's
+  // integrator kernel keeps the copy current itself)
+  typename Vec<R>::T4 rec;  // one full 16/32-byte store (partial writes of a record are slower)
+  rec.x = x;
+  rec.y = y;
+  rec.z = z;
+  rec.w = qs[i];
+  sorted[inv[i]] = rec;
+}
+
+template <typename R>
+__global__ void bin_count_kernel(int n, const R *__restrict__ pos, Grid g, int *__restrict__ cell_of,
+                                 int *__restrict__ slot, int *__restrict__ count, const int *flag) {
+  if (*flag == 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cx = cell_coord(pos[3 * i + 0], g, 0);
+  const int cy = cell_coord(pos[3 * i + 1], g, 1);
+  const int cz = cell_coord(pos[3 * i + 2], g, 2);
+  const int cidx = (cx * g.nc[1] + cy) * g.nc[2] + cz;
+  cell_of[i] = cidx;
+  slot[i] = atomicAdd(&count[cidx], 1);
+}
+
+// single block of 1024 threads; cell_start[ncell] = n afterwards; counts are zeroed for the next rebuild
+__global__ __launch_bounds__(1024) void scan_cells_kernel(int ncell, int *__restrict__ count,
+                                                          int *__restrict__ cell_start, const int *flag) {
+  if (*flag == 0) return;
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ncell; base += 1024) {
+    const int idx = base + t;
+    const int v = idx < ncell ? count[idx] : 0;
+    int inc = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int woff = carry;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    if (idx < ncell) {
+      cell_start[idx] = woff + inc - v;
+      count[idx] = 0;
+    }
+    __syncthreads();
+    if (t == 1023) carry = woff + inc;
+    __syncthreads();
+  }
+  if (t == 0) cell_start[ncell] = carry;
+}
+
+__global__ void fill_cells_kernel(int n, const int *__restrict__ cell_of, const int *__restrict__ slot,
+                                  const int *__restrict__ cell_start, int *__restrict__ order_tmp,
+                                  const int *flag) {
+  if (*flag == 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  order_tmp[cell_start[cell_of[i]] + slot[i]] = i;
+}
+
+// atom at position `a` of the unsorted cell order -> its final slot (rank by original index inside the cell) and every
+// per-slot copy the pair kernels read
+template <typename R>
+__device__ __forceinline__ void place_atom(const PlaceArgs<R> &P, int a) {
+  const int me = P.order_tmp[a];
+  const int cidx = P.cell_of[me];
+  const int s = P.cell_start[cidx], e = P.cell_start[cidx + 1];
+  int rank = 0;
+  for (int k = s; k < e; ++k) rank += P.order_tmp[k] < me;
+  const int dst = s + rank;
+  P.order[dst] = me;
+  P.inv[me] = dst;
+  typename Vec<R>::T4 v;
+  v.x = P.pos[3 * me + 0];
+  v.y = P.pos[3 * me + 1];
+  v.z = P.pos[3 * me + 2];
+  v.w = P.qs[me];
+  P.sorted[dst] = v;
+  extent_note<R>(P.ext, v.x, v.y, v.z);
+  P.stype[dst] = P.types[me];
+  if (P.half_skin) {
+    // this list's half skin of the atom: its static share, or — inside an MD run, where the velocity is known —
+    // a reduced floor plus the distance it covers in `vs_time` at its present speed, capped at vs_cap times the
+    // largest static share (the cells are sized for that).  Any choice is safe: the displacement test uses the
+    // same number (hs2_dyn); a good choice lets fast atoms go further before they force a rebuild while slow
+    // ones keep short lists.
+    R h = P.half_skin[me];
+    if (P.vel) {
+      const R vx = P.vel[3 * me + 0], vy = P.vel[3 * me + 1], vz = P.vel[3 * me + 2];
+      h = min(P.vs_floor * h + P.vs_time * sqrt(vx * vx + vy * vy + vz * vz), P.vs_cap);
+    }
+    P.sorted_hs[dst] = h;
+    if (P.hs2_dyn) P.hs2_dyn[me] = h * h;
+  }
+  P.ref[3 * me + 0] = v.x;
+  P.ref[3 * me + 1] = v.y;
+  P.ref[3 * me + 2] = v.z;
+}
+
+template <typename R>
+__global__ void place_sorted_kernel(int n, PlaceArgs<R> P, const int *flag) {
+  if (*flag == 0) return;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  place_atom<R>(P, a);
+}
+
+// Binning of a small system in ONE launch of one block: count (LDS atomics), scan, fill and place — the work of
+// bin_count / scan_cells / fill_cells / place_sorted.  On the ~10 of 11 steps without a rebuild the chain then costs
+// two early-exit launches instead of five (~1.7 us each).  A rebuild on one CU is slower than the four parallel
+// launches, which sets the size limit — measured, water boxes, us per MD step without / with: 5 184 atoms 27.2 / 23.8,
+// 12 288 atoms 34.6 / 36.1, 41 472 atoms 41.8 / 67.1.
+constexpr int kPrepSmallMaxCells = 4096;
+constexpr int kPrepSmallMaxAtoms = 8192;
+template <typename R>
+__global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__restrict__ pos, Grid g, int ncell,
+                                                          int *__restrict__ cell_of, int *__restrict__ slot,
+                                                          int *__restrict__ cell_start, int *__restrict__ order_tmp,
+                                                          PlaceArgs<R> P, const int *flag) {
+  if (*flag == 0) return;
+  __shared__ int s_count[kPrepSmallMaxCells];
+  __shared__ int s_start[kPrepSmallMaxCells + 1];
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int c = t; c < ncell; c += 1024) s_count[c] = 0;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) {
+    const int cx = cell_coord(pos[3 * i + 0], g, 0);
+    const int cy = cell_coord(pos[3 * i + 1], g, 1);
+    const int cz = cell_coord(pos[3 * i + 2], g, 2);
+    const int cidx = (cx * g.nc[1] + cy) * g.nc[2] + cz;
+    cell_of[i] = cidx;
+    slot[i] = atomicAdd(&s_count[cidx], 1);
+  }
+  __syncthreads();
+  // exclusive scan: thread t owns cells 4t .. 4t+3
+  int v[4], mine = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * t + k;
+    v[k] = c < ncell ? s_count[c] : 0;
+    mine += v[k];
+  }
+  int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int run = inc - mine;
+  for (int k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 4 * t + k;
+    if (c < ncell) {
+      s_start[c] = run;
+      cell_start[c] = run;
+    }
+    run += v[k];
+  }
+  if (t == 0) {
+    s_start[ncell] = n;
+    cell_start[ncell] = n;
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) order_tmp[s_start[cell_of[i]] + slot[i]] = i;
+  __threadfence_block();
+  __syncthreads();  // order_tmp and cell_start are complete for the whole block
+  for (int a = t; a < n; a += 1024) place_atom<R>(P, a);
+}
+
+// ---- K2: Verlet list build ---------------------------------------------------------------------
+// One wave per cell.  The candidates (all atoms of the (2m+1)^3 stencil cells, which are contiguous
+// runs of the cell-sorted arrays) are streamed through the 64 lanes with coalesced loads; for every
+// chunk of 64 candidates the wave loops over the atoms i of its cell (wave-uniform data), tests
+// |d|^2 <= rlist^2 and the exclusions, and appends the hits of atom i with a ballot / prefix-popcount
+// compaction.  Entry order per atom is fixed by the stencil order -> lists are bit-reproducible.
+// WSKIN: per-atom skins — pair (i, j) is listed when |d| <= cutoff + s_i + s_j (s = the atom's half skin: the
+// displacement it may reach before a rebuild, see ListCheck), instead of cutoff + skin for every pair.
+template <typename R, bool LOOP, bool WSKIN>
+__global__ __launch_bounds__(64) void build_list_kernel(
+    int n, const typename Vec<R>::T4 *__restrict__ sorted, const R *__restrict__ sorted_hs,
+    const int *__restrict__ stype,
+    const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
+    const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
+    unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
+    int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split) {
+  if (*flag == 0) return;
+  const unsigned long long dbg_t0 = dbg ? __builtin_readcyclecounter() : 0ull;  // TMDHIP_DEBUG_TIMELINE (tools/build_timeline.py)
+  using R4 = typename Vec<R>::T4;
+  // the whole list as a bounds-checked buffer (< 2^30 entries): an out-of-range store is dropped
+  const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      nlist, 0, (int)((((size_t)n + lg.apw - 1) / lg.apw) * (size_t)lg.maxn * lg.apw * 4u), 0x00020000);
+  __shared__ int seg_start[128];
+  __shared__ int seg_prefix[129];
+  __shared__ int seg_code[128];  // periodic image of the stencil cell: 2 bits per axis, 0:-L 1:0 2:+L
+  const int lane = threadIdx.x;
+  int wmax = 0;
+  unsigned long long dbg_work = 0;  // candidates x atoms over the block's cells (debug timeline only)
+  // LOOP: the grid is capped and a block walks several cells (a launch that returns at once on the steps
+  // without a rebuild still costs time proportional to its block count: the 343k cells of the 10^6-atom
+  // LJ box = 100 us per step).  Systems with fewer cells keep one cell per block (no loop: faster code).
+  // split > 1 (few cells: the one-wave-per-cell grid would leave most SIMDs idle — 729 cells on 1 024 SIMDs at 12 288
+  // atoms, 109 us per build): `split` blocks share a cell, each builds the lists of its share of the cell's atoms
+  // from the same candidates (never together with LOOP)
+  int cell = LOOP ? (int)blockIdx.x : (int)blockIdx.x / split;
+  const int part = LOOP ? 0 : (int)blockIdx.x % split;
+  do {
+  int cs = cell_start[cell], ce = cell_start[cell + 1];
+  if (cell == 0 && part == 0 && lane == 0) status[1] += 1;  // flags[F_NREBUILD]
+  if (!LOOP && split > 1) {  // this block's atoms of the cell (multiples of 4: whole batches)
+    const int per = ((ce - cs + split - 1) / split + 3) & ~3;
+    cs = min(cs + part * per, ce);
+    ce = min(cs + per, ce);
+  }
+  if (cs == ce) continue;
+  __syncthreads();  // LDS tables of the previous cell are no longer read
+  const int cz = cell % g.nc[2], cy = (cell / g.nc[2]) % g.nc[1], cx = cell / (g.nc[2] * g.nc[1]);
+  // stencil segments: a segment is a run of cells along z (contiguous in the cell-sorted arrays) of one
+  // (x, y) stencil row, clipped to the cells that can hold an atom within rlist of this cell
+  // (g.zreach) and split where it crosses the periodic boundary: <= 2 pieces per row, <= 98 segments.
+  // Lane handles segments `lane` and `lane + 64` (segment = 2 * row + piece).
+  const int w = 2 * g.m + 1, nrows = w * w;  // <= 49
+  int cnt2[2], st2[2], code2[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int sidx = lane + 64 * h;
+    const int row = sidx >> 1, piece = sidx & 1;
+    int count = 0, start = 0, code = 1 | (1 << 2) | (1 << 4);
+    if (row < nrows) {
+      const int ox = row / w - g.m, oy = row % w - g.m;
+      const int zr = g.zreach[ox + g.m][oy + g.m];  // -1: no cell of this row is in reach
+      int x = cx + ox, y = cy + oy;
+      bool ok = zr >= 0;
+      int codexy = 1 | (1 << 2);
+      if (g.periodic) {
+        codexy = (x < 0 ? 0 : (x >= g.nc[0] ? 2 : 1)) | ((y < 0 ? 0 : (y >= g.nc[1] ? 2 : 1)) << 2);
+        x = (x + g.nc[0]) % g.nc[0];
+        y = (y + g.nc[1]) % g.nc[1];
+      } else {
+        ok = ok && x >= 0 && x < g.nc[0] && y >= 0 && y < g.nc[1];
+      }
+      if (ok) {
+        const int zlo = cz - zr, zhi = cz + zr, nz = g.nc[2];
+        // piece 0: the part inside [0, nz); piece 1: the part that wraps (below 0 or beyond nz-1)
+        int a = max(zlo, 0), b = min(zhi, nz - 1), zc = 1;
+        if (piece == 1) {
+          if (!g.periodic) {
+            a = 1, b = 0;
+          } else if (zlo < 0) {
+            a = zlo + nz, b = nz - 1, zc = 0;
+          } else if (zhi >= nz) {
+            a = 0, b = zhi - nz, zc = 2;
+          } else {
+            a = 1, b = 0;
+          }
+        }
+        if (a <= b) {
+          const int base = (x * g.nc[1] + y) * nz;
+          start = cell_start[base + a];
+          count = cell_start[base + b + 1] - start;
+          code = codexy | (zc << 4);
+        }
+      }
+    }
+    cnt2[h] = count;
+    st2[h] = start;
+    code2[h] = code;
+  }
+  // exclusive prefix over the 128 slots
+  int inc0 = cnt2[0], inc1 = cnt2[1];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t0 = __shfl_up(inc0, o, 64), t1 = __shfl_up(inc1, o, 64);
+    if (lane >= o) {
+      inc0 += t0;
+      inc1 += t1;
+    }
+  }
+  const int tot0 = __shfl(inc0, 63, 64);
+  const int ncand = tot0 + __shfl(inc1, 63, 64);
+  seg_start[lane] = st2[0];
+  seg_start[lane + 64] = st2[1];
+  seg_code[lane] = code2[0];
+  seg_code[lane + 64] = code2[1];
+  seg_prefix[lane] = inc0 - cnt2[0];
+  seg_prefix[lane + 64] = tot0 + inc1 - cnt2[1];
+  if (lane == 0) seg_prefix[128] = ncand;
+  if (dbg) dbg_work += (unsigned long long)ncand * (unsigned long long)(ce - cs);
+  __syncthreads();
+
+  // per-atom data of the i block staged in LDS as two 16-byte records that the inner loop reads with
+  // wave-uniform (broadcast) LDS loads: rec0 = {wrapped xyz, cutoff + own half skin (WSKIN)},
+  // rec1 = {own original index, first two excluded partners, word offset of the atom's list row} (so
+  // "j == i" is just one more exclusion; longer exclusion rows spill to global reads).  PMC showed this loop limited by the
+  // scalar unit (one SALU per CU, shared by the 4 SIMDs) as much as by VALU, hence: LDS addresses and
+  // the row offset live in VGPRs, the per-atom hit counters move with readlane/writelane, and the
+  // rare long-exclusion path is hoisted out as a separate loop version.
+  constexpr int EXS = 3;
+  __shared__ R4 s_rec0[64];
+  __shared__ int4 s_rec1[64];
+  __shared__ int s_eb[64], s_more[64];
+  __shared__ unsigned s_bm[64];
+  __shared__ __align__(16) int s_cnt[64];
+  const int apw_shift = 6 - lg.lpa_shift;
+  const unsigned kmask = (unsigned)lg.lpa - 1u;
+  // entry k of a row sits at byte ((k / (4 LPA)) << 10) + ((k % LPA) << 4) + (((k / LPA) % 4) << 2)  (list_slot); the
+  // masks live in VGPRs (an SGPR operand halves the VALU rate)
+  unsigned vmask_hi, vmask_lo;
+  asm("v_mov_b32 %0, %1" : "=v"(vmask_hi) : "s"(~((4u << lg.lpa_shift) - 1u)));
+  asm("v_mov_b32 %0, %1" : "=v"(vmask_lo) : "s"(kmask));
+  unsigned vmaxn1;
+  asm("v_mov_b32 %0, %1" : "=v"(vmaxn1) : "s"((unsigned)lg.maxn - 1u));
+  const unsigned sh_hi = 8u - (unsigned)lg.lpa_shift;  // (k / (4 LPA)) << 10 == (k & ~(4 LPA - 1)) << (10 - 2 - lpa_shift)
+  for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
+    const int iend = min(ib + 64, ce);
+    const int ni = iend - ib;
+    __syncthreads();
+    int long_rows = 0;
+    if (lane < ni) {
+      const int a = ib + lane;
+      R4 p = sorted[a];
+      p.x = wrap_into_box(p.x, c.box[0], c.invbox[0]);
+      p.y = wrap_into_box(p.y, c.box[1], c.invbox[1]);
+      p.z = wrap_into_box(p.z, c.box[2], c.invbox[2]);
+      const unsigned rowoff = (((unsigned)(a >> apw_shift) * (unsigned)lg.maxn) << apw_shift) +
+                              ((unsigned)(a & (lg.apw - 1)) << (lg.lpa_shift + 2));
+      p.w = WSKIN ? rcut + sorted_hs[a] : R(0);
+      const int oi = order[a];
+      // passive atoms (original index >= nactive: halo images of a domain) get no list: parked out of reach
+      if (oi >= nactive) p.x = (R)-1e18;
+      const int eb = excl_off[oi], ne = excl_off[oi + 1] - eb;
+      s_rec0[lane] = p;
+      s_eb[lane] = eb + (EXS - 1);
+      s_more[lane] = max(ne - (EXS - 1), 0);
+      int4 ex;
+      ex.x = oi;
+      ex.y = 0 < ne ? excl_idx[eb + 0] : -1;
+      ex.z = 1 < ne ? excl_idx[eb + 1] : -1;
+      ex.w = (int)(rowoff * 4u);  // byte offset of the atom's list row
+      s_rec1[lane] = ex;
+      long_rows = ne > EXS - 1;
+    } else {
+      // dummy atoms that pad the last batch of four: parked out of reach (never a hit, never a store)
+      R4 p;
+      p.x = (R)-1e18;
+      p.y = p.z = p.w = R(0);
+      s_rec0[lane] = p;
+      s_rec1[lane] = make_int4(-1, -1, -1, 0);
+    }
+    const bool any_long = __ballot(long_rows) != 0ull;
+    s_bm[lane] = 0u;
+    __syncthreads();
+    s_cnt[lane] = 0;  // neighbour count of atom ib + lane (lives in LDS: one broadcast read + one
+                      // same-value write per iteration instead of cross-lane register traffic)
+    // Bitmap (2 048 bits, key = original index mod 2048) of everything some atom of this block excludes — itself and
+    // its first two excluded partners.  A candidate whose bit is clear is excluded by nobody here: the three index
+    // compares per (atom, chunk) are only made for batches that meet a flagged candidate (for water: the chunks of the
+    // own and the adjacent cells, ~15 %).
+    if (lane < ni) {
+      const int4 ex = s_rec1[lane];
+      atomicOr(&s_bm[((unsigned)ex.x & 2047u) >> 5], 1u << ((unsigned)ex.x & 31u));
+      if (ex.y >= 0) atomicOr(&s_bm[((unsigned)ex.y & 2047u) >> 5], 1u << ((unsigned)ex.y & 31u));
+      if (ex.z >= 0) atomicOr(&s_bm[((unsigned)ex.z & 2047u) >> 5], 1u << ((unsigned)ex.z & 31u));
+    }
+    __syncthreads();
+    int seg = 0;      // segment of this lane's candidate; q grows by 64 per chunk so it only moves forward
+    // candidate stream, software-pipelined: the three global loads of chunk q0 + 64 are issued before
+    // chunk q0 is processed, so their latency overlaps the i loop instead of stalling the wave at the
+    // top of every chunk (the build is latency-bound: PMC showed VALU busy 57 %)
+    R4 nx_p;
+    R nx_hs = 0;
+    int nx_j = cs, nx_code = 0, nx_order = 0, nx_type = 0;
+    bool nx_valid = false;
+    auto fetch = [&](int q0) {
+      const int q = q0 + lane;
+      nx_valid = q < ncand;
+      nx_j = cs;
+      if (nx_valid) {  // last s with seg_prefix[s] <= q
+        while (seg_prefix[seg + 1] <= q) ++seg;
+        nx_j = seg_start[seg] + (q - seg_prefix[seg]);
+      }
+      nx_code = seg_code[seg];
+      nx_p = sorted[nx_j];
+      nx_order = order[nx_j];
+      nx_type = stype[nx_j];
+      if constexpr (WSKIN) nx_hs = sorted_hs[nx_j];
+    };
+    fetch(0);
+    for (int q0 = 0; q0 < ncand; q0 += 64) {
+      R4 pj = nx_p;
+      const R sj = nx_hs;
+      const int j = nx_j, code = nx_code;
+      const bool valid = nx_valid;
+      const unsigned oj = (unsigned)nx_order;
+      const unsigned entry = ((unsigned)j << 4) | (type_in_entry ? (unsigned)nx_type << kEntryTypeShift : 0u);
+      if (q0 + 64 < ncand) fetch(q0 + 64);
+      // candidate position as the periodic image that lies next to this cell: the i loop then needs
+      // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
+      // the reference's rounding; the pair kernel's cutoff test does).  Lanes past the end of the
+      // candidate list are parked far away so that they can never hit.
+      pj.x = wrap_into_box(pj.x, c.box[0], c.invbox[0]) + (R)((code & 3) - 1) * c.box[0];
+      pj.y = wrap_into_box(pj.y, c.box[1], c.invbox[1]) + (R)(((code >> 2) & 3) - 1) * c.box[1];
+      pj.z = wrap_into_box(pj.z, c.box[2], c.invbox[2]) + (R)(((code >> 4) & 3) - 1) * c.box[2];
+      if (!valid) pj.x = (R)1e18;
+      // exclusions, compaction and store of the hits of atom t (mask = lanes whose candidate is in range)
+      auto handle = [&](int t, unsigned roff, const R4 &pi, unsigned long long mask) {
+        const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + roff);
+        const int base = s_cnt[t];
+        // wave-wide masks (SGPR pairs) instead of per-lane booleans: the compares write the masks
+        // directly, they are combined on the scalar unit, and the prefix count is two v_mbcnt
+        mask &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) |
+                  __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
+                  __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32));
+        if (any_long) {  // wave-uniform, rare (atoms with more than EXS-1 exclusions: proteins)
+          const int more = s_more[t], eb = s_eb[t];
+          for (int e = 0; e < more; ++e) mask &= ~__builtin_amdgcn_uicmp((unsigned)excl_idx[eb + e], oj, 32);
+        }
+        const unsigned k = (unsigned)base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
+          const unsigned rowoff = (unsigned)ex.w >> 2;
+          const unsigned kk = k >> lg.lpa_shift;
+          nlist[rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u)] = entry;
+        }
+        s_cnt[t] = base + (int)__popcll(mask);  // every lane writes the same value
+      };
+      auto rec0 = [&](unsigned roff) -> R4 {
+        return *reinterpret_cast<const R4 *>(reinterpret_cast<const char *>(s_rec0) + roff * (unsigned)(sizeof(R4) / 16));
+      };
+      auto in_range = [&](const R4 &pi) -> unsigned long long {
+        const R dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        if constexpr (WSKIN) {
+          const R reach = pi.w + sj;  // cutoff + s_i + s_j
+          return wave_mask_le(dx * dx + dy * dy + dz * dz, reach * reach);
+        }
+        return wave_mask_le(dx * dx + dy * dy + dz * dz, rlist2);
+      };
+      // LDS byte offset of the current i record, kept in a VGPR on purpose (see above).  Two-level test:
+      // the distance masks of four atoms are computed together (independent LDS reads and arithmetic
+      // chains), the expensive part only runs for (atom, chunk) combinations with at least one hit
+      // (a chunk is ~one z-column of the stencil, so for a given atom many chunks are out of reach).
+      unsigned recoff;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(recoff));
+      int t = 0;
+      // Batches of four atoms with ONE branch (any hit at all?) and none inside: a taken scalar branch costs more than
+      // the arithmetic it skips (the per-block timeline gives ~150 cycles per (atom, chunk) combination against ~70
+      // of VALU work).  The four hit counters travel as one 16-byte LDS word each way, and a lane without a hit
+      // stores to an out-of-range offset of a bounds-checked buffer (dropped by the hardware) instead of leaving
+      // exec.  Atoms with long exclusion rows (proteins) keep the branching path.
+      // The last batch is padded with parked dummy atoms (staged above), so there is no scalar remainder loop.
+      if (!any_long) {
+        // candidates that somebody in this block excludes (see s_bm); lanes past the end never hit anyway
+        const unsigned bmw = s_bm[(oj & 2047u) >> 5];
+        const unsigned long long special = __builtin_amdgcn_uicmp((bmw >> (oj & 31u)) & 1u, 0u, 33 /* ne */);
+        for (; t < ni; t += 4, recoff += 64u) {
+          const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
+          unsigned long long m[4] = {in_range(p0), in_range(p1), in_range(p2), in_range(p3)};
+          const unsigned long long any = m[0] | m[1] | m[2] | m[3];
+          if (!any) continue;
+          const int4 base4 = *reinterpret_cast<const int4 *>(&s_cnt[t]);
+          const int base[4] = {base4.x, base4.y, base4.z, base4.w};
+          int4 ex[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            ex[u] = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff + 16u * u);
+          if (any & special) {  // rare: a flagged candidate is in range of one of the four
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              m[u] &= ~(__builtin_amdgcn_uicmp((unsigned)ex[u].x, oj, 32 /* eq */) | __builtin_amdgcn_uicmp((unsigned)ex[u].y, oj, 32) |
+                        __builtin_amdgcn_uicmp((unsigned)ex[u].z, oj, 32));
+          }
+          int cnt[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            // slot of this lane's hit, clamped to the row's last one: a row that overflows is reported through F_MAXN
+            // and its list thrown away (the caller grows the capacity and rebuilds), so what lands there is never used
+            const unsigned k = min((unsigned)base[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u)),
+                                   vmaxn1);
+            // byte offset of entry k in the row: iteration kk = k / LPA, lane part k % LPA (list_slot's layout)
+            unsigned posb = (unsigned)ex[u].w + ((k & vmask_hi) << sh_hi);
+            posb += (k & vmask_lo) << 4;
+            posb += __builtin_amdgcn_ubfe(k, (unsigned)lg.lpa_shift, 2u) << 2;
+            // only the lanes with a hit store: exec = the hit mask for the one instruction (every lane of the block is
+            // active here); a v_cndmask on an out-of-range offset would cost a half-rate VALU slot instead
+            asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_dword %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
+                         :: "v"(entry), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
+            cnt[u] = base[u] + (int)__popcll(m[u]);
+          }
+          *reinterpret_cast<int4 *>(&s_cnt[t]) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);  // every lane writes the same values
+        }
+      }
+      for (; t + 4 <= ni; t += 4, recoff += 64u) {  // (cells with long exclusion rows: the branching path)
+        const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
+        const unsigned long long m0 = in_range(p0), m1 = in_range(p1), m2 = in_range(p2), m3 = in_range(p3);
+        if (m0) handle(t, recoff, p0, m0);
+        if (m1) handle(t + 1, recoff + 16u, p1, m1);
+        if (m2) handle(t + 2, recoff + 32u, p2, m2);
+        if (m3) handle(t + 3, recoff + 48u, p3, m3);
+      }
+      for (; t < ni; ++t, recoff += 16u) {
+        const R4 p0 = rec0(recoff);
+        const unsigned long long m0 = in_range(p0);
+        if (m0) handle(t, recoff, p0, m0);
+      }
+    }
+    __syncthreads();
+    const int mycnt = s_cnt[lane];
+    if (lane < ni) nneigh[ib + lane] = min(mycnt, lg.maxn);
+    wmax = max(wmax, lane < ni ? mycnt : 0);
+  }
+  } while (LOOP && (cell += gridDim.x) < ncell);
+  if (dbg && lane == 0) {  // per block: entry / exit cycle counters, XCC id, candidates x atoms of its (last) cell
+    unsigned long long *o = dbg + 4 * (size_t)blockIdx.x;
+    o[0] = dbg_t0;
+    o[1] = __builtin_readcyclecounter();
+    // XCC id | HW_ID (wave 0-3, SIMD 4-5, pipe 6-7, CU 8-11, SH 12, SE 13-15) << 8; longest list | work << 32
+    o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((6 << 11) | 20) |
+           ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8);
+    o[3] = (unsigned long long)wmax | (dbg_work << 32);
+  }
+  // flags[2] = largest neighbour count ever seen; > maxn means a list was truncated (overflow)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+  if (lane == 0 && wmax > 0) atomicMax(status, wmax);
+}
+
+// TMDHIP_DEBUG_TIMELINE=1: every block of the list build records its entry / exit cycle counters (4 x u64 per block),
+// read back with tmdhip_debug_build_timeline (tools/build_timeline.py).  Null otherwise: the kernel stores nothing.
+static DevBuf g_dbg_timeline;
+static size_t g_dbg_blocks = 0;
+unsigned long long *debug_timeline_buffer(int blocks) {
+  static const bool on = std::getenv("TMDHIP_DEBUG_TIMELINE") != nullptr;
+  if (!on) return nullptr;
+  if (g_dbg_timeline.ensure(sizeof(unsigned long long) * 4 * (size_t)blocks)) return nullptr;
+  g_dbg_blocks = (size_t)blocks;
+  return g_dbg_timeline.as<unsigned long long>();
+}
+
+// Enqueue: displacement check -> conditional rebuild chain -> gather.  `force` forces a rebuild.
+// `prechecked`: the fused MD-step kernel already ran the displacement test of this step.
+template <typename R>
+int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force,
+                        hipStream_t st, bool prechecked) {
+  using R4 = typename Vec<R>::T4;
+  const int n = ctx->d.natoms;
+  const int parity = (int)(rp.step & 1);
+  int *flags = rp.flags.as<int>();
+  const int *flag = flags + F_REBUILD0 + parity;
+  const int nb = (n + 255) / 256;
+  if (!prechecked)
+    hipLaunchKernelGGL((check_displacement_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, make_check<R>(ctx, rp), c,
+                       force, rp.inv.as<int>(), ctx->qs.as<R>(), rp.sorted.as<R4>());
+  PlaceArgs<R> P;
+  P.cell_of = rp.cell_of.as<int>();
+  P.cell_start = rp.cell_start.as<int>();
+  P.order_tmp = rp.order_tmp.as<int>();
+  P.pos = pos;
+  P.qs = ctx->qs.as<R>();
+  P.types = ctx->types.as<int>();
+  P.order = rp.order.as<int>();
+  P.inv = rp.inv.as<int>();
+  P.sorted = rp.sorted.as<R4>();
+  P.stype = rp.stype.as<int>();
+  P.ref = rp.ref.as<R>();
+  P.half_skin = ctx->half_skin.as<R>();
+  P.sorted_hs = rp.sorted_hs.as<R>();
+  P.vel = ctx->vskin_time > 0 ? (const R *)rp.skin_vel : nullptr;
+  P.vs_floor = (R)ctx->vskin_floor;
+  P.vs_time = (R)ctx->vskin_time;
+  P.vs_cap = (R)ctx->vskin_cap_len;
+  P.hs2_dyn = rp.hs2_dyn.as<R>();
+  P.ext = rp.extent.as<int>();
+  static const bool prep_small_on = !(std::getenv("TMDHIP_PREP_SMALL") && std::atoi(std::getenv("TMDHIP_PREP_SMALL")) == 0);
+  if (prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells) {
+    hipLaunchKernelGGL((prep_small_kernel<R>), dim3(1), dim3(1024), 0, st, n, pos, rp.grid, rp.ncell, rp.cell_of.as<int>(),
+                       rp.slot.as<int>(), rp.cell_start.as<int>(), rp.order_tmp.as<int>(), P, flag);
+  } else {
+    hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, rp.cell_of.as<int>(),
+                       rp.slot.as<int>(), rp.count.as<int>(), flag);
+    hipLaunchKernelGGL(scan_cells_kernel, dim3(1), dim3(1024), 0, st, rp.ncell, rp.count.as<int>(),
+                       rp.cell_start.as<int>(), flag);
+    hipLaunchKernelGGL(fill_cells_kernel, dim3(nb), dim3(256), 0, st, n, rp.cell_of.as<int>(), rp.slot.as<int>(),
+                       rp.cell_start.as<int>(), rp.order_tmp.as<int>(), flag);
+    hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, P, flag);
+  }
+  const R rl = (R)ctx->rlist;
+  constexpr int kMaxBuildBlocks = 16384;
+  const bool wskin = ctx->half_skin.p != nullptr;
+  // few cells: several blocks per cell (see build_list_kernel), so that ~2 000 waves are in flight
+  int split = 1;
+  if (const char *e = std::getenv("TMDHIP_BUILD_SPLIT")) split = std::max(1, std::min(std::atoi(e), 8));
+  else if (rp.ncell <= 1100) split = 2;  // measured (water boxes of 5 184 / 12 288 / 41 472 atoms = 343 / 729 / 2 197 cells, us per
+                                         // MD step at split 1, 2, 4): 29.7 27.7 (28-37) / 37.8 35.5 35.0 / 43.0 44.6 48.3
+  if (rp.ncell > kMaxBuildBlocks) split = 1;
+  auto launch_build = [&](auto kernel, int blocks) {
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st, n, rp.sorted.as<R4>(), rp.sorted_hs.as<R>(),
+                       rp.stype.as<int>(), rp.order.as<int>(), rp.cell_start.as<int>(), rp.grid, c, rl * rl,
+                       (R)ctx->d.cutoff, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, rp.nlist.as<unsigned>(),
+                       rp.nneigh.as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes,
+                       debug_timeline_buffer(blocks), split);
+  };
+  if (rp.ncell <= kMaxBuildBlocks) {
+    if (wskin) launch_build(build_list_kernel<R, false, true>, rp.ncell * split);
+    else launch_build(build_list_kernel<R, false, false>, rp.ncell * split);
+  } else {
+    if (wskin) launch_build(build_list_kernel<R, true, true>, kMaxBuildBlocks);
+    else launch_build(build_list_kernel<R, true, false>, kMaxBuildBlocks);
+  }
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+template int enqueue_list_update<float>(tmdhip_ctx *, Replica &, const float *, const PairConsts<float> &, int, hipStream_t, bool);
+template int enqueue_list_update<double>(tmdhip_ctx *, Replica &, const double *, const PairConsts<double> &, int, hipStream_t, bool);
+
+}  // namespace tmd
+
+using namespace tmd;
+
+extern "C" {
+
+// debug aid (TMDHIP_DEBUG_TIMELINE=1, tools/build_timeline.py): copies the last list build's per-block timeline, returns blocks
+int tmdhip_debug_build_timeline(void *out, size_t max_bytes) {
+  if (!g_dbg_timeline.p || !out) return 0;
+  const size_t bytes = std::min(max_bytes, sizeof(unsigned long long) * 4 * g_dbg_blocks);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(out, g_dbg_timeline.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)g_dbg_blocks;
+}
+
+}  // extern "C"

@@ -1,0 +1,556 @@
+// K3f: the lean fp32 list pair kernel of the nonbonded engine for gfx950 (MI355X) — the dominant kernel of the
+// headline configuration — and the MD step inside its launch (step blocks).
+//
+// Reference semantics: torchmd/forces.py:260-319 restricted to LJ (381-415, with or without switching) and/or
+// electrostatics (453-491, plain Coulomb or reaction field); the step blocks: torchmd/integrator.py:61-74.
+#include "engine.h"
+#include "md_step.h"
+
+namespace tmd {
+
+// ---- K3f: lean fp32 specialisation of the list pair kernel ---------------------------------------
+// Issue-rate measurements on gfx950 (tools/ubench/valu_rates.hip, 8 waves per SIMD): a plain fp32 / integer
+// VALU op (v_fma_f32, v_mul, v_add, v_and, v_mov, v_cndmask) retires in ~2.3 cycles per wave, a PACKED op
+// (v_pk_fma/mul/add_f32) in ~4.3 — packing two entries into one instruction buys no ALU throughput on this
+// chip — 32-bit shifts and v_mul_u32_u24 run at half rate (4.2), v_cmp costs 5.3, v_rsq/v_rcp 8.2.  The first
+// version of this kernel evaluated entries two at a time on float2 vectors: 60 packed ops + 47 v_mov
+// (transposes of {pj[u].x, pj[u+1].x} into register pairs) per 4 entries = ~155 cycles per entry.  This
+// version is plain scalar code on the natural float4 record: ~32 full-rate ops + 1 v_cmp + 1 v_rsq per
+// entry (~85 cycles), no transposes, no shifts:
+//   entry = type << 27 | j << 4      -> gather offset = entry & 0x07FFFFF0 (one v_and), LDS table address
+//                                       = (type_i << 8) | entry >> 24 (one SDWA v_or; table rows of 32 x 8 B)
+//   minimum image by the magic-number trick (3 ops per component, bit-exact, see min_image_magic)
+//   force scale factored as  rinv2 * ((a12 rinv6 + b6) rinv6 - qq rinv) + qq 2 krf   (9 ops)
+// Same decision arithmetic (bit-exact) as pair_math.h.  Terms: LJ and/or electrostatics (plain Coulomb or
+// reaction field), optionally the LJ switching function (SWITCH) and the per-term energies (ENERGY);
+// repulsion terms, fp64, more than 32 LJ classes and pair counting take list_pair_kernel.
+
+// What the loop below is shaped by (gfx950, tools/ubench/valu_detail.hip + body_bisect.hip, 6 waves per SIMD; cycles
+// per wave-instruction per SIMD at 2.4 GHz):
+//   plain fp32 / integer VALU with VGPR, inline-constant or 32-bit-literal operands     2.1 - 2.35
+//   ANY SGPR operand (VOP2 src0, VOP3 src0/src2: v_fma/v_mul/v_sub/v_fmac)              4.05   <- half rate
+//   v_cmp (VCC or SGPR pair) 4.1, v_cndmask with an SGPR/VCC mask 4.1, SDWA forms 4.1, v_mov_b64 4.1,
+//   VOP3-only integer ops (v_perm, v_bfe, v_alignbit, v_and_or, v_lshl_or) 4.1
+//   v_rsq_f32: 8.1 back to back, ~10 in bursts of four, ~19 when it stands alone among plain instructions
+//   VGPR bank conflicts: none measurable (only three sources in ONE bank cost 4.1)
+// The compiler keeps every uniform value (box, 1/box, r2max) in SGPRs — 24 of the 36 v_fma of a 4-entry group read
+// one — rotates the prefetched list words with v_mov_b64, advances the list pointer with a 64-bit VALU add and puts
+// the list load IN FRONT of the gathers, where every wait for a gather (vmcnt retires in order) also waits for the
+// list stream from the Infinity Cache.  Hence: loop constants laundered into VGPRs; the cutoff test as arithmetic
+// (v_fma with clamp + v_mul) where no energy is wanted; the four v_rsq of a group issued back to back; list words
+// through a raw buffer with a SCALAR running offset, requested behind the gathers issued in the same breath; and the
+// unchecked groups software-pipelined over two register sets (gathers of group g+1 in flight while g is evaluated).
+constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs); measured at 4 / 6 / 7 / 8: section 6c of DESIGN.md
+// ---- the MD step inside the pair launch (FUSED variants; tmdhip_md_run, interior steps) -----------------------
+// Between two force evaluations an MD step is per-atom work on the force just computed: second half kick of step
+// `it` (+ thermostat), first half kick and drift of step it+1, the displacement test, the new record of the
+// cell-sorted copy.  As a kernel of its own that is 8.8 us at C3 (22 us at 10^6 atoms): a chain of memory round
+// trips (order -> bonded records -> partner positions -> update) with one wave per SIMD and nothing to hide it behind.
+// A FUSED launch appends "step blocks" to the grid.  Workgroups are dispatched in order, so a step block starts when
+// every pair block has been dispatched — in the slots the launch's last, partial round of pair blocks leaves idle —
+// and does everything that does not need the new forces (bonded records of its 64 atoms, noise, loads) while the
+// last pair blocks are still gathering; then every lane waits for the force record of ITS atom (the pair wave stores
+// {force, launch number} as one 16-byte word) and updates.  Behind the last pair block only one load-update-store
+// round remains, and the stored force array, its reload and one launch per step go away.
+// Pair blocks never wait for anything, so the wait cannot deadlock; it is bounded all the same.
+// Other blocks still read the positions of this launch, so the new ones go to the OTHER position buffer and the
+// OTHER cell-sorted copy (the host swaps the two after every fused launch).  Same device functions in the same
+// order as md_step_bonded_kernel / md_step_kernel: trajectories are bit-identical to the separate kernels.
+template <bool LANGEVIN, int APB>
+__device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict__ fst, const FusedStep &fs,
+                                                  const PairConsts<float> &c, int n, const float4 *__restrict__ sorted,
+                                                  const int *__restrict__ order, int j, int npair, float *s_lds);
+
+constexpr int kStepPollSleep = 4;  // s_sleep argument between two polls of a force record (x 64 cycles)
+template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
+// (LJ-only systems — liquid argon, short lists of ~90 entries — run the plain loop at one wave more per SIMD: 10^6 atoms
+// 175.5 -> 168.5 us/step; with charges the pipelined loop at 5 waves wins, section 6c)
+__global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) void list_pair_fast_f32_kernel(
+    int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
+    int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
+    const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
+    double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext,
+    int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep) {
+  constexpr int APW = 64 / LPA;
+  constexpr int UNROLL = 4;
+  static_assert(!(FUSED && ENERGY), "the fused step is for interior steps");
+  static_assert(kFastThreads == 256, "step blocks are four waves");
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // tells the host (host-mapped word) that everything enqueued before this launch has completed
+    if (publish) __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lflags) {
+      const int parity = (lmode & kLmParity) ? 1 : 0;
+      if ((lmode & kLmViolation) && lflags[F_REBUILD0 + parity] != 0) lflags[F_VIOLATION] = 1;
+      // the epilogue's test (parity ^ 1) is the next step's: this step's request is history (list_check_clear)
+      if (FUSED) lflags[F_REBUILD0 + parity] = 0;
+    }
+  }
+  __shared__ __align__(16) float2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
+  const int lane = threadIdx.x & 63;
+  // pair blocks of the launch (FUSED: step blocks follow them)
+  const unsigned npair = FUSED ? gridDim.x - (unsigned)fstep.nstep_blocks : gridDim.x;
+  if (FUSED && blockIdx.x >= npair) {
+    fused_step_blocks<FUSED == 2, kFastThreads / LPA>(fst, fstep, c, n, sorted, order, (int)(blockIdx.x - npair),
+                                                          (int)npair, reinterpret_cast<float *>(stab));
+    return;
+  }
+  // XCD-aware block order: consecutive block ids go to the 8 XCDs round-robin, so block b works on
+  // chunk (b % 8) * npair/8 + b / 8 — every XCD (own L2) gets a contiguous eighth of the cell-sorted
+  // atoms and gathers neighbours from that region only.  npair is a multiple of 8; the surplus
+  // blocks of the last eighths have nothing to do.
+  const int blk = (int)((blockIdx.x & 7u) * (npair >> 3) + (blockIdx.x >> 3));
+  if (blk * (int)(blockDim.x >> 6) * APW >= n) return;  // (block-uniform: nobody is left waiting at the barrier below)
+  const int wave = __builtin_amdgcn_readfirstlane(blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+  const int a = wave * APW + lane / LPA;
+  const int sub = lane % LPA;
+  const bool active = a < n;
+
+  // ---- prologue: every load a wave needs before its first gather is requested HERE, in one batch, and only then
+  // is the LJ table staged (a wave's life used to begin with three dependent memory round trips — table, then
+  // atom record / list length, then the first list word — 5 500 of its ~40 000 cycles)
+  // list words of this wave: group G (iterations 4G .. 4G+3 of all 64 lanes) is the 1 KB at byte G * 1024; rows are
+  // padded, and reads past the buffer's end return 0
+  const unsigned *wrow = nlist + (size_t)wave * maxn * APW;
+  const __amdgpu_buffer_rsrc_t lrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(wrow), 0, maxn * APW * 4 + 4096, 0x00020000);
+  const unsigned lvoff = (unsigned)lane * 16u;
+  auto list_word = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * 1024, 0); };
+  v4u word = list_word(0);  // list word of the next group to be gathered (in flight)
+  float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+  int nn = 0, oi = 0;
+  unsigned trow = 0;  // byte offset of this atom's row of the LDS table
+  if (active) {
+    pi = sorted[a];
+    nn = nneigh[a];
+    trow = (unsigned)stype[a] << 8;
+    oi = order[a];
+  }
+  // (only the rows of existing classes are ever read: ntypes x 32 entries instead of 32 x 32 — at 10^6 LJ atoms
+  // with 64 atoms per block the full table was 15 625 x 8 KB of staging)
+  for (int t = threadIdx.x; t < ntypes * kEntryTypes; t += blockDim.x) {
+    const int ti = t >> 5, tj = t & 31;
+    float2 ab = make_float2(0.f, 0.f);
+    if (tj < ntypes) ab = tab[ti * ntypes + tj];
+    stab[t] = make_float2(-12.0f * ab.x, 6.0f * ab.y);
+  }
+  __syncthreads();
+
+  const int myiters = (nn - sub + LPA - 1) / LPA;  // entries kk < myiters are real for this lane
+  int itmax = myiters, itmin = myiters;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    itmax = max(itmax, __shfl_xor(itmax, o, 64));
+    itmin = min(itmin, __shfl_xor(itmin, o, 64));
+  }
+  const int nkk = __builtin_amdgcn_readfirstlane(itmax);
+  // iterations every lane has entries for.  The unchecked loop takes the table offset as `entry >> 24`, which needs
+  // the slot's bits 20..22 to be zero: systems of more than 2^20 atoms run all their iterations in the checked
+  // loop, which masks the offset
+  const int nfull = n > (1 << 20) ? 0 : __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL;
+  // bounds-checked raw buffer over sorted_xyzq: lanes past the end of their list read whatever the
+  // (uninitialised) padding entry points at — out-of-range offsets return 0 instead of faulting — and
+  // are discarded by `valid`
+  const __amdgpu_buffer_rsrc_t srsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(sorted), 0, n * 16, 0x00020000);
+  const char *tbase = reinterpret_cast<const char *>(stab);
+  const float two_krf = 2.0f * c.krf;
+  const float qi2k = pi.w * two_krf;
+  const float sw_ir = c.inv_switch_range, sw_t0 = -c.switch_dist * c.inv_switch_range;
+  auto in_vgpr = [](float sv) {  // a uniform value the compiler can no longer keep in an SGPR
+    float v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(sv));
+    return v;
+  };
+  const float vbx = in_vgpr(c.box[0]), vby = in_vgpr(c.box[1]), vbz = in_vgpr(c.box[2]);
+  const float vibx = in_vgpr(c.invbox[0]), viby = in_vgpr(c.invbox[1]), vibz = in_vgpr(c.invbox[2]);
+  const float vr2max = in_vgpr(c.r2max);
+  // cutoff test as arithmetic: step = clamp((r2max' - r2) * 2^100, 0, 1) with r2max' the successor of r2max is exactly
+  // 1 for r2 <= r2max and 0 beyond
+  const float cut_h = in_vgpr(-1.2676506e30f);  // -2^100
+  const float cut_c0 = in_vgpr(__int_as_float(__float_as_int(c.r2max) + 1) * 1.2676506e30f);
+
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  float e_lj = 0.f, e_el = 0.f;  // per-lane fp32 partial sums (~55 pairs), reduced in fp64
+
+  using checked_t = std::integral_constant<bool, false>;
+  using unchecked_t = std::integral_constant<bool, true>;
+  // one group = this lane's 4 entries of iterations kk0 .. kk0+3 (one 16-byte list word) and their 4 gathered records;
+  // tab[u] = byte offset of entry u's {-12 A, 6 B} in the LDS table (row of type i | 8 x type j)
+  auto group = [&](auto image, auto unchecked, const auto &tab, const auto &raw, int kk0) {
+    constexpr bool EXACT = decltype(image)::value;
+    constexpr bool UNCHECKED = decltype(unchecked)::value;
+    constexpr bool ARITH_CUT = UNCHECKED && !ENERGY;
+    constexpr int NU = (int)std::extent<std::remove_reference_t<decltype(tab)>>::value;
+    static_assert(NU == 4, "a stage is one whole list word of a lane");
+    float dx[NU], dy[NU], dz[NU], r2[NU], rinv[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      dx[u] = min_image_magic<EXACT>(pi.x - __uint_as_float(raw[u].x), vbx, vibx);
+      dy[u] = min_image_magic<EXACT>(pi.y - __uint_as_float(raw[u].y), vby, viby);
+      dz[u] = min_image_magic<EXACT>(pi.z - __uint_as_float(raw[u].z), vbz, vibz);
+      r2[u] = norm2(dx[u], dy[u], dz[u]);
+    }
+    asm("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7"
+        : "=&v"(rinv[0]), "=&v"(rinv[1]), "=&v"(rinv[2]), "=&v"(rinv[3])
+        : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]));
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const bool valid = UNCHECKED || (kk0 + u < myiters);  // padding words are garbage
+      const float pjw = __uint_as_float(raw[u].w);
+      const bool hit = valid && (r2[u] <= vr2max);
+      const float rinv2 = rinv[u] * rinv[u];
+      const float rinv6 = rinv2 * rinv2 * rinv2;
+      float fs;  // (dE/dr) / r; rejected entries may produce inf/NaN here, the select below discards them
+      float2 ab = make_float2(0.f, 0.f);  // (-12 A, 6 B)
+      if (LJ) ab = *reinterpret_cast<const float2 *>(tbase + tab[u]);
+      // E_lj = (A r^-6 - B) r^-6 from the force coefficients (energy / switching variants only)
+      auto elj_of = [&](float r6) { return __builtin_fmaf(ab.x * (-1.0f / 12.0f), r6, ab.y * (-1.0f / 6.0f)) * r6; };
+      if (LJ && !SWITCH && ELEC) {
+        const float qq = pi.w * pjw;
+        const float p = __builtin_fmaf(ab.x, rinv6, ab.y) * rinv6;  // (a12 rinv6 + b6) rinv6
+        const float g = __builtin_fmaf(-qq, rinv[u], p);
+        fs = __builtin_fmaf(rinv2, g, qi2k * pjw);
+        if (ENERGY) e_lj += hit ? elj_of(rinv6) : 0.f;
+      } else {
+        fs = 0.f;
+        float sw = 1.f;  // switching function S(r) of the LJ term (forces.py:402-412), 1 below switch_dist
+        if (LJ) {
+          fs = __builtin_fmaf(ab.x, rinv6, ab.y) * (rinv6 * rinv2);
+          if (SWITCH) {
+            // t = (r - r_s)/(r_c - r_s) clamped at 0: S = 1 + t^3 (-10 + t (15 - 6 t)),
+            // S' = t^2 (-30 + t (60 - 30 t)) / (r_c - r_s);  (dE/dr)/r = S f + E S' x, x = 1/r (exact) or
+            // 1/r^2 (the reference's explicit-force expression divides the switching term by r once more)
+            const float r = r2[u] * rinv[u];
+            const float t = fmaxf(__builtin_fmaf(r, sw_ir, sw_t0), 0.f);
+            const float t2 = t * t;
+            const float pp = __builtin_fmaf(t, __builtin_fmaf(t, -6.f, 15.f), -10.f);
+            sw = __builtin_fmaf(t2 * t, pp, 1.f);
+            const float dq = __builtin_fmaf(t, __builtin_fmaf(t, -30.f * sw_ir, 60.f * sw_ir), -30.f * sw_ir);
+            const float elj = elj_of(rinv6);
+            const float x = c.switch_reference_mode ? rinv2 : rinv[u];
+            fs = __builtin_fmaf(sw, fs, elj * (t2 * dq) * x);
+          }
+          if (ENERGY) e_lj += hit ? sw * elj_of(rinv6) : 0.f;
+        }
+        if (ELEC) fs += (pi.w * pjw) * (two_krf - rinv2 * rinv[u]);
+      }
+      if (ENERGY && ELEC) e_el += hit ? (pi.w * pjw) * (rinv[u] + c.krf * r2[u] - c.crf) : 0.f;  // krf = crf = 0: plain Coulomb
+      if (ARITH_CUT) {
+        float step;
+        asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(step) : "v"(r2[u]), "v"(cut_h), "v"(cut_c0));
+        fs *= step;  // (every entry of the unchecked loop is a real pair, not a padding word: fs is finite)
+      } else {
+        fs = hit ? fs : 0.f;
+      }
+      fx = __builtin_fmaf(-dx[u], fs, fx);
+      fy = __builtin_fmaf(-dy[u], fs, fy);
+      fz = __builtin_fmaf(-dz[u], fs, fz);
+    }
+  };
+
+  static_assert(UNROLL == 4, "one dwordx4 of list per lane and group");
+  // issue the 4 gathers of the group whose list word is `w` and form its table offsets (unchecked: n <= 2^20, bits
+  // 24..27 of an entry are zero; checked: padding words are garbage, the offset is masked)
+  auto issue = [&](auto unchecked, const v4u &w, v4u (&raw)[UNROLL], unsigned (&tab)[UNROLL]) {
+    const unsigned entry[UNROLL] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) tab[u] = trow | (decltype(unchecked)::value ? entry[u] >> 24 : (entry[u] >> 24) & 0xF8u);
+  };
+  const int gall = (nkk + UNROLL - 1) / UNROLL;  // groups of this wave
+  int g = 0;                                     // next group to evaluate; `word` = its list word
+  // A list word is requested AFTER the gathers issued in the same breath (see the head comment); sched_barrier pins
+  // that order against the compiler's preference.
+  auto checked_loop = [&](auto image) {  // per-lane validity; not pipelined (the tail is short)
+    for (; g < gall; ++g) {
+      v4u raw[UNROLL];
+      unsigned tab[UNROLL];
+      issue(checked_t{}, word, raw, tab);
+      __builtin_amdgcn_sched_barrier(0);
+      word = list_word(g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      group(image, checked_t{}, tab, raw, g * UNROLL);
+    }
+  };
+  if (extent_needs_exact_image(ext, c.box)) {  // wave-uniform, rare: atoms more than 2.4 box edges apart
+    checked_loop(exact_image{});
+  } else {
+    const int gfull = nfull / UNROLL;  // groups in which every lane has real entries: no validity test
+    // Software pipeline over the unchecked groups: the gathers of group g+1 (and the list word of g+2) are requested
+    // before group g is evaluated, into the other register set; a wave then waits for memory once per group, for
+    // requests it made a whole group's arithmetic earlier (counters of the unpipelined loop: 44 % of a wave's cycles
+    // in s_waitcnt, 27 % issuing — at the ~5 cycles per instruction a wave can issue by itself, six such waves do
+    // not fill the VALU pipe).  94 VGPRs: five waves per SIMD.
+    if constexpr (ENERGY || SWITCH || !ELEC) {  // (the variants with more live values keep the plain loop: no spills at 5 waves)
+      for (; g < gfull; ++g) {
+        v4u raw[UNROLL];
+        unsigned tab[UNROLL];
+        issue(unchecked_t{}, word, raw, tab);
+        __builtin_amdgcn_sched_barrier(0);
+        word = list_word(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, tab, raw, g * UNROLL);
+      }
+    } else if (gfull > 0) {
+      v4u ra[UNROLL], rb[UNROLL];
+      unsigned ta[UNROLL], tb[UNROLL];
+      issue(unchecked_t{}, word, ra, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      word = list_word(1);
+      __builtin_amdgcn_sched_barrier(0);
+      while (true) {
+        if (g + 1 >= gfull) {
+          group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
+          g += 1;
+          break;
+        }
+        issue(unchecked_t{}, word, rb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        word = list_word(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 >= gfull) {
+          group(fused_image{}, unchecked_t{}, tb, rb, (g + 1) * UNROLL);
+          g += 2;
+          break;
+        }
+        issue(unchecked_t{}, word, ra, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        word = list_word(g + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        group(fused_image{}, unchecked_t{}, tb, rb, (g + 1) * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
+        g += 2;
+      }
+    }
+    checked_loop(fused_image{});  // tail
+  }
+  float sx = fx, sy = fy, sz = fz;
+#pragma unroll
+  for (int o = LPA >> 1; o > 0; o >>= 1) {
+    sx += __shfl_xor(sx, o, 64);
+    sy += __shfl_xor(sy, o, 64);
+    sz += __shfl_xor(sz, o, 64);
+  }
+  if constexpr (FUSED != 0) {
+    // The force record {fx, fy, fz, launch number} goes to the cell-sorted array the step blocks watch, as ONE 16-byte
+    // store written through to device scope (sc1): the number in .w says the force beside it is this launch's.
+    // (A flag per wave behind the stores cost a memory round trip more at the end of the launch; an agent-scope
+    // release does it with buffer_wbl2, a write-back of the whole L2 per wave: 365 us per launch.)
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fstep.fsort, 0, n * 16, 0x00020000);
+    if (active && sub == 0)
+      __builtin_amdgcn_raw_buffer_store_b128((v4u){__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(sz), fstep.gen},
+                                             frsrc, a * 16, 0, kAuxDeviceScope);
+    return;
+  }
+  if (active && sub == 0 && forces) {
+    if (overwrite) {
+      forces[3 * oi + 0] = sx;
+      forces[3 * oi + 1] = sy;
+      forces[3 * oi + 2] = sz;
+    } else {
+      forces[3 * oi + 0] += sx;
+      forces[3 * oi + 1] += sy;
+      forces[3 * oi + 2] += sz;
+    }
+  }
+  if (ENERGY) {  // every pair is listed from both atoms: half of the sum
+    if (LJ) {
+      const double s = wave_sum((double)e_lj);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_LJ], 0.5 * s);
+    }
+    if (ELEC) {
+      const double s = wave_sum((double)e_el);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_ELECTROSTATICS], 0.5 * s);
+    }
+  }
+}
+
+// Step block j of a FUSED pair launch (four waves, 64 atoms): the atoms of the 64 / APB pair blocks that run on the
+// same XCD (block ids congruent mod 8) and are neighbours in the cell-sorted order.  Like md_step_bonded_kernel, wave w
+// evaluates bonded record slots w, w + 4, ... of all 64 atoms (lane = atom), the partial forces meet in LDS as
+// (p0 + p1) + (p2 + p3), and the first wave updates — after it has waited for the pair waves of its atoms.
+template <bool LANGEVIN, int APB>
+__device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict__ fst, const FusedStep &fs,
+                                                  const PairConsts<float> &c, int n, const float4 *__restrict__ sorted,
+                                                  const int *__restrict__ order, int j, int npair, float *s_lds) {
+  constexpr int K = 64 / APB;  // pair blocks per 64 atoms
+  float(*s_part)[3][64] = reinterpret_cast<float(*)[3][64]>(s_lds);  // [kQuad][3][64], the pair role's LJ table space
+  const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  // With bonded records a step block is 64 atoms (its four waves share their records); without, every wave is a unit
+  // of 64 atoms of its own (four waves of which three only met at the barrier doubled the waves of a 10^6-atom LJ launch).
+  const bool bonded = fs.bonded == 1;  // (launch-uniform; 2 = the bonded force comes from a buffer: waves are units too)
+  const int xcd = j & 7, q = bonded ? (j >> 3) : (j >> 3) * kQuad + w, g8 = npair >> 3;
+  const int kc = K * q + lane / APB;  // this lane's pair block within the XCD's eighth
+  const int a = (xcd * g8 + kc) * APB + lane % APB;
+  const bool exists = kc < g8 && a < n;
+  const int o = exists ? order[a] : 0;
+  MdStepArgs<float> s = fst->s;
+  s.pos_in = fs.pos_in;
+  s.pos_out = fs.pos_out;
+  s.sorted = fs.sorted_out;
+  s.noise_step = fs.noise_step;
+  s.f_zero = nullptr;
+  s.chk.near_host = fs.near_host;
+  s.chk.seq = fs.seq;
+  s.chk.parity = fs.parity;
+  s.chk.skipped = 0;  // (unknown here: the next launch's first thread looks, kLmViolation)
+  const bool integrates = (w == 0 || !bonded) && exists;
+  AtomIn<float> x{};
+  if (integrates) {  // every load of the update but the force, in flight during the bonded part
+    x.m = s.mass[o];
+    x.vc = LANGEVIN ? s.vcoeff[o] : 0.f;
+    const float4 p = sorted[a];  // x, y, z, scaled charge: exactly what the position buffer holds
+    x.p[0] = p.x, x.p[1] = p.y, x.p[2] = p.z;
+    x.q = p.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      x.v[k] = s.vel[3 * o + k];
+      x.r[k] = s.chk.ref[3 * o + k];
+    }
+    x.h2 = list_check_limit(s.chk, o);
+    x.slot = a;
+  }
+  float fb[3] = {0.f, 0.f, 0.f};
+  float g[3] = {0.f, 0.f, 0.f};
+  if (bonded) {
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (exists) {
+      const BondedArgs<float> A = fst->A;
+      double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
+      const AtomRec<float> *rec = A.arec + (size_t)o * A.arec_stride;
+      for (int k = w; k < A.arec_stride; k += kQuad) {
+        const AtomRec<float> r = rec[k];
+        if (r.ent == kNoRec) break;  // records are packed from the front
+        eval_rec<float>(A, s.pos_in, o, r, fx, fy, fz, e);
+      }
+    }
+    s_part[w][0][lane] = fx;
+    s_part[w][1][lane] = fy;
+    s_part[w][2][lane] = fz;
+    if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
+  } else {
+    if (fs.bonded == 2 && integrates) {
+      const float *fbond = fst->fbond;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fb[k] = fbond[3 * o + k];
+    }
+    if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
+  }
+  // Wait for this atom's force record of THIS launch (.w = launch number; a 16-byte access is one request at the L2).
+  // Its pair block was dispatched before this block and waits for nothing; the bound only keeps a broken assumption
+  // from hanging the GPU.
+  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fs.fsort, 0, n * 16, 0x00020000);
+  v4u f = (v4u){0u, 0u, 0u, fs.gen};
+  if (integrates) {
+    unsigned spins = 0;
+    while (true) {
+      f = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope);
+      if (f.w == fs.gen) break;
+      __builtin_amdgcn_s_sleep(kStepPollSleep);
+      if (++spins > (1u << 22)) {
+        s.chk.flags[F_VIOLATION] = 1;  // the caller rewinds and repeats the batch
+        break;
+      }
+    }
+  }
+  if (!integrates) return;
+  x.f[0] = __uint_as_float(f.x), x.f[1] = __uint_as_float(f.y), x.f[2] = __uint_as_float(f.z);
+  md_step_atom<float, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, fs.bonded != 0, LANGEVIN ? g : nullptr);
+}
+
+// host side: one launch of the lean fp32 kernel over the replica's list (fl: with step blocks behind the pair blocks)
+template <bool ENERGY>
+int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &c, float *f, int overwrite, hipStream_t st,
+                         hipEvent_t e0, hipEvent_t e1, int lmode, const FusedLaunch *fl) {
+  const int n = ctx->d.natoms;
+  const int apw = rp.lg.apw;
+  const int waves = (n + apw - 1) / apw;
+  const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
+#define TMD_LAUNCH_FAST_T(L, A, B, F)       \
+  if (c.switch_on && A) {                  \
+    TMD_LAUNCH_FAST_S(L, A, B, true, F);   \
+  } else {                                 \
+    TMD_LAUNCH_FAST_S(L, A, B, false, F);  \
+  }
+#define TMD_LAUNCH_FAST_S(L, A, B, S, F)                                                                                  \
+  launch_with_events(list_pair_fast_f32_kernel<L, A, B, ENERGY, S, F>, dim3(npair8 + (F ? fstep.nstep_blocks : 0)),        \
+                     dim3(kFastThreads), 0u, st, e0, e1, n, rp.sorted.as<float4>(), rp.stype.as<int>(), rp.order.as<int>(), \
+                     ctx->d.ntypes, ctx->tab.as<float2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
+                     overwrite, ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>(),                  \
+                     rp.flags.as<int>(), lmode, F ? fl->fst : nullptr, fstep)
+#define TMD_LAUNCH_FAST(L, F)               \
+  if (lj && el) {                           \
+    TMD_LAUNCH_FAST_T(L, true, true, F);    \
+  } else if (lj) {                          \
+    TMD_LAUNCH_FAST_T(L, true, false, F);   \
+  } else {                                  \
+    TMD_LAUNCH_FAST_T(L, false, true, F);   \
+  }
+  constexpr int wpb = kFastThreads / 64;
+  const int npair8 = ((waves + wpb - 1) / wpb + 7) / 8 * 8;
+  FusedStep fstep{};
+  if (fl) {
+    // step blocks behind the pair blocks (interior steps of tmdhip_md_run; fused_step_possible() has been asked):
+    // one per 64 / (atoms of a pair block) pair blocks of an XCD's eighth
+    fstep = fl->step;
+    const int k = rp.lg.lpa * 64 / kFastThreads, g8 = npair8 / 8;
+    const int units = (g8 + k - 1) / k;  // 64-atom units per XCD's eighth: a block with bonded records, a wave without
+    fstep.nstep_blocks = 8 * (fstep.bonded == 1 ? units : (units + 3) / 4);
+    if (rp.fsort.bytes < sizeof(float4) * (size_t)n) {
+      TMD_TRY(rp.fsort.ensure(sizeof(float4) * (size_t)n));
+      TMD_HIP(hipMemsetAsync(rp.fsort.p, 0, rp.fsort.bytes, st));  // launch number 0 = never written
+      rp.fused_gen = 0;
+    }
+    if (rp.fused_gen == 0)  // test knob: start the launch counter just below its wrap-around
+      if (const char *e = std::getenv("TMDHIP_DEBUG_FUSED_GEN0")) rp.fused_gen = (unsigned)std::strtoul(e, nullptr, 0);
+    if (++rp.fused_gen == 0) rp.fused_gen = 1;  // (0 = "never written" in the records)
+    fstep.gen = rp.fused_gen;
+    fstep.fsort = rp.fsort.as<float4>();
+    if constexpr (!ENERGY) {
+#define TMD_LAUNCH_FUSED(L)    \
+  if (fl->langevin) {          \
+    TMD_LAUNCH_FAST(L, 2);     \
+  } else {                     \
+    TMD_LAUNCH_FAST(L, 1);     \
+  }
+      switch (rp.lg.lpa) {
+        case 4: TMD_LAUNCH_FUSED(4); break;
+        case 8: TMD_LAUNCH_FUSED(8); break;
+        case 16: TMD_LAUNCH_FUSED(16); break;
+        case 32: TMD_LAUNCH_FUSED(32); break;
+        case 64: TMD_LAUNCH_FUSED(64); break;
+        default: return fail("fused MD step: unsupported lanes-per-atom");
+      }
+#undef TMD_LAUNCH_FUSED
+    } else {
+      return fail("fused MD step with energies");
+    }
+  } else {
+    switch (rp.lg.lpa) {  // (pick_lpa never returns less than 4)
+      case 4: TMD_LAUNCH_FAST(4, 0); break;
+      case 8: TMD_LAUNCH_FAST(8, 0); break;
+      case 16: TMD_LAUNCH_FAST(16, 0); break;
+      case 32: TMD_LAUNCH_FAST(32, 0); break;
+      default: TMD_LAUNCH_FAST(64, 0); break;
+    }
+  }
+#undef TMD_LAUNCH_FAST
+#undef TMD_LAUNCH_FAST_T
+#undef TMD_LAUNCH_FAST_S
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+template int launch_pair_fast_f32<true>(tmdhip_ctx *, Replica &, const PairConsts<float> &, float *, int, hipStream_t,
+                                        hipEvent_t, hipEvent_t, int, const FusedLaunch *);
+template int launch_pair_fast_f32<false>(tmdhip_ctx *, Replica &, const PairConsts<float> &, float *, int, hipStream_t,
+                                         hipEvent_t, hipEvent_t, int, const FusedLaunch *);
+
+}  // namespace tmd

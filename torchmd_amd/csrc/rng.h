@@ -1,5 +1,5 @@
 // Counter-based Gaussian noise for the Langevin thermostat (shared by integrator.hip and the fused
-// MD-step kernels in nonbonded.hip).
+// MD-step kernels in md_loop.hip).
 #pragma once
 
 #include "common.h"
