@@ -21,6 +21,7 @@
 #ifndef TMDHIP_H
 #define TMDHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
