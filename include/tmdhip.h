@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TMDHIP_ABI_VERSION 4
+#define TMDHIP_ABI_VERSION 5
 
 /* dtype */
 #define TMDHIP_F32 0
@@ -136,6 +136,7 @@ typedef struct tmdhip_stats {
   double skin;              /* Verlet skin in use (Angstrom)                                */
   int64_t chains_skipped;   /* MD steps whose rebuild chain the host left out (tmdhip_md_run)  */
   int64_t steps_in_pair_launch; /* MD steps made by step blocks of the pair launch instead of an integrator launch (ABI 4) */
+  int64_t fused_step_timeouts;  /* batches rewound because a step block of a fused launch gave up waiting (ABI 5; whole context) */
 } tmdhip_stats;
 
 int tmdhip_abi_version(void);

@@ -596,6 +596,67 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_fused_launch_timeout_falls_back_to_the_integrator_kernel(monkeypatch):
+    """Fail-safe of the fused pair + step launch.  Its step blocks wait for force records written by pair blocks of
+    the SAME launch, which relies on workgroups being dispatched in block order; the wait is bounded.  The test knob
+    makes the step blocks of the 7th fused launch wait for a launch number nobody writes: they give up
+    (F_STEP_TIMEOUT) without integrating, `tmdhip_md_observe` reports the batch invalid, Integrator.step rewinds it
+    ONCE and repeats it with the separate integrator kernel (no fused launch, every rebuild chain in place).  The
+    result must equal — bit for bit — an unfused run that also rebuilds its list in the first step of the call (what
+    the rewind does), and the next step() call fuses again."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(14, seed=4)  # 8 232 atoms
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    monkeypatch.setenv("TMDHIP_LPA", "8")
+    torch.manual_seed(3)
+    vel0 = maxwell_boltzmann(par.masses, 300.0, 1)
+
+    def run(knob):
+        if knob:
+            monkeypatch.setenv("TMDHIP_DEBUG_STEP_TIMEOUT", "7")
+            monkeypatch.delenv("TMDHIP_FUSED_STEP", raising=False)
+            monkeypatch.delenv("TMDHIP_CHAIN_SKIP", raising=False)
+        else:
+            monkeypatch.delenv("TMDHIP_DEBUG_STEP_TIMEOUT", raising=False)
+            monkeypatch.setenv("TMDHIP_FUSED_STEP", "0")
+            monkeypatch.setenv("TMDHIP_CHAIN_SKIP", "0")
+        s = System(mol.numAtoms, 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        s.set_velocities(vel0)
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        f.compute(s.pos, s.box, s.forces)
+        if not knob:
+            f.invalidate_lists(s.pos)  # the rewound batch of the other run starts with a re-plan + rebuild as well
+        torch.manual_seed(9)
+        integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+        res = [integ.step(30)]
+        mid = f.stats(s.pos)
+        monkeypatch.delenv("TMDHIP_DEBUG_STEP_TIMEOUT", raising=False)
+        res.append(integ.step(20))
+        return s.pos.cpu(), s.vel.cpu(), s.forces.cpu(), res, mid, f.stats(s.pos)
+
+    p1, v1, f1, r1, mid1, st1 = run(True)
+    p0, v0, f0, r0, mid0, st0 = run(False)
+    assert mid1["fused_step_timeouts"] == 1 and st1["fused_step_timeouts"] == 1, (mid1, st1)
+    assert mid1["steps_in_pair_launch"] == 29  # the first attempt of the batch; its repetition made none
+    assert st1["steps_in_pair_launch"] == 29 + 19  # the next call fuses again
+    assert st0["fused_step_timeouts"] == 0 and st0["steps_in_pair_launch"] == 0
+    assert torch.isfinite(p1).all()
+    assert torch.equal(p1, p0) and torch.equal(v1, v0) and torch.equal(f1, f0)
+    for a, b in zip(r1, r0):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), (a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin", "water_counter_wraps",
                                   "water_32_lanes", "water_64_lanes", "thrombin"])
 def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):

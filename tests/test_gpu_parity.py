@@ -473,6 +473,76 @@ def test_lj_million_atoms_properties():
     assert -1.6 < e / 1e6 < -0.6  # cohesive LJ energy per atom (eps = 0.238 kcal/mol, jittered lattice: -1.01)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("nside", [100, 104])
+def test_lj_million_atoms_vs_oracle(nside):
+    """Config C5 size against the ORACLE (reference arithmetic: forces.py:260-319, 360-372, 381-415; argon parameters of
+    /root/reference/tests/argon/argon_forcefield.yaml:8-18), on one GPU, after a few MD steps so that the state is the
+    one the bench times (device-side rebuilds, the LJ-only loop of the lean kernel at 4 lanes per atom; 104^3 =
+    1 124 864 atoms > 2^20: every iteration in the checked loop with the masked table offset).  The oracle cannot
+    evaluate 3.3e7 pairs' worth of [P, 3] temporaries in seconds, so: (i) 20 000 random atoms — every candidate pair
+    that touches one of them (cKDTree, 9.5 A) goes through the oracle, and the forces on the picked atoms (complete:
+    all of their pairs are there) must equal the GPU's within the fp32 bar; (ii) 10^6-atom box only: the in-cutoff
+    pair COUNT of the whole box by the oracle's decision arithmetic (pair_geometry + `dist <= cutoff`, fp32, in chunks)
+    must equal the GPU's count exactly."""
+    from scipy.spatial import cKDTree
+
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import argon_forcefield, lj_box
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = lj_box(nside, seed=4)
+    n = mol.numAtoms
+    par = Parameters(argon_forcefield(mol), mol, ["lj"], precision=dt)
+    s = System(n, 1, dt, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    torch.manual_seed(2)
+    s.set_velocities(maxwell_boltzmann(par.masses, 85.0, 1))
+    f = Forces(par, terms=["lj"], cutoff=9.0)
+    f.compute(s.pos, s.box, s.forces)
+    Integrator(s, f, 1.0, dev, gamma=1.0, T=85.0).step(12)  # forces of the final positions are in s.forces
+    st = f.stats(s.pos)
+    assert st["algorithm"] == "celllist" and st["overflow"] == 0 and st["steps_in_pair_launch"] >= 10, st
+    p = s.pos.detach().cpu()
+    Fg = s.forces.detach().cpu()
+    p64 = p[0].double().numpy()
+    b = np.asarray(box, dtype=np.float64)
+    w = p64 - np.floor(p64 / b) * b
+    w = np.where(w >= b, w - b, w)
+    tree = cKDTree(w, boxsize=b)
+    pick = np.sort(np.random.default_rng(7).choice(n, 20000, replace=False))
+    nb = tree.query_ball_point(w[pick], 9.5, workers=-1)
+    i = np.repeat(pick, [len(x) for x in nb])
+    j = np.concatenate([np.asarray(x, dtype=np.int64) for x in nb])
+    keep = i != j
+    lo, hi = np.minimum(i[keep], j[keep]), np.maximum(i[keep], j[keep])
+    key = np.unique(lo * np.int64(n) + hi)  # pairs between two picked atoms were found twice; sorted (i asc, j asc)
+    pairs = np.stack([key // n, key % n], axis=1)
+    _, Fo, nin = orc.compute(par, p, s.box.cpu(), ["lj"], pairs=pairs, cutoff=9.0)
+    err = (Fg[0, pick] - Fo[0, pick]).abs().max().item()
+    print(f"{n} argon atoms after 12 MD steps: {len(pairs)} candidate pairs touch the 20 000 picked atoms, {nin[0]} inside the "
+          f"cutoff; max|dF| on the picked atoms = {err:.3e} (max|F| = {Fg[0, pick].abs().max().item():.2f})")
+    assert nin[0] > 600000
+    assert err < FTOL["f32"]
+    if nside == 100:
+        n_gpu = f.count_pairs(s.pos, s.box)[0]
+        allp = tree.query_pairs(9.05, output_type="ndarray")
+        pt, bt = p[0], s.box.cpu()[0][torch.eye(3).bool()]
+        total = 0
+        for c in range(0, len(allp), 4_000_000):
+            idx = torch.as_tensor(allp[c: c + 4_000_000].astype(np.int64))
+            d, _, _ = orc.pair_geometry(pt, idx, bt)
+            total += int((d <= 9.0).sum().item())
+        print(f"P_cut of the whole box: oracle {total}, GPU {n_gpu}")
+        assert n_gpu == total
+    f.close()
+
+
 def test_auto_falls_back_to_allpairs_in_small_boxes():
     """N >= 2048 with a cutoff selects the cell-list path, but with cutoff 10.5 A a 27.9 A box holds fewer than 5 cells of
     (cutoff + skin)/2 per edge: algorithm='auto' must switch to the all-pairs kernel by itself (also inside

@@ -395,8 +395,17 @@ int tmdhip_compute_bonded(tmdhip_ctx *ctx, int replica, const void *pos_dev, con
   if ((flags & TMDHIP_WANT_ENERGY) && !energies_dev)
     return fail("tmdhip_compute_bonded: energies requested without a buffer");
   Bonded *b = (Bonded *)ctx_bonded_slot(ctx);
-  if (!b) return 0;
   hipStream_t st = (hipStream_t)stream;
+  const bool overwrite = (flags & TMDHIP_WANT_FORCES) && (flags & TMDHIP_OVERWRITE_FORCES);
+  if (!b || b->nentries == 0) {
+    // no bonded terms: "the bonded force alone" is zero (TMDHIP_OVERWRITE_FORCES), an accumulating call changes nothing
+    if (overwrite) {
+      const size_t nrep0 = replica == TMDHIP_ALL_REPLICAS ? (size_t)ctx_nreplicas(ctx) : 1;
+      const size_t esz = ctx_desc(ctx).dtype == TMDHIP_F32 ? 4 : 8;
+      TMD_HIP(hipMemsetAsync(forces_dev, 0, esz * 3 * (size_t)ctx_desc(ctx).natoms * nrep0, st));
+    }
+    return 0;
+  }
   // all replicas ([R][N][3] positions/forces, [R][8] energies, [R][3] boxes): one launch with grid.y = R
   const int nrep = replica == TMDHIP_ALL_REPLICAS ? ctx_nreplicas(ctx) : 1;
   return ctx_desc(ctx).dtype == TMDHIP_F32

@@ -322,6 +322,21 @@ int upload_params(tmdhip_ctx *ctx) {
 
 // verdict on the list flags of one replica (already on the host): 0 valid, 1 repeat the work, < 0 error
 int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
+  if (h[F_STEP_TIMEOUT]) {
+    // a step block of a fused pair launch gave up waiting for its atoms' force records (pair_fast_f32.hip): those atoms
+    // were not integrated.  Repeat the batch with the separate integrator kernel; a second time-out of this context
+    // switches the fused launch off for good.
+    (void)hipMemsetAsync(rp.flags.as<int>() + F_STEP_TIMEOUT, 0, sizeof(int), st);
+    ctx->fused_step_timeouts++;
+    ctx->no_fused_once = true;
+    if (ctx->fused_step_timeouts >= 2) ctx->fused_disabled = true;
+    ctx->no_chain_skip_once = true;
+    rp.seq_valid = false;
+    rp.box[0] = -1;  // re-plan + rebuild
+    last_error() = "a step block of the fused pair + step launch timed out waiting for a force record (workgroups not "
+                   "dispatched in block order?); the batch is repeated with the separate integrator kernel";
+    if (h[F_MAXN] <= rp.lg.maxn) return 1;
+  }
   if (h[F_VIOLATION]) {
     // an atom crossed its displacement limit in a step whose rebuild chain had been left out (ListCheck)
     (void)hipMemsetAsync(rp.flags.as<int>() + F_VIOLATION, 0, sizeof(int), st);
@@ -621,6 +636,7 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   out->skin = ctx->skin;
   out->chains_skipped = rp.chains_skipped;
   out->steps_in_pair_launch = rp.steps_in_pair_launch;
+  out->fused_step_timeouts = ctx->fused_step_timeouts;
   out->pairs_in_cutoff = (int64_t)pc;
   out->algorithm = ctx->algorithm;
   out->max_neighbours = rp.lg.maxn;

@@ -88,7 +88,9 @@ __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
 //   F_NREBUILD    rebuild counter
 //   F_VIOLATION   a rebuild was requested in a step whose rebuild chain the host had not enqueued (see
 //                 ListCheck::skipped): the forces since then are invalid, the caller rewinds and repeats
-enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_COUNT = 5 };
+//   F_STEP_TIMEOUT  a step block of a fused pair launch gave up waiting for a force record (pair_fast_f32.hip): its
+//                 atoms were NOT integrated; the caller rewinds and repeats the batch with the separate integrator kernel
+enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_STEP_TIMEOUT = 5, F_COUNT = 6 };
 
 // Displacement test that drives the rebuilds: the list (cutoff + skin) is valid while no atom has moved
 // further than skin/2 from `ref`; the test runs on the device (in the fused integrator kernel, or in
@@ -304,7 +306,9 @@ struct FusedStep {   // what does (kernel argument)
   float *pos_out;       // drifted positions
   float4 *sorted_out;   // their cell-sorted records
   float4 *fsort;        // {pair force, launch number} per atom, cell-sorted order (pair blocks write, step blocks watch)
-  unsigned gen;         // number of this launch (never 0)
+  unsigned gen;         // number of this launch (never 0): what the pair blocks write beside a force
+  unsigned watch_gen;   // what the step blocks wait for: == gen (a test knob makes it differ, so that the wait times out)
+  unsigned poll_limit;  // polls of a force record before a step block gives up (F_STEP_TIMEOUT)
   int bonded;           // FusedStatic::has_bonded (0 none, 1 inline records, 2 from FusedStatic::fbond)
   int nstep_blocks;     // step blocks at the end of the grid (a multiple of 8, like the pair blocks)
   uint64_t noise_step;
@@ -313,6 +317,8 @@ struct FusedStep {   // what does (kernel argument)
   int parity;           // of the next step
 };
 constexpr int kAuxDeviceScope = 16;  // sc1 of a gfx942/950 buffer access: coherent across the XCDs' L2s
+constexpr int kAuxVolatile = (int)0x80000000;  // bit 31 of a raw-buffer intrinsic's aux operand: a volatile access (the
+                                               // compiler must neither hoist it out of a loop nor merge two of them)
 // lmode bits (list bookkeeping duties of the launch's first thread)
 constexpr int kLmViolation = 1;  // the chain of this step was left out and its displacement test ran in the previous
                                  // launch's epilogue, which could not know that: a rebuild request found now = F_VIOLATION
@@ -388,6 +394,7 @@ struct Replica {
   DevBuf fsort;            // {pair force, launch number} per atom in cell-sorted order (fused launches)
   DevBuf fbond;            // bonded force of a fused launch's positions (heavy topologies), original atom order
   unsigned fused_gen = 0;  // number of the last fused launch
+  int64_t fused_launches = 0;  // fused launches of this replica (test knob TMDHIP_DEBUG_STEP_TIMEOUT counts them)
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf extent;  // int[6]: keys of the coordinate extent of sorted_xyzq (extent_note)
   DevBuf paircount;  // unsigned long long
@@ -418,6 +425,11 @@ struct tmdhip_ctx {
   // order; empty = skin / 2 for every atom
   tmd::DevBuf half_skin, half_skin2;
   bool no_chain_skip_once = false;  // the next tmdhip_md_run enqueues every rebuild chain (repetition of a rewound batch)
+  // Fail-safe of the fused pair + step launch (F_STEP_TIMEOUT): the batch that timed out is repeated with the separate
+  // integrator kernel (`no_fused_once`, consumed by the next tmdhip_md_run into `fused_off_call`); a context that timed
+  // out twice stops fusing for good (`fused_disabled`): the hand-over's in-order-dispatch assumption does not hold here.
+  bool no_fused_once = false, fused_off_call = false, fused_disabled = false;
+  int64_t fused_step_timeouts = 0;
   // velocity-dependent skins inside tmdhip_md_run (place_sorted_kernel): s_i = min(floor * static_i + time * |v_i|, cap)
   double vskin_floor = 0.8, vskin_time = 0, vskin_cap = 1.2, vskin_cap_len = 0;
   double mean_list_scale = 1;  // mean list length / length of a list at the largest pair radius (per-atom skins)

@@ -145,9 +145,9 @@ constexpr int kPrepSmallMaxCells = 4096;
 constexpr int kPrepSmallMaxAtoms = 8192;
 template <typename R>
 __global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__restrict__ pos, Grid g, int ncell,
-                                                          int *__restrict__ cell_of, int *__restrict__ slot,
-                                                          int *__restrict__ cell_start, int *__restrict__ order_tmp,
-                                                          PlaceArgs<R> P, const int *flag) {
+                                                          int *cell_of, int *__restrict__ slot, int *cell_start,
+                                                          int *order_tmp, PlaceArgs<R> P, const int *flag) {
+  // (cell_of, cell_start and order_tmp are read back through P by place_atom below: no __restrict__ on them)
   if (*flag == 0) return;
   __shared__ int s_count[kPrepSmallMaxCells];
   __shared__ int s_start[kPrepSmallMaxCells + 1];

@@ -193,6 +193,7 @@ bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairCon
   if (!std::is_same<R, float>::value) return false;
   const char *e = std::getenv("TMDHIP_FUSED_STEP");  // (read per call: tests switch it within a process)
   if (e && std::atoi(e) == 0) return false;
+  if (ctx->fused_off_call || ctx->fused_disabled) return false;  // repetition of a batch whose fused launch timed out
   const bool only_lj_el = c.terms != 0 && (c.terms & ~(TMDHIP_TERM_LJ | TMDHIP_TERM_ELECTROSTATICS)) == 0;
   return only_lj_el && ctx->d.ntypes <= kEntryTypes && rp.lg.lpa >= 4 && rp.lg.lpa <= 64 && kFastThreads / rp.lg.lpa <= 64;
 }
@@ -209,6 +210,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   const int64_t chain_min_entries = e_min ? std::atoll(e_min) : kChainSkipMinEntries;
   const double chain_near = e_near ? std::atof(e_near) : kChainSkipNear;
   ctx->no_chain_skip_once = false;
+  ctx->fused_off_call = ctx->no_fused_once;
+  ctx->no_fused_once = false;
   bool pace_timed_out = false;  // the device did not report within wait_published's limit: no more waiting in this call
   const int nrep = (int)ctx->rep.size();
   const bool langevin = d->vcoeff_dev != nullptr;

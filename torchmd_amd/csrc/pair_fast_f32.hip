@@ -444,19 +444,22 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
     if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
   }
   // Wait for this atom's force record of THIS launch (.w = launch number; a 16-byte access is one request at the L2).
-  // Its pair block was dispatched before this block and waits for nothing; the bound only keeps a broken assumption
-  // from hanging the GPU.
+  // Its pair block has a lower block id: it was dispatched before this block (in-order dispatch of a grid's workgroups —
+  // what the hardware does, not something HIP promises) and waits for nothing.  Should that ever not hold, the wait is
+  // bounded: the lane gives up, reports F_STEP_TIMEOUT and does NOT integrate its atom; the caller rewinds the batch
+  // and repeats it with the separate integrator kernel (judge_flags).  The poll is a volatile device-scope load:
+  // nothing may hoist it out of the loop.
   const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fs.fsort, 0, n * 16, 0x00020000);
-  v4u f = (v4u){0u, 0u, 0u, fs.gen};
+  v4u f = (v4u){0u, 0u, 0u, fs.watch_gen};
   if (integrates) {
     unsigned spins = 0;
     while (true) {
-      f = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope);
-      if (f.w == fs.gen) break;
+      f = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope | kAuxVolatile);
+      if (f.w == fs.watch_gen) break;
       __builtin_amdgcn_s_sleep(kStepPollSleep);
-      if (++spins > (1u << 22)) {
-        s.chk.flags[F_VIOLATION] = 1;  // the caller rewinds and repeats the batch
-        break;
+      if (++spins > fs.poll_limit) {
+        s.chk.flags[F_STEP_TIMEOUT] = 1;
+        return;  // no update from a stale record
       }
     }
   }
@@ -511,7 +514,12 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
     if (rp.fused_gen == 0)  // test knob: start the launch counter just below its wrap-around
       if (const char *e = std::getenv("TMDHIP_DEBUG_FUSED_GEN0")) rp.fused_gen = (unsigned)std::strtoul(e, nullptr, 0);
     if (++rp.fused_gen == 0) rp.fused_gen = 1;  // (0 = "never written" in the records)
-    fstep.gen = rp.fused_gen;
+    fstep.gen = fstep.watch_gen = rp.fused_gen;
+    fstep.poll_limit = 1u << 22;  // ~4 s of polling
+    rp.fused_launches++;
+    // test knob: the step blocks of this replica's k-th fused launch wait for a launch number nobody writes
+    if (const char *e = std::getenv("TMDHIP_DEBUG_STEP_TIMEOUT"))
+      if (rp.fused_launches == std::atoll(e)) fstep.watch_gen ^= 0x80000000u, fstep.poll_limit = 1u << 8;
     fstep.fsort = rp.fsort.as<float4>();
     if constexpr (!ENERGY) {
 #define TMD_LAUNCH_FUSED(L)    \

@@ -692,6 +692,13 @@ class Forces:
         self._evaluate(pos, box, None, False, False, count_pairs=True)
         return [self.stats(pos, r)["pairs_in_cutoff"] for r in range(pos.shape[0])]
 
+    def invalidate_lists(self, pos):
+        """Drop the neighbour lists of every replica: the next evaluation re-plans the grid and rebuilds them
+        (`tmdhip_invalidate_list`; after positions were changed out of band, and by tests)."""
+        eng = self._engine(pos.detach())
+        for r in range(pos.shape[0]):
+            L.check(eng.lib.tmdhip_invalidate_list(eng.ctx, r), "tmdhip_invalidate_list")
+
     def stats(self, pos, replica=0):
         eng = self._engine(pos.detach())
         st = L.Stats()
@@ -708,6 +715,7 @@ class Forces:
             "skin": st.skin,
             "chains_skipped": int(st.chains_skipped),
             "steps_in_pair_launch": int(st.steps_in_pair_launch),
+            "fused_step_timeouts": int(st.fused_step_timeouts),
         }
 
     def enable_timing(self, pos, on=True, every=1, limit=0, skip=0):

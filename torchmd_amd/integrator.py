@@ -88,6 +88,10 @@ def _second_VV(vel, force, mass, dt):
         )
 
 
+_REPLAY_FAILED = ("Integrator.step(): the batch of steps was rewound and repeated once and failed again; the trajectory "
+                  "since the previous step() call is invalid (restart from the last saved state).  The library says: ")
+
+
 class Integrator:
     def __init__(self, systems, forces, timestep, device, gamma=None, T=None, batch=None):
         self.dt = timestep / TIMEFACTOR
@@ -142,118 +146,109 @@ class Integrator:
         code = L.dtype_code(s.pos.dtype)
         R, N = s.pos.shape[0], s.pos.shape[1]
         fast = isinstance(self.forces, Forces)
-        pot = None
-        ebuf = ext = None
         fused = fast and not self.forces.external and niter > 0
         with torch.cuda.device(dev):
             return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=False)
 
     def _step_body(self, lib, s, dev, code, R, N, fast, fused, niter, replay):
-        from .forces import Forces  # noqa: F401
 
         pot = None
         ebuf = ext = None
-        if True:
-            if fused:
-                # whole loop enqueued from C (tmdhip_md_run): fused half-kick/drift/displacement-test
-                # kernels, no Python or ctypes work per step
-                step0 = self._nstep - niter if replay else self._nstep
-                ebuf = self.forces._md_run(
-                    s, self.masses, self.vcoeff if self.T else None, self.dt,
-                    float(self.gamma) if self.T else 0.0, self._seed, step0, niter, restore=replay,
-                )
-                if not replay:
-                    self._nstep += niter
-            for it in range(0 if not fused else niter, niter):
-                st = _stream(dev)
+        if fused:
+            # whole loop enqueued from C (tmdhip_md_run): fused half-kick/drift/displacement-test
+            # kernels, no Python or ctypes work per step
+            step0 = self._nstep - niter if replay else self._nstep
+            ebuf = self.forces._md_run(
+                s, self.masses, self.vcoeff if self.T else None, self.dt,
+                float(self.gamma) if self.T else 0.0, self._seed, step0, niter, restore=replay,
+            )
+            if not replay:
+                self._nstep += niter
+        for it in range(0 if not fused else niter, niter):
+            st = _stream(dev)
+            L.check(
+                lib.tmdhip_first_vv(code, R, N, s.pos.data_ptr(), s.vel.data_ptr(), s.forces.data_ptr(),
+                                    self.masses.data_ptr(), self.dt, st),
+                "tmdhip_first_vv",
+            )
+            if fast:
+                ebuf, ext = self.forces._compute_async(s.pos, s.box, s.forces, want_energy=(it == niter - 1))
+            else:
+                pot = self.forces.compute(s.pos, s.box, s.forces)
+            if self.T:
                 L.check(
-                    lib.tmdhip_first_vv(code, R, N, s.pos.data_ptr(), s.vel.data_ptr(), s.forces.data_ptr(),
-                                        self.masses.data_ptr(), self.dt, st),
-                    "tmdhip_first_vv",
+                    lib.tmdhip_langevin_second_vv(code, R, N, s.vel.data_ptr(), s.forces.data_ptr(),
+                                                  self.masses.data_ptr(), self.vcoeff.data_ptr(), self.dt,
+                                                  float(self.gamma), self._seed, self._nstep, st),
+                    "tmdhip_langevin_second_vv",
                 )
-                if fast:
-                    ebuf, ext = self.forces._compute_async(s.pos, s.box, s.forces, want_energy=(it == niter - 1))
-                else:
-                    pot = self.forces.compute(s.pos, s.box, s.forces)
-                if self.T:
-                    L.check(
-                        lib.tmdhip_langevin_second_vv(code, R, N, s.vel.data_ptr(), s.forces.data_ptr(),
-                                                      self.masses.data_ptr(), self.vcoeff.data_ptr(), self.dt,
-                                                      float(self.gamma), self._seed, self._nstep, st),
-                        "tmdhip_langevin_second_vv",
-                    )
-                else:
-                    L.check(
-                        lib.tmdhip_second_vv(code, R, N, s.vel.data_ptr(), s.forces.data_ptr(),
-                                             self.masses.data_ptr(), self.dt, st),
-                        "tmdhip_second_vv",
-                    )
-                self._nstep += 1
+            else:
+                L.check(
+                    lib.tmdhip_second_vv(code, R, N, s.vel.data_ptr(), s.forces.data_ptr(),
+                                         self.masses.data_ptr(), self.dt, st),
+                    "tmdhip_second_vv",
+                )
+            self._nstep += 1
 
-            eng = self.forces._engine(s.pos) if (fast and niter > 0) else None
-            if fused and self.batch is None:
-                # kinetic energy + energies of the last step + neighbour-list validity: ONE C call, ONE read-back,
-                # ONE host synchronisation (tmdhip_md_observe)
-                obs = np.empty((R, L.NENERGY + 1), dtype=np.float64)
-                rc = L.check(
-                    lib.tmdhip_md_observe(eng.ctx, s.vel.data_ptr(), self.masses.data_ptr(), ebuf.data_ptr(),
-                                          obs.ctypes.data_as(C.POINTER(C.c_double)), _stream(dev)),
-                    "tmdhip_md_observe",
-                )
-                if rc != 0:
-                    # a neighbour list was truncated, or outlived its skin between two scheduled rebuilds: rewind
-                    # to the entry state (saved by tmdhip_md_run) and repeat the batch with the rebuild chain on
-                    # every step; the noise stream is counter based, so it is the same trajectory
-                    if not replay:
-                        return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
-                    raise RuntimeError(
-                        "a neighbour list overflowed during Integrator.step(); the trajectory since the previous "
-                        "step() call is invalid (capacity has been grown — restart from the last saved state)"
-                    )
-                cols = self.forces.energy_columns()
-                tot = obs[:, cols].sum(axis=1) if cols else np.zeros(R)
-                pot = [float(v) for v in tot]
-                Ekin = obs[:, L.NENERGY].copy()
-                Ekin = Ekin.astype(np.dtype("float32") if s.pos.dtype == torch.float32 else np.float64)
-                return Ekin, pot, kinetic_to_temp(Ekin, self.natoms)
-            if self.batch is None:
-                if eng is not None:
-                    kebuf = eng.kebuf  # shares one buffer with the energies: a single read-back below
-                else:
-                    if self._ke is None or self._ke.shape[0] != R or self._ke.device != dev:
-                        self._ke = torch.zeros(R, dtype=torch.float64, device=dev)
-                    kebuf = self._ke
-                L.check(
-                    lib.tmdhip_kinetic_energy(code, R, N, s.vel.data_ptr(), self.masses.data_ptr(),
-                                              kebuf.data_ptr(), _stream(dev)),
-                    "tmdhip_kinetic_energy",
-                )
-                ke = kebuf
-            else:
-                ke = kinetic_energy(self.masses, s.vel, self.batch).flatten().to(torch.float64)
+        eng = self.forces._engine(s.pos) if (fast and niter > 0) else None
+        if fused and self.batch is None:
+            # kinetic energy + energies of the last step + neighbour-list validity: ONE C call, ONE read-back,
+            # ONE host synchronisation (tmdhip_md_observe)
+            obs = np.empty((R, L.NENERGY + 1), dtype=np.float64)
+            rc = L.check(
+                lib.tmdhip_md_observe(eng.ctx, s.vel.data_ptr(), self.masses.data_ptr(), ebuf.data_ptr(),
+                                      obs.ctypes.data_as(C.POINTER(C.c_double)), _stream(dev)),
+                "tmdhip_md_observe",
+            )
+            if rc != 0:
+                # a neighbour list was truncated or outlived its skin between two scheduled rebuilds, or a step block
+                # of a fused pair + step launch timed out: rewind to the entry state (saved by tmdhip_md_run) and
+                # repeat the batch with the rebuild chain on every step (and, after a time-out, the separate
+                # integrator kernel); the noise stream is counter based, so it is the same trajectory
+                if not replay:
+                    return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
+                raise RuntimeError(_REPLAY_FAILED + L.last_error())
+            cols = self.forces.energy_columns()
+            tot = obs[:, cols].sum(axis=1) if cols else np.zeros(R)
+            pot = [float(v) for v in tot]
+            Ekin = obs[:, L.NENERGY].copy()
+            Ekin = Ekin.astype(np.dtype("float32") if s.pos.dtype == torch.float32 else np.float64)
+            return Ekin, pot, kinetic_to_temp(Ekin, self.natoms)
+        if self.batch is None:
             if eng is not None:
-                if self.batch is None and ebuf is eng.ebuf:
-                    host = eng.comb.cpu().numpy()  # the only synchronising call of step()
-                    e = host[: R * L.NENERGY].reshape(R, L.NENERGY)
-                    Ekin = host[R * L.NENERGY:].copy()
-                    cols = self.forces.energy_columns()
-                    tot = e[:, cols].sum(axis=1) if cols else np.zeros(R)
-                    if ext is not None:
-                        tot = tot + ext.cpu().numpy()
-                    pot = [float(v) for v in tot]
-                else:
-                    tot = self.forces.total_energy_from(ebuf, ext)
-                    host = torch.cat([ke.flatten(), tot]).cpu().numpy()
-                    Ekin, pot = host[: ke.numel()], [float(v) for v in host[ke.numel():]]
-                if not self.forces._verify(eng, s.pos):
-                    if fused and not replay:  # (batch mode of the fused loop: same rewind as above)
-                        return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
-                    raise RuntimeError(
-                        "a neighbour list overflowed during Integrator.step(); the trajectory since the previous "
-                        "step() call is invalid (capacity has been grown — restart from the last saved state)"
-                    )
+                kebuf = eng.kebuf  # shares one buffer with the energies: a single read-back below
             else:
-                Ekin = ke.flatten().cpu().numpy()
+                if self._ke is None or self._ke.shape[0] != R or self._ke.device != dev:
+                    self._ke = torch.zeros(R, dtype=torch.float64, device=dev)
+                kebuf = self._ke
+            L.check(
+                lib.tmdhip_kinetic_energy(code, R, N, s.vel.data_ptr(), self.masses.data_ptr(),
+                                          kebuf.data_ptr(), _stream(dev)),
+                "tmdhip_kinetic_energy",
+            )
+            ke = kebuf
+        else:
+            ke = kinetic_energy(self.masses, s.vel, self.batch).flatten().to(torch.float64)
+        if eng is not None:
+            if self.batch is None and ebuf is eng.ebuf:
+                host = eng.comb.cpu().numpy()  # the only synchronising call of step()
+                e = host[: R * L.NENERGY].reshape(R, L.NENERGY)
+                Ekin = host[R * L.NENERGY:].copy()
+                cols = self.forces.energy_columns()
+                tot = e[:, cols].sum(axis=1) if cols else np.zeros(R)
+                if ext is not None:
+                    tot = tot + ext.cpu().numpy()
+                pot = [float(v) for v in tot]
+            else:
+                tot = self.forces.total_energy_from(ebuf, ext)
+                host = torch.cat([ke.flatten(), tot]).cpu().numpy()
+                Ekin, pot = host[: ke.numel()], [float(v) for v in host[ke.numel():]]
+            if not self.forces._verify(eng, s.pos):
+                if fused and not replay:  # (batch mode of the fused loop: same rewind as above)
+                    return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
+                raise RuntimeError(_REPLAY_FAILED + L.last_error())
+        else:
+            Ekin = ke.flatten().cpu().numpy()
         Ekin = Ekin.astype(np.dtype("float32") if s.pos.dtype == torch.float32 else np.float64)
         T = kinetic_to_temp(Ekin, self.natoms)
         return Ekin, pot, T
