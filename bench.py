@@ -30,7 +30,7 @@ TIMESTEP_FS = 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-PMC_TRAFFIC_FILES = ("r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
+PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 FLOP_PER_PAIR = 50.0             # ~50 FLOP + 1 rsqrt per in-cutoff pair
 SIMDS, NOMINAL_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues over 2 cycles per SIMD
@@ -109,17 +109,17 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
-def run_c5(args, rank, world, local_rank, device, launched):
-    """Config C5 of BASELINE.json: synthetic 10^6-atom Lennard-Jones (argon) box, cutoff 9 A, Langevin 85 K,
-    1 fs.  One GPU: the whole box on the single-domain engine.  N > 1: spatial domain decomposition, one brick
-    per rank, positions of the halo atoms exchanged over RCCL every step (torchmd_amd/domain.py); strong
-    scaling (the box is fixed)."""
-    import torch.distributed as dist
+C5_TRAFFIC_FILES = ("r04_c5_pmc_traffic.json", "r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json")  # newest committed PMC pass first
 
+
+def c5_single_gpu(args, device, cpu_budget_s=15.0):
+    """Config C5 on ONE GPU: the whole 10^6-atom argon box on the single-domain engine.  Returns the fields of a bench
+    line (value, ms_per_step, roofline, cpu_baseline, ...): `--config c5 --gpus 1` prints them as its line, the default
+    run embeds them as `secondary.c5`."""
     from torchmd_amd.builders import argon_forcefield, lj_box
+    from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import Integrator, maxwell_boltzmann
     from torchmd_amd.parameters import Parameters
-    from torchmd_amd.replicas import ReplicaFanout
     from torchmd_amd.systems import System
 
     nside = args.nside if args.nside != 32 else 100
@@ -128,46 +128,45 @@ def run_c5(args, rank, world, local_rank, device, launched):
     natoms = mol.numAtoms
     torch.manual_seed(1)
     vel0 = maxwell_boltzmann(par.masses, 85.0, 1)
-    fan = ReplicaFanout(total_replicas=world, device=device)
-    extra = {}
-    if world == 1:
-        from torchmd_amd.forces import Forces
-
-        s = System(natoms, 1, torch.float32, device)
-        s.set_positions(pos[:, :, None])
-        s.set_box(box)
-        s.set_velocities(vel0)
-        f = Forces(par, terms=["lj"], cutoff=CUTOFF, **({} if args.skin is None else {"skin": args.skin}))
-        f.compute(s.pos, s.box, s.forces)
-        integ = Integrator(s, f, TIMESTEP_FS, device, gamma=1.0, T=85.0)
-        integ.step(max(args.warmup, 1))
-        stride = timing_stride(args.steps)
-        f.enable_timing(s.pos, True, every=stride, limit=SHORT_TIMED if args.steps < 128 else 0, skip=1 if args.steps < 128 else 0)
-        f.read_timing(s.pos, reset=True)
-        st0 = f.stats(s.pos)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ekin, epot, temp = integ.step(args.steps)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        pair_ms, pair_launches = f.read_timing(s.pos, reset=True)
-        st1 = f.stats(s.pos)
-        pcut = f.count_pairs(s.pos, s.box)[0]
-        # (as in the C3 line: the timed launches also make the MD step -> SURVEY 8(d)'s whole-step bytes)
-        fused = st1["steps_in_pair_launch"] - st0["steps_in_pair_launch"] >= args.steps - 2
-        alg_bytes = 4.0 * pcut + (132.0 if fused else 28.0) * natoms
-        pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
-        achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
-        c5_traffic, c5_traffic_src = None, None
-        for name in ("r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json"):  # newest committed PMC pass of this configuration
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as fh:
-                    c5_traffic = float(json.load(fh)["hbm_bytes_per_launch"])
-                    c5_traffic_src = "profiles/" + name
-                break
-            except Exception:
-                continue
-        extra["roofline"] = {
+    s = System(natoms, 1, torch.float32, device)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    s.set_velocities(vel0)
+    f = Forces(par, terms=["lj"], cutoff=CUTOFF, **({} if args.skin is None else {"skin": args.skin}))
+    f.compute(s.pos, s.box, s.forces)
+    integ = Integrator(s, f, TIMESTEP_FS, device, gamma=1.0, T=85.0)
+    integ.step(max(args.warmup, 1))
+    stride = timing_stride(args.steps)
+    f.enable_timing(s.pos, True, every=stride, limit=SHORT_TIMED if args.steps < 128 else 0, skip=1 if args.steps < 128 else 0)
+    f.read_timing(s.pos, reset=True)
+    st0 = f.stats(s.pos)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ekin, epot, temp = integ.step(args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pair_ms, pair_launches = f.read_timing(s.pos, reset=True)
+    st1 = f.stats(s.pos)
+    pcut = f.count_pairs(s.pos, s.box)[0]
+    # (as in the C3 line: the timed launches also make the MD step -> SURVEY 8(d)'s whole-step bytes)
+    fused = st1["steps_in_pair_launch"] - st0["steps_in_pair_launch"] >= args.steps - 2
+    alg_bytes = 4.0 * pcut + (132.0 if fused else 28.0) * natoms
+    pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
+    achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
+    c5_traffic, c5_traffic_src = None, None
+    for name in C5_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                c5_traffic = float(json.load(fh)["hbm_bytes_per_launch"])
+                c5_traffic_src = "profiles/" + name
+            break
+        except Exception:
+            continue
+    out = {
+        "value": ns_per_day(args.steps, elapsed), "unit": "ns/day", "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f32", "natoms": natoms, "box": [float(x) for x in box],
+        "pairs_in_cutoff": pcut, "pair_interactions_per_s": pcut * args.steps / elapsed,
+        "roofline": {
             "kernel": "list_pair_fast_f32_kernel (fp32, LJ)" + (" with the MD step in the same launch (step blocks)" if fused else ""),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": c5_traffic, "traffic_source": c5_traffic_src,
@@ -177,16 +176,51 @@ def run_c5(args, rank, world, local_rank, device, launched):
             "avg_kernel_us": pair_avg_s * 1e6, "launches_timed": int(pair_launches),
             "alu": {"flops_per_launch": 30.0 * pcut, "achieved_tflops": 30.0 * pcut / pair_avg_s / 1e12 if pair_avg_s > 0 else 0.0,
                     "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "note": "~30 FLOP per LJ-only pair"},
-        }
-        extra["list"] = {"rebuilds_in_timed_region": int(st1["n_rebuilds"] - st0["n_rebuilds"]),
-                         "entries": int(st1["list_entries"]), "ncell": list(st1["ncell"]), "skin": st1["skin"]}
-        extra["temperature_K"] = [float(temp[0])]
-        if not args.no_cpu_baseline:
-            extra["cpu_baseline"] = cpu_baseline_c5(natoms)
-        f.close()
-    else:
-        from torchmd_amd.domain import DistTransport, DomainSet
+        },
+        "list": {"rebuilds_in_timed_region": int(st1["n_rebuilds"] - st0["n_rebuilds"]),
+                 "entries": int(st1["list_entries"]), "ncell": list(st1["ncell"]), "skin": st1["skin"]},
+        "temperature_K": [float(temp[0])],
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_c5(natoms, budget_s=cpu_budget_s)
+    f.close()
+    del s, f, integ
+    torch.cuda.empty_cache()
+    return out
 
+
+def c5_workload(natoms, box, world=1):
+    return (f"C5 synthetic argon box: {natoms} atoms, L={box[0]:.1f} A, cutoff 9 A, LJ only, Langevin 85 K gamma 1/ps, "
+            "timestep 1 fs" + ("; one brick per GPU, halo exchange over RCCL" if world > 1 else ""))
+
+
+def run_c5(args, rank, world, local_rank, device, launched):
+    """Config C5 of BASELINE.json: synthetic 10^6-atom Lennard-Jones (argon) box, cutoff 9 A, Langevin 85 K,
+    1 fs.  One GPU: the whole box on the single-domain engine.  N > 1: spatial domain decomposition, one brick
+    per rank, positions of the halo atoms exchanged over RCCL every step (torchmd_amd/domain.py); strong
+    scaling (the box is fixed)."""
+    import torch.distributed as dist
+
+    from torchmd_amd.replicas import ReplicaFanout
+
+    fan = ReplicaFanout(total_replicas=world, device=device)
+    extra = {}
+    if world == 1:
+        r = c5_single_gpu(args, device)
+        natoms, box, elapsed, pcut = r["natoms"], r["box"], r["ms_per_step"] * 1e-3 * args.steps, r["pairs_in_cutoff"]
+        extra = {k: r[k] for k in ("roofline", "list", "temperature_K", "cpu_baseline") if k in r}
+    else:
+        from torchmd_amd.builders import argon_forcefield, lj_box
+        from torchmd_amd.domain import DistTransport, DomainSet
+        from torchmd_amd.integrator import maxwell_boltzmann
+        from torchmd_amd.parameters import Parameters
+
+        nside = args.nside if args.nside != 32 else 100
+        mol, pos, box = lj_box(nside, seed=0)
+        par = Parameters(argon_forcefield(mol), mol, ["lj"], precision=torch.float32)
+        natoms = mol.numAtoms
+        torch.manual_seed(1)
+        vel0 = maxwell_boltzmann(par.masses, 85.0, 1)
         A, B = par.get_AB()
         ds = DomainSet(box, world, device, torch.float32, ["lj"], CUTOFF, A=A, B=B, skin=args.skin or 2.5,
                        transport=DistTransport())
@@ -216,9 +250,7 @@ def run_c5(args, rank, world, local_rank, device, launched):
         "value": ns_per_day(args.steps, elapsed), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C5 synthetic argon box: {natoms} atoms, L={box[0]:.1f} A, cutoff 9 A, LJ only, "
-                   "Langevin 85 K gamma 1/ps, timestep 1 fs" + ("; one brick per GPU, halo exchange over RCCL" if world > 1 else ""),
-                   "natoms": natoms, "timestep_fs": TIMESTEP_FS},
+        "config": {"workload": c5_workload(natoms, box, world), "natoms": natoms, "timestep_fs": TIMESTEP_FS},
         "pairs_in_cutoff": pcut,
         "pair_interactions_per_s": (pcut * args.steps / elapsed) if pcut else None,
     }
@@ -264,7 +296,7 @@ def cpu_baseline_c5(natoms_full, nside_sample=50, budget_s=15.0):
     ratio = mol.numAtoms / float(natoms_full)
     return {
         "value": ns_per_day(n, el) * ratio, "unit": "ns/day", "cores": torch.get_num_threads(), "kind": "port",
-        "s_per_step_sample": el / n,
+        "extrapolated": True, "s_per_step_sample": el / n,
         "source": "oracle (pinned port of the reference arithmetic; /root/reference does not exist on the GPU box)",
         "sample": f"{n} MD steps of a {mol.numAtoms}-atom argon box at the same density (oracle md_step, {len(pairs)} candidate "
         f"pairs, list build excluded); value = the sample's ns/day x {ratio:.4f} (atom ratio to the {natoms_full}-atom box: the "
@@ -346,6 +378,7 @@ def main():
     ap.add_argument("--nside", type=int, default=32, help="molecules per box edge (32 -> 98 304 atoms)")
     ap.add_argument("--relax-steps", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary C5 leg of the default run")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin in A (default: the library's)")
     ap.add_argument("--skin-weights", default="mass", choices=["mass", "none"],
                     help="per-atom Verlet skins by mass (default) or one skin for every atom")
@@ -514,9 +547,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(par, system, box)
         out["speedup_vs_cpu_baseline"] = out["ns_per_day_per_replica"] / out["cpu_baseline"]["value"]
+    forces.close()
+    if rank == 0 and world == 1 and args.nside == 32 and not args.no_secondary:
+        # Secondary configuration in the same line (headline keys untouched): BASELINE.json's config 5 on this one GPU —
+        # the 10^6-atom argon box on the single-domain engine, same --steps / --warmup.  A failure is recorded, not raised.
+        del system, forces, integ
+        torch.cuda.empty_cache()
+        try:
+            c5 = c5_single_gpu(args, device, cpu_budget_s=8.0)
+            c5["metric"] = "ns/day, 1M-atom Lennard-Jones box, 9 A cutoff, 1 GPU (the cpu_baseline is extrapolated from a 125k-atom sample)"
+            c5["config"] = {"workload": c5_workload(c5["natoms"], c5["box"]), "natoms": c5["natoms"], "timestep_fs": TIMESTEP_FS}
+            out["secondary"] = {"c5": c5}
+        except Exception as exc:  # noqa: BLE001
+            out["secondary"] = {"c5": {"error": f"{type(exc).__name__}: {exc}"[:500]}}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    forces.close()
     if launched:
         import torch.distributed as dist
 

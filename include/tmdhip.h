@@ -301,6 +301,16 @@ typedef struct tmdhip_comm tmdhip_comm;
 int tmdhip_comm_unique_id(const char *librccl_path, void *id_out);
 int tmdhip_comm_create(tmdhip_comm **out, const char *librccl_path, const void *id, int rank, int world);
 void tmdhip_comm_destroy(tmdhip_comm *comm);
+/* The same communicator over an IN-PROCESS transport (ABI 5): all `world` ranks live in one process on one device, one
+ * host thread per rank, each with a stream of its own.  An exchange is a rendezvous of the threads around device-side
+ * copies ordered by events (no RCCL, no second GPU): what lets tmdhip_dd_run execute at world 2 / 4 / 8 on a one-GPU
+ * box with the decisions it takes over RCCL.  Create one hub, then one communicator per rank (any thread); every
+ * rank's thread must take part in every exchange (tmdhip_comm_exchange / tmdhip_dd_run); a rank that stays away for
+ * 30 s breaks the hub (all later calls fail).  Destroy the communicators before the hub. */
+typedef struct tmdhip_local_hub tmdhip_local_hub;
+int tmdhip_local_hub_create(tmdhip_local_hub **out, int world);
+void tmdhip_local_hub_destroy(tmdhip_local_hub *hub);
+int tmdhip_comm_create_local(tmdhip_comm **out, tmdhip_local_hub *hub, int rank);
 /* One grouped exchange on `stream`: rows of `width` reals; the first send_counts_host[0] rows of send_dev go to
  * rank 0, the next send_counts_host[1] to rank 1, ...; recv_dev receives recv_counts_host[p] rows from rank p
  * in rank order (the layout of an all-to-all with split sizes, as ncclSend/ncclRecv pairs between the

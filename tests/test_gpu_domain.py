@@ -162,6 +162,85 @@ def test_native_exchange_and_step_loop_single_rank():
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_native_loop_at_world_2_4_8_on_one_gpu(world):
+    """The library's own brick loop (`tmdhip_dd_run`: kick/drift, halo pack, exchange into the halo rows, forces, the
+    asynchronous migration trigger with its max-reduction over the ranks) at world 2 / 4 / 8 on ONE GPU: one host
+    thread and one stream per rank, the ranks exchange through the library's in-process communicator
+    (`tmdhip_comm_create_local`: device copies ordered by events around a host barrier — the stand-in for RCCL where
+    there is one GPU).  (i) one grouped exchange from `world` threads equals the reference all-to-all; (ii) 40 hot NVE
+    steps with migrations equal the single-domain integrator (fp64: 1e-7 / 1e-7 / 1e-6) and (iii) the Python-driven
+    loop over the same kernels (same migration decisions; 1e-9)."""
+    import ctypes as C
+    import threading
+
+    from torchmd_amd import _lib as L
+    from torchmd_amd.domain import DomainSet, LocalTransport
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.systems import System
+
+    dev, dt = torch.device("cuda:0"), torch.float64
+    mol, pos, box, par = _system(22, dt)
+    n = mol.numAtoms
+    torch.manual_seed(3)
+    vel = maxwell_boltzmann(par.masses, 4000.0, 1)[0].numpy()
+    A, B = par.get_AB()
+    results = {}
+    for native in (True, False):
+        tr = LocalTransport(world, native_threads=native)
+        ds = DomainSet(box, world, dev, dt, ["lj"], 9.0, A=A, B=B, skin=1.0, transport=tr)
+        ds.scatter(pos, vel, par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
+        if native:  # (i) tmdhip_comm_exchange from one thread per rank
+            lib = L.load()
+            comms, streams = tr.native(dev)
+            sent = {r: d.pack_halo().clone() for r, d in ds.domains.items()}
+            counts = {r: d.plan.send_counts for r, d in ds.domains.items()}
+            want = ds._all_to_all("probe", sent, counts)
+            got = {r: torch.zeros_like(want[r]) for r in ds.domains}
+            torch.cuda.synchronize()
+            rcs = {}
+
+            def work(r):
+                sc = (C.c_int64 * world)(*counts[r])
+                rc = (C.c_int64 * world)(*[counts[src][r] for src in range(world)])
+                with torch.cuda.device(dev):
+                    rcs[r] = lib.tmdhip_comm_exchange(comms[r], L.dtype_code(dt), sent[r].data_ptr(), sc, got[r].data_ptr(),
+                                                      rc, 3, streams[r].cuda_stream)
+
+            ths = [threading.Thread(target=work, args=(r,)) for r in ds.domains]
+            [th.start() for th in ths]
+            [th.join() for th in ths]
+            torch.cuda.synchronize()
+            assert all(v == 0 for v in rcs.values()), rcs
+            for r in ds.domains:
+                assert got[r].shape[0] > 0 and torch.equal(got[r], want[r]), r
+        ds.compute_forces()
+        ds.step(25, timestep_fs=2.0)
+        ds.step(15, timestep_fs=2.0)
+        results[native] = ds.gather(n) + (ds.migrations,)
+        for d in ds.domains.values():
+            d.forces_engine.close()
+        tr.close()
+    P, V, F, mig = results[True]
+    assert mig >= 1
+    s = System(n, 1, dt, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    s.set_velocities(torch.tensor(vel)[None])
+    f = Forces(par, terms=["lj"], cutoff=9.0)
+    f.compute(s.pos, s.box, s.forces)
+    Integrator(s, f, 2.0, dev).step(40)
+    ep, ev, ef = (P - s.pos[0]).abs().max().item(), (V - s.vel[0]).abs().max().item(), (F - s.forces[0]).abs().max().item()
+    P0, V0, F0, mig0 = results[False]
+    same = torch.equal(P, P0) and torch.equal(V, V0) and torch.equal(F, F0)
+    print(f"world {world}: migrations {mig} (Python-driven loop: {mig0}), vs single domain max|dx| {ep:.2e} max|dv| {ev:.2e} "
+          f"max|dF| {ef:.2e}; bit-identical to the Python-driven loop: {same}")
+    assert ep < 1e-7 and ev < 1e-7 and ef < 1e-6
+    assert (P - P0).abs().max().item() < 1e-9 and (V - V0).abs().max().item() < 1e-9 and (F - F0).abs().max().item() < 1e-8
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_native_loop_over_rccl_ranks(world):
     """`tmdhip_comm_exchange` and `tmdhip_dd_run` between REAL ranks, one GPU each (tests/_dd_ranks.py under

@@ -2,7 +2,7 @@
 # A/B timing of differently built libraries on the GPU box: tools/ab.sh lib1.so lib2.so ... (bench, no CPU baseline)
 for lib in "$@"; do
   echo "== $lib"
-  TMDHIP_LIB=$PWD/$lib python bench.py --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | python -c "
+  TMDHIP_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-secondary ${BENCH_ARGS:-} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 l=d['list']

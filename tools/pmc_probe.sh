@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 [ -n "$LIB" ] && export TMDHIP_LIB=$R/$LIB
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 200 --warmup 50 --relax-steps 600 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 200 --warmup 50 --relax-steps 600 --no-cpu-baseline --no-secondary"
 i=0
 while read -r group; do
   [ -z "$group" ] && continue

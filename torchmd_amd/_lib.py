@@ -240,6 +240,9 @@ SIGNATURES = {
     ),
     "tmdhip_dd_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(DdDesc), C.POINTER(C.c_int32), C.c_void_p]),
     "tmdhip_dd_reset": (C.c_int, [C.c_void_p]),
+    "tmdhip_local_hub_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "tmdhip_local_hub_destroy": (None, [C.c_void_p]),
+    "tmdhip_comm_create_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]),
     "tmdhip_debug_build_timeline": (C.c_int, [C.c_void_p, C.c_size_t]),
 }
 

@@ -22,8 +22,12 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "pair_math.h"
@@ -170,10 +174,71 @@ int load_rccl(const char *path, RcclApi &api) {
 
 }  // namespace
 
+// ---- in-process transport: all ranks of the brick grid inside ONE process on ONE device ------------------------
+// What RCCL does between processes, between host threads: one thread per rank drives its brick's loop
+// (tmdhip_dd_run) on a stream of its own; an exchange is a rendezvous of the threads on the host (a reusable barrier)
+// around device-side copies ordered by events:
+//   every rank publishes {send buffer, counts} and records `ready` on its stream (its pack kernel is in front of it);
+//   barrier;  every rank makes its stream wait for the senders' `ready` events and copies its rows out of their send
+//   buffers into its own halo rows, then records `done`;  barrier;  every rank makes its stream wait for the `done` of
+//   the ranks that read from it, so that its next pack cannot overwrite rows still being copied.
+// The host threads only enqueue; nothing waits for the device.  A rank that does not arrive within 30 s (its loop
+// returned with an error) breaks the hub: every later call fails instead of hanging.
+// Purpose: the library's own step loop at world 2 / 4 / 8 on a one-GPU box (tests), with the same decisions
+// (migration trigger from the max over ranks) as over RCCL.
+struct LocalSlot {
+  const void *send = nullptr;
+  const int64_t *send_counts = nullptr;
+  float *red = nullptr;          // this rank's operand of the max reduction (device)
+  float *red_tmp = nullptr;      // hub-owned device word the rank reduces into before copying back
+  hipEvent_t ready = nullptr, done = nullptr;
+};
+
+struct tmdhip_local_hub {
+  int world = 1;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t phase = 0;
+  bool broken = false;
+  int attached = 0;
+  std::vector<LocalSlot> slot;
+  // false: somebody did not arrive (the hub is broken from then on)
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
+    const uint64_t my = phase;
+    if (++arrived == world) {
+      arrived = 0;
+      ++phase;
+      cv.notify_all();
+      return true;
+    }
+    if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return phase != my || broken; })) {
+      broken = true;
+      cv.notify_all();
+      return false;
+    }
+    return !broken;
+  }
+};
+
+struct MaxPtrs {
+  const float *p[64];
+};
+__global__ void local_max_kernel(MaxPtrs src, int world, float *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float v = src.p[0][0];
+    for (int r = 1; r < world; ++r) v = fmaxf(v, src.p[r][0]);
+    *out = v;
+  }
+}
+
 // halo-exchange communicator of one rank + the state of the asynchronous migration trigger
 struct tmdhip_comm {
-  RcclApi api;
+  RcclApi api;                       // RCCL transport (hub == nullptr)
   ncclComm_t comm = nullptr;
+  tmdhip_local_hub *hub = nullptr;   // in-process transport
   int rank = 0, world = 1;
   // displacement read-back: two pinned slots / events used alternately; `pending` = slot `cur` holds the
   // maximum squared displacement measured `at` steps after the last migration
@@ -192,10 +257,64 @@ struct tmdhip_comm {
 
 namespace {
 
+int local_exchange_rows(tmdhip_comm *c, size_t esz, const void *send, const int64_t *send_counts, void *recv,
+                        const int64_t *recv_counts, int width, hipStream_t st) {
+  tmdhip_local_hub *h = c->hub;
+  LocalSlot &me = h->slot[c->rank];
+  me.send = send;
+  me.send_counts = send_counts;
+  TMD_HIP(hipEventRecord(me.ready, st));
+  if (!h->barrier()) return fail("in-process communicator: a rank did not arrive at the exchange");
+  size_t ro = 0;
+  for (int p = 0; p < c->world; ++p) {
+    const LocalSlot &src = h->slot[p];
+    const size_t n = (size_t)src.send_counts[c->rank] * width;  // what p sends to me
+    if (n != (size_t)recv_counts[p] * width) {
+      h->barrier();
+      return fail("in-process communicator: send / receive counts of ranks " + std::to_string(p) + " and " +
+                  std::to_string(c->rank) + " disagree");
+    }
+    if (n) {
+      size_t so = 0;
+      for (int q = 0; q < c->rank; ++q) so += (size_t)src.send_counts[q] * width;
+      if (p != c->rank) TMD_HIP(hipStreamWaitEvent(st, src.ready, 0));
+      TMD_HIP(hipMemcpyAsync((char *)recv + ro * esz, (const char *)src.send + so * esz, n * esz, hipMemcpyDeviceToDevice, st));
+    }
+    ro += n;
+  }
+  TMD_HIP(hipEventRecord(me.done, st));
+  if (!h->barrier()) return fail("in-process communicator: a rank did not arrive behind the exchange");
+  for (int p = 0; p < c->world; ++p)  // my send buffer may be rewritten once its readers are through
+    if (p != c->rank && send_counts[p] > 0) TMD_HIP(hipStreamWaitEvent(st, h->slot[p].done, 0));
+  return 0;
+}
+
+int local_allreduce_max(tmdhip_comm *c, float *buf, hipStream_t st) {
+  tmdhip_local_hub *h = c->hub;
+  LocalSlot &me = h->slot[c->rank];
+  me.red = buf;
+  TMD_HIP(hipEventRecord(me.ready, st));
+  if (!h->barrier()) return fail("in-process communicator: a rank did not arrive at the reduction");
+  MaxPtrs src;
+  for (int p = 0; p < c->world; ++p) {
+    src.p[p] = h->slot[p].red;
+    if (p != c->rank) TMD_HIP(hipStreamWaitEvent(st, h->slot[p].ready, 0));
+  }
+  hipLaunchKernelGGL(local_max_kernel, dim3(1), dim3(64), 0, st, src, c->world, me.red_tmp);
+  TMD_HIP(hipGetLastError());
+  TMD_HIP(hipEventRecord(me.done, st));
+  if (!h->barrier()) return fail("in-process communicator: a rank did not arrive behind the reduction");
+  for (int p = 0; p < c->world; ++p)  // everybody has read my operand: now it may receive the result
+    if (p != c->rank) TMD_HIP(hipStreamWaitEvent(st, h->slot[p].done, 0));
+  TMD_HIP(hipMemcpyAsync(buf, me.red_tmp, sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 int exchange_rows(tmdhip_comm *c, int dtype, const void *send, const int64_t *send_counts, void *recv,
                   const int64_t *recv_counts, int width, hipStream_t st) {
   const ncclDataType_t dt = dtype == TMDHIP_F32 ? ncclFloat32 : ncclFloat64;
   const size_t esz = dtype == TMDHIP_F32 ? 4 : 8;
+  if (c->hub) return local_exchange_rows(c, esz, send, send_counts, recv, recv_counts, width, st);
   TMD_NCCL(c, c->api.group_start());
   size_t so = 0, ro = 0;
   for (int p = 0; p < c->world; ++p) {
@@ -206,6 +325,22 @@ int exchange_rows(tmdhip_comm *c, int dtype, const void *send, const int64_t *se
     ro += nr;
   }
   TMD_NCCL(c, c->api.group_end());
+  return 0;
+}
+
+// in-place maximum over the ranks of one float on the device
+int allreduce_max(tmdhip_comm *c, void *buf, hipStream_t st) {
+  if (c->world == 1) return 0;
+  if (c->hub) return local_allreduce_max(c, (float *)buf, st);
+  TMD_NCCL(c, c->api.all_reduce(buf, buf, 1, ncclFloat32, ncclMax, c->comm, st));
+  return 0;
+}
+
+int comm_alloc_trigger(tmdhip_comm *c) {
+  if (hipHostMalloc((void **)&c->host_flag, 2 * sizeof(float), hipHostMallocDefault) != hipSuccess)
+    return fail("tmdhip_comm_create: pinned allocation failed");
+  for (auto &e : c->ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("tmdhip_comm_create: event creation failed");
   return 0;
 }
 
@@ -240,10 +375,50 @@ int tmdhip_comm_create(tmdhip_comm **out, const char *librccl_path, const void *
   std::memcpy(&uid, id, sizeof(uid));
   const ncclResult_t r = c->api.comm_init_rank(&c->comm, world, uid, rank);
   if (r != ncclSuccess) return bail(fail(std::string("ncclCommInitRank: ") + c->api.error_string(r)));
-  if (hipHostMalloc((void **)&c->host_flag, 2 * sizeof(float), hipHostMallocDefault) != hipSuccess)
-    return bail(fail("tmdhip_comm_create: pinned allocation failed"));
-  for (auto &e : c->ev)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail("tmdhip_comm_create: event creation failed"));
+  if (comm_alloc_trigger(c)) return bail(-1);
+  *out = c;
+  return 0;
+}
+
+int tmdhip_local_hub_create(tmdhip_local_hub **out, int world) {
+  if (!out) return fail("tmdhip_local_hub_create: null argument");
+  if (world < 1 || world > 64) return fail("tmdhip_local_hub_create: world size must lie in 1..64");
+  tmdhip_local_hub *h = new tmdhip_local_hub();
+  h->world = world;
+  h->slot.resize(world);
+  for (auto &s : h->slot) {
+    if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&s.red_tmp, sizeof(float)) != hipSuccess) {
+      tmdhip_local_hub_destroy(h);
+      return fail("tmdhip_local_hub_create: event / buffer creation failed");
+    }
+  }
+  *out = h;
+  return 0;
+}
+
+void tmdhip_local_hub_destroy(tmdhip_local_hub *h) {
+  if (!h) return;
+  for (auto &s : h->slot) {
+    if (s.ready) (void)hipEventDestroy(s.ready);
+    if (s.done) (void)hipEventDestroy(s.done);
+    if (s.red_tmp) (void)hipFree(s.red_tmp);
+  }
+  delete h;
+}
+
+int tmdhip_comm_create_local(tmdhip_comm **out, tmdhip_local_hub *hub, int rank) {
+  if (!out || !hub) return fail("tmdhip_comm_create_local: null argument");
+  if (rank < 0 || rank >= hub->world) return fail("tmdhip_comm_create_local: bad rank");
+  tmdhip_comm *c = new tmdhip_comm();
+  c->hub = hub;
+  c->rank = rank;
+  c->world = hub->world;
+  if (comm_alloc_trigger(c)) {
+    tmdhip_comm_destroy(c);
+    return -1;
+  }
   *out = c;
   return 0;
 }
@@ -319,7 +494,7 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
       }
       const bool first_check = !c->pending;  // first boundary after a migration: nothing measured yet
       c->cur ^= 1;
-      if (c->world > 1) TMD_NCCL(c, c->api.all_reduce(d->disp2_dev, d->disp2_dev, 1, ncclFloat32, ncclMax, c->comm, st));
+      TMD_TRY(allreduce_max(c, d->disp2_dev, st));
       TMD_HIP(hipMemcpyAsync(&c->host_flag[c->cur], d->disp2_dev, sizeof(float), hipMemcpyDeviceToHost, st));
       TMD_HIP(hipEventRecord(c->ev[c->cur], st));
       c->pending = true;

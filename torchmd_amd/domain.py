@@ -248,11 +248,49 @@ class DistTransport:
 
 class LocalTransport:
     """All ranks in one process (round-robin driven by DomainSet): the same calls, served from a shared
-    mailbox.  Used to validate the decomposition on a single GPU."""
+    mailbox.  Used to validate the decomposition on a single GPU.
 
-    def __init__(self, world):
+    `native_threads=True`: between migrations every brick's step loop is enqueued from C (`tmdhip_dd_run`) by a host
+    thread of its own, on a stream of its own, and the bricks exchange their halo rows through the library's
+    in-process communicator (`tmdhip_comm_create_local`: device copies ordered by events, a host barrier instead of
+    RCCL) — the code path of a multi-GPU run at world 2 / 4 / 8 on a one-GPU box."""
+
+    def __init__(self, world, native_threads=False):
         self.world = world
         self.box = {}
+        self.native_threads = native_threads
+        self._hub = None
+        self._comms = self._streams = None
+
+    def native(self, device):
+        """(communicators, streams), one per rank, created on first use."""
+        import ctypes as C
+
+        from . import _lib as L
+
+        if self._comms is None:
+            lib = L.load()
+            hub = C.c_void_p()
+            with torch.cuda.device(device):
+                L.check(lib.tmdhip_local_hub_create(C.byref(hub), self.world), "tmdhip_local_hub_create")
+                comms = []
+                for r in range(self.world):
+                    h = C.c_void_p()
+                    L.check(lib.tmdhip_comm_create_local(C.byref(h), hub, r), "tmdhip_comm_create_local")
+                    comms.append(h)
+                self._streams = [torch.cuda.Stream(device) for _ in range(self.world)]
+            self._hub, self._comms = hub, comms
+        return self._comms, self._streams
+
+    def close(self):
+        if self._comms is not None:
+            from . import _lib as L
+
+            lib = L.load()
+            for h in self._comms:
+                lib.tmdhip_comm_destroy(h)
+            lib.tmdhip_local_hub_destroy(self._hub)
+        self._hub = self._comms = self._streams = None
 
     def post(self, key, rank, value):
         self.box.setdefault(key, {})[rank] = value
@@ -537,6 +575,11 @@ class DomainSet:
             from . import _lib as L
 
             L.check(L.load().tmdhip_dd_reset(self.transport.native()))
+        if self.local and getattr(self.transport, "_comms", None):
+            from . import _lib as L
+
+            for h in self.transport._comms:
+                L.check(L.load().tmdhip_dd_reset(h))
         self._exchange(static=True)
 
     # -- dynamics -------------------------------------------------------------------------------
@@ -571,6 +614,8 @@ class DomainSet:
         comm = None if self.local else self.transport.native()
         if comm is not None:
             return self._step_native(comm, niter, dt, gamma, vnoise if T else None, seed)
+        if self.local and self.transport.native_threads and self.device.type == "cuda":
+            return self._step_native_threads(niter, dt, gamma, vnoise if T else None, seed)
         for it in range(niter):
             for d in self.domains.values():
                 dd_step(d, 2 if it == 0 else 3)
@@ -584,6 +629,95 @@ class DomainSet:
             for d in self.domains.values():
                 dd_step(d, 1)
 
+    def _dd_desc(self, d, recv_counts, remaining, first, dt, gamma, vnoise, seed):
+        """The `tmdhip_dd_desc` of one brick (+ the ctypes arrays it points into, which must outlive the call)."""
+        import ctypes as C
+
+        from . import _lib as L
+
+        eng = d.forces_engine._engine(d.local_pos)
+        if not eng.stores_forces:
+            raise RuntimeError("domain decomposition needs the cell-list engine (brick too small)")
+        vc = 0
+        if vnoise is not None:
+            if getattr(d, "_vc_key", None) != (vnoise, d.nown, id(d.vcoeff_unit)):
+                d._vc = (d.vcoeff_unit * vnoise).contiguous()
+                d._vc_key = (vnoise, d.nown, id(d.vcoeff_unit))
+            vc = d._vc.data_ptr()
+        sc = (C.c_int64 * self.grid.world)(*d.plan.send_counts)
+        rc_ = (C.c_int64 * self.grid.world)(*recv_counts)
+        desc = L.DdDesc(
+            struct_size=C.sizeof(L.DdDesc), dtype=L.dtype_code(self.dtype), niter=remaining, first_phases=first,
+            check_every=self.check_every, nown=d.nown, nhalo=d.local_pos.shape[1] - d.nown,
+            pos_dev=d.local_pos.data_ptr(), vel_dev=d.vel.data_ptr(), forces_dev=d.local_forces.data_ptr(),
+            mass_dev=d.masses.data_ptr(), vcoeff_dev=vc, ref_dev=d.ref.data_ptr(), disp2_dev=d.disp2.data_ptr(),
+            dt=dt, gamma=gamma, seed=seed + 7919 * d.rank, step0=self._nstep, nsend=len(d.send_index32),
+            send_index_dev=d.send_index32.data_ptr(), send_shift_dev=d.send_shift.data_ptr(),
+            send_buf_dev=d.send_buf.data_ptr(), send_counts_host=C.addressof(sc), recv_counts_host=C.addressof(rc_),
+            skin=d.skin, since_migration=self._since_migration,
+        )
+        return eng, desc, (sc, rc_)
+
+    def _step_native_threads(self, niter, dt, gamma, vnoise, seed):
+        """All bricks in this process, each brick's loop enqueued from C by a host thread of its own over the
+        in-process communicator (`LocalTransport(native_threads=True)`); Python takes over for a migration."""
+        import ctypes as C
+        import threading
+
+        from . import _lib as L
+
+        lib = L.load()
+        comms, streams = self.transport.native(self.device)
+        world = self.grid.world
+        remaining, first = niter, 2
+        while True:
+            jobs = {}
+            for r, d in self.domains.items():
+                recv_counts = [self.domains[src].plan.send_counts[r] for src in range(world)]
+                jobs[r] = self._dd_desc(d, recv_counts, remaining, first, dt, gamma, vnoise, seed)
+            torch.cuda.synchronize(self.device)  # the ranks' streams do not order themselves behind the default stream
+            results = {}
+
+            def work(r):
+                eng, desc, _keep = jobs[r]
+                done = C.c_int32(0)
+                try:
+                    with torch.cuda.device(self.device):
+                        rc = lib.tmdhip_dd_run(eng.ctx, comms[r], C.byref(desc), C.byref(done), streams[r].cuda_stream)
+                    results[r] = (rc, done.value, L.last_error() if rc < 0 else "")
+                except Exception as exc:  # noqa: BLE001
+                    results[r] = (-99, 0, repr(exc))
+
+            threads = [threading.Thread(target=work, args=(r,)) for r in self.domains]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            torch.cuda.synchronize(self.device)
+            bad = {r: v for r, v in results.items() if v[0] < 0}
+            if bad:
+                raise RuntimeError(f"tmdhip_dd_run failed on ranks {sorted(bad)}: {next(iter(bad.values()))[2]}")
+            rcs, dones = {v[0] for v in results.values()}, {v[1] for v in results.values()}
+            if len(rcs) != 1 or len(dones) != 1:
+                raise RuntimeError(f"the ranks of the brick grid disagree about the migration: {results}")
+            rc, done = rcs.pop(), dones.pop()
+            for d in self.domains.values():
+                d.forces = d.local_forces[0, : d.nown]
+            self._nstep += done
+            self._since_migration += done + (1 if rc == 1 else 0)
+            remaining -= done
+            if rc == 0:
+                break
+            self.migrate()  # the iteration that has already drifted: new bricks, new halo, then its forces
+            self.compute_forces()
+            self._nstep += 1
+            remaining -= 1
+            first = 3
+        for d in self.domains.values():
+            if not d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos):
+                raise RuntimeError("a neighbour list of a brick was truncated during the batch (capacity has been grown): "
+                                   "repeat the batch")
+
     def _step_native(self, comm, niter, dt, gamma, vnoise, seed):
         """`niter` iterations enqueued from C (`tmdhip_dd_run`: RCCL send/recv on the compute stream); Python
         only takes over for a migration."""
@@ -596,27 +730,7 @@ class DomainSet:
         remaining, first = niter, 2
         done = C.c_int32(0)
         while True:
-            eng = d.forces_engine._engine(d.local_pos)
-            if not eng.stores_forces:
-                raise RuntimeError("domain decomposition needs the cell-list engine (brick too small)")
-            vc = 0
-            if vnoise is not None:
-                if getattr(d, "_vc_key", None) != (vnoise, d.nown, id(d.vcoeff_unit)):
-                    d._vc = (d.vcoeff_unit * vnoise).contiguous()
-                    d._vc_key = (vnoise, d.nown, id(d.vcoeff_unit))
-                vc = d._vc.data_ptr()
-            sc = (C.c_int64 * self.grid.world)(*d.plan.send_counts)
-            rc_ = (C.c_int64 * self.grid.world)(*self._recv_counts["halo"])
-            desc = L.DdDesc(
-                struct_size=C.sizeof(L.DdDesc), dtype=L.dtype_code(self.dtype), niter=remaining, first_phases=first,
-                check_every=self.check_every, nown=d.nown, nhalo=d.local_pos.shape[1] - d.nown,
-                pos_dev=d.local_pos.data_ptr(), vel_dev=d.vel.data_ptr(), forces_dev=d.local_forces.data_ptr(),
-                mass_dev=d.masses.data_ptr(), vcoeff_dev=vc, ref_dev=d.ref.data_ptr(), disp2_dev=d.disp2.data_ptr(),
-                dt=dt, gamma=gamma, seed=seed + 7919 * d.rank, step0=self._nstep, nsend=len(d.send_index32),
-                send_index_dev=d.send_index32.data_ptr(), send_shift_dev=d.send_shift.data_ptr(),
-                send_buf_dev=d.send_buf.data_ptr(), send_counts_host=C.addressof(sc), recv_counts_host=C.addressof(rc_),
-                skin=d.skin, since_migration=self._since_migration,
-            )
+            eng, desc, _keep = self._dd_desc(d, self._recv_counts["halo"], remaining, first, dt, gamma, vnoise, seed)
             with torch.cuda.device(self.device):
                 rc = L.check(lib.tmdhip_dd_run(eng.ctx, comm, C.byref(desc), C.byref(done),
                                                torch.cuda.current_stream(self.device).cuda_stream), "tmdhip_dd_run")
