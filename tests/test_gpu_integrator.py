@@ -544,11 +544,15 @@ def test_rebuild_chain_left_out_with_two_list_replicas(monkeypatch):
     assert (p0[0] - p0[1]).abs().max().item() > 1e-3
 
 
-def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
+@pytest.mark.parametrize("lookahead", [False, True])
+def test_aged_lists_hold_every_pair_inside_the_cutoff(lookahead, monkeypatch):
     """Exactness of the skin policy over a trajectory: per-atom skins by mass, skins sized from the velocities at
     every rebuild and rebuild chains left out.  After every few MD steps the number of pairs inside the cutoff
     found through the CURRENT list (aged by several steps, no rebuild forced) must equal the oracle's count at
-    those positions — a pair missing from a list would show — and the forces must be those of a fresh evaluation."""
+    those positions — a pair missing from a list would show — and the forces must be those of a fresh evaluation.
+    `lookahead`: with the next list built ahead of its use on the second stream from a snapshot of the positions and
+    adopted four steps later (size gate opened for this box): the lists in use are then older than their rebuild
+    interval suggests, and the test that guards them is the adoption kernel's."""
     from oracle import torchmd_oracle as orc
     from torchmd_amd.builders import tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
@@ -564,6 +568,11 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
     monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
     monkeypatch.setenv("TMDHIP_CHAIN_SKIP", "1")
     monkeypatch.delenv("TMDHIP_VSKIN", raising=False)
+    if lookahead:
+        monkeypatch.setenv("TMDHIP_DEBUG_LOOKAHEAD_MIN_ENTRIES", "1")
+        monkeypatch.delenv("TMDHIP_LOOKAHEAD", raising=False)
+    else:
+        monkeypatch.setenv("TMDHIP_LOOKAHEAD", "0")
     s = System(mol.numAtoms, 1, dt, dev)
     s.set_positions(pos[:, :, None])
     s.set_box(box)
@@ -589,10 +598,66 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
         assert err < 2e-3, (k, err)
     st = f.stats(s.pos)
     assert aged >= 3 and st["chains_skipped"] > 20 and st["overflow"] == 0
+    print(f"lookahead {lookahead}: rebuilds {st['n_rebuilds']}, look-ahead builds {st['lookahead_builds']} (adopted "
+          f"{st['lookahead_adopted']}), chains skipped {st['chains_skipped']}")
+    if lookahead:
+        assert st["lookahead_adopted"] >= 8 and st["lookahead_builds"] - st["lookahead_adopted"] <= 1, st
+    else:
+        assert st["lookahead_builds"] == 0
     fresh = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist", skin_weights=None)
     F2 = torch.zeros_like(s.pos)
     fresh.compute(s.pos, s.box, F2)
     assert (F2 - s.forces).abs().max().item() < 2e-3
+
+
+@pytest.mark.gpu
+def test_lookahead_lists_are_deterministic_and_equal_with_and_without_the_fused_step(monkeypatch):
+    """Look-ahead list builds (second stream, adopted a fixed number of steps after their snapshot): which step starts
+    and which adopts a list follows from device-side reports the paced host reads with a fixed lag — not from timing —
+    so a run is reproducible bit for bit, and the fused launch (step blocks) and the separate integrator kernel take
+    the same decisions: identical trajectories, with rebuild counts that show the look-ahead lists were used."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(14, seed=4)  # 8 232 atoms
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    monkeypatch.setenv("TMDHIP_LPA", "8")
+    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    monkeypatch.setenv("TMDHIP_DEBUG_LOOKAHEAD_MIN_ENTRIES", "1")
+    monkeypatch.delenv("TMDHIP_LOOKAHEAD", raising=False)
+    torch.manual_seed(3)
+    vel0 = maxwell_boltzmann(par.masses, 300.0, 1)
+
+    def run(fused):
+        monkeypatch.setenv("TMDHIP_FUSED_STEP", "1" if fused else "0")
+        s = System(mol.numAtoms, 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        s.set_velocities(vel0)
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        f.compute(s.pos, s.box, s.forces)
+        torch.manual_seed(9)
+        integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+        res = [integ.step(50), integ.step(7), integ.step(43)]
+        return s.pos.cpu(), s.vel.cpu(), s.forces.cpu(), res, f.stats(s.pos)
+
+    a = run(True)
+    b = run(True)
+    c = run(False)
+    for other in (b, c):
+        assert torch.equal(a[0], other[0]) and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
+        for x, y in zip(a[3], other[3]):
+            for u, v in zip(x, y):
+                assert np.array_equal(np.asarray(u), np.asarray(v))
+    st = a[4]
+    assert st["lookahead_adopted"] >= 5 and st["overflow"] == 0 and st["fused_step_timeouts"] == 0, st
+    assert a[4]["lookahead_adopted"] == c[4]["lookahead_adopted"] and a[4]["n_rebuilds"] == c[4]["n_rebuilds"]
+    assert a[4]["steps_in_pair_launch"] == 97 and c[4]["steps_in_pair_launch"] == 0
 
 
 @pytest.mark.gpu

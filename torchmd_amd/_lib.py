@@ -162,6 +162,8 @@ class Stats(C.Structure):
         ("chains_skipped", C.c_int64),
         ("steps_in_pair_launch", C.c_int64),
         ("fused_step_timeouts", C.c_int64),
+        ("lookahead_builds", C.c_int64),
+        ("lookahead_adopted", C.c_int64),
     ]
 
 
