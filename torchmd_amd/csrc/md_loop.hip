@@ -170,20 +170,25 @@ constexpr double kChainSkipNear = 0.75;  // "near": beyond this fraction of the 
                                          // skin 1.2: 2.2 x the largest per-step move seen in the water box, 9.5
                                          // standard deviations of a hydrogen's thermal velocity at 300 K)
 
-// ---- look-ahead list builds (Replica::shadow) ----------------------------------------------------------------------
-// A list build is 158 us at C3 and used to run alone between two pair launches, every ~11 steps: 14.5 us per step, while
-// the pair launches themselves leave more than half of the VALU issue slots idle.  Now the host starts the NEXT list's
-// build early — when the displacement test reports the first atom beyond kLookaheadFrac of its limit — from a snapshot
-// of the current positions into the replica's second buffer set: binning on the compute stream (4 short launches), the
-// build kernel on a second stream, concurrently with the pair launches of the next kLookaheadSteps steps, which keep
-// using the old list.  Then the new list is adopted at a launch boundary (adopt_list_kernel: current positions in the
-// new cell order + the displacement test against the new reference positions, so the list's age is charged to its
-// skin by the same test that guards every list; the buffer sets swap).  The number of steps is fixed, not "when the
-// build is done": which step adopts must not depend on timing, or trajectories would not be reproducible; if the build
-// is late the compute stream waits for it.  The old list's own rebuild chain stays in place as before (a device-side
-// rebuild request before the adoption is served synchronously, or flagged as a violation where the chain was left out).
-// TMDHIP_LOOKAHEAD = "0" (off) | "frac,steps".
-constexpr int64_t kLookaheadMinEntries = 20'000'000;  // list slots from which the build is worth hiding
+// ---- look-ahead list builds (Replica::shadow): OPT-IN, measured slower on MI355X ------------------------------------
+// A list build is 158 us at C3 and runs alone between two pair launches, every ~11 steps: 14.5 us per step, while the
+// pair launches leave more than half of the VALU issue slots idle.  The idea: start the NEXT list's build early — when
+// the displacement test reports the first atom beyond `frac` of its limit — from a snapshot of the current positions
+// into the replica's second buffer set: binning on the compute stream (4 short launches), the build kernel on a second
+// stream, concurrently with the pair launches of the next `steps` steps, which keep using the old list.  Then the new
+// list is adopted at a launch boundary (adopt_list_kernel: current positions in the new cell order + the displacement
+// test against the new reference positions, so the list's age is charged to its skin by the same test that guards
+// every list; the buffer sets swap).  The number of steps is fixed, not "when the build is done": which step adopts
+// must not depend on timing, or trajectories would not be reproducible; if the build is late the compute stream waits.
+// The old list's own rebuild chain stays in place (a device-side rebuild request before the adoption is served
+// synchronously, or flagged as a violation where the chain was left out).
+// MEASURED (round 4, C3): correct (exact pair counts, reproducible trajectories) and 40 % SLOWER — 62.3 ->
+// 89 us per step at "0.55,4".  The pair kernel's five waves per SIMD hold 480 of the 512 VGPRs, so a build wave only
+// becomes resident where a pair wave retires: the two kernels time-slice the SIMDs instead of sharing them (pair
+// launches 45 -> 64-69 us while a build is in flight; a cycle of 5.1 steps costs exactly one build more than the
+// same steps without one), and a list that is adopted at age `steps` is retired `steps` earlier: a build every 5.1
+// instead of every 10.9 steps.  Hence off unless TMDHIP_LOOKAHEAD = "frac,steps" asks for it (e.g. "0.55,4").
+constexpr int64_t kLookaheadMinEntries = 20'000'000;  // list slots from which the build would be worth hiding
 constexpr double kLookaheadFrac = 0.55;
 constexpr int kLookaheadSteps = 4;
 
@@ -231,13 +236,13 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   ctx->no_fused_once = false;
   double la_frac = kLookaheadFrac;
   int la_steps = kLookaheadSteps;
-  bool la_on = true;
+  bool la_on = false;
   if (const char *e = std::getenv("TMDHIP_LOOKAHEAD")) {
     double fr = 0;
     int k = 0;
     const int got = std::sscanf(e, "%lf,%d", &fr, &k);
-    if (got >= 1 && fr <= 0) la_on = false;
-    if (got >= 1 && fr > 0 && fr < 1) la_frac = fr;
+    la_on = got >= 1 && fr > 0 && fr < 1;
+    if (la_on) la_frac = fr;
     if (got == 2 && k >= 1 && k <= 64) la_steps = k;
   }
   const char *e_lamin = std::getenv("TMDHIP_DEBUG_LOOKAHEAD_MIN_ENTRIES");
