@@ -657,7 +657,10 @@ def test_lookahead_lists_are_deterministic_and_equal_with_and_without_the_fused_
     st = a[4]
     assert st["lookahead_adopted"] >= 5 and st["overflow"] == 0 and st["fused_step_timeouts"] == 0, st
     assert a[4]["lookahead_adopted"] == c[4]["lookahead_adopted"] and a[4]["n_rebuilds"] == c[4]["n_rebuilds"]
-    assert a[4]["steps_in_pair_launch"] == 97 and c[4]["steps_in_pair_launch"] == 0
+    # (97 interior steps; more if a batch was rewound — the unrelaxed lattice start is hot enough for an adoption test to fail — which
+    # must then have happened in every run alike)
+    assert a[4]["steps_in_pair_launch"] >= 97 and a[4]["steps_in_pair_launch"] == b[4]["steps_in_pair_launch"]
+    assert c[4]["steps_in_pair_launch"] == 0
 
 
 @pytest.mark.gpu
