@@ -652,6 +652,66 @@ def test_every_lanes_per_atom_variant(lpa, monkeypatch):
         assert f.count_pairs(pd, bd) == npairs
 
 
+@pytest.mark.parametrize("case", ["water-4", "water-8", "water-32", "lj-4", "thrombin-open"])
+def test_padded_list_rows_are_bit_identical(case, monkeypatch):
+    """Padded rows (pad_rows_kernel): the padding slots of every wave group point at a dummy record out of reach and the
+    lean fp32 kernel runs every group unchecked.  A padding slot contributes exactly 0 and the real entries see the
+    same arithmetic in the same order, so forces and energies must equal the unpadded list's (TMDHIP_PAD_ROWS=0) bit
+    for bit — plain evaluations and along an MD trajectory (fused pair + step launches, device-side rebuilds).  Water:
+    periodic, reaction field; the LJ box: the plain loop of the LJ-only variants; thrombin: open boundaries (dummies
+    10^6 A out) and the switching-free protein terms."""
+    from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    kind, lanes = case.split("-")
+    if kind == "thrombin":
+        g = load("thrombin")
+        par = GoldenParameters(g, dt)
+        pos, box = np.asarray(g["pos"], dtype=np.float64), np.zeros(3)
+        terms, kw, lanes = ALL_TERMS, dict(cutoff=9.0), "64"
+    elif kind == "water":
+        mol, pos, box = tip3p_box(14, seed=23)
+        terms = ["lj", "electrostatics", "bonds", "angles"]
+        par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+        kw = dict(cutoff=9.0, rfa=True)
+    else:
+        mol, pos, box = lj_box(22, seed=5)
+        terms = ["lj"]
+        par = Parameters(argon_forcefield(mol), mol, terms, precision=dt)
+        kw = dict(cutoff=9.0)
+    monkeypatch.setenv("TMDHIP_LPA", lanes)
+    torch.manual_seed(5)
+    vel0 = maxwell_boltzmann(par.masses, 300.0, 1)
+
+    def run(pad):
+        monkeypatch.setenv("TMDHIP_PAD_ROWS", pad)
+        s = System(pos.shape[0], 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        s.set_velocities(vel0)
+        f = Forces(par, terms=terms, algorithm="celllist", **kw)
+        e0 = f.compute(s.pos, s.box, s.forces, returnDetails=True)
+        F0 = s.forces.clone().cpu()
+        torch.manual_seed(9)
+        res = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0).step(60)
+        st = f.stats(s.pos)
+        out = (e0[0], F0, s.pos.cpu(), s.forces.cpu(), res, st["n_rebuilds"], st["list_entries"], f.count_pairs(s.pos, s.box))
+        f.close()
+        return out
+
+    a, b = run("1"), run("0")
+    assert a[0] == b[0], (a[0], b[0])
+    assert torch.isfinite(a[2]).all()
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for x, y in zip(a[4], b[4]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert a[5] == b[5] and a[5] >= 2 and a[6] == b[6] and a[7] == b[7]
+
+
 def test_box_change_and_capacity_growth():
     """(a) changing the box between calls re-plans the cell grid; (b) a denser configuration makes a
     device-side rebuild overflow the list capacity: tmdhip_check reports it, the capacity grows and the

@@ -142,6 +142,21 @@ bool plan_grid(const tmdhip_ctx *ctx, const double *box, const double *lo, const
   return false;
 }
 
+// Padded list rows (pad_rows_kernel): fp32 contexts whose entries can address the two dummy records with bits 20..22
+// of the slot clear, in a box where one of the dummies is always out of reach — they are half a box diagonal apart, so
+// one of them is >= a quarter of the diagonal from any atom at build time, and an atom moves less than one skin before
+// the next build.  A box with an open dimension has them 10^6 A out.  TMDHIP_PAD_ROWS=0 switches the padding off.
+bool plan_pad_rows(const tmdhip_ctx *ctx, const double *box) {
+  const char *e = std::getenv("TMDHIP_PAD_ROWS");  // (read at every re-plan: tests switch it between two evaluations)
+  if ((e && std::atoi(e) == 0) || ctx->d.dtype != TMDHIP_F32 || (int64_t)ctx->d.natoms + 2 > (1 << 20)) return false;
+  double diag2 = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (!(box[k] > 0)) return true;
+    diag2 += box[k] * box[k];
+  }
+  return 0.25 * std::sqrt(diag2) > ctx->rlist + 2.0 * ctx->skin;
+}
+
 template <typename R>
 int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   using R4 = typename Vec<R>::T4;
@@ -152,8 +167,9 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.order_tmp.ensure(sizeof(int) * n));
   TMD_TRY(rp.order.ensure(sizeof(int) * n));
   TMD_TRY(rp.inv.ensure(sizeof(int) * n));
-  TMD_TRY(rp.sorted.ensure(sizeof(R4) * n));
-  TMD_TRY(rp.sorted_alt.ensure(sizeof(R4) * n));
+  // (+ 2: the dummy records the padding entries of a list point at, Replica::pad_rows)
+  TMD_TRY(rp.sorted.ensure(sizeof(R4) * ((size_t)n + 2)));
+  TMD_TRY(rp.sorted_alt.ensure(sizeof(R4) * ((size_t)n + 2)));
   TMD_TRY(rp.stype.ensure(sizeof(int) * n));
   if (ctx->half_skin.p) {
     TMD_TRY(rp.sorted_hs.ensure(ctx->real_size * (size_t)n));
@@ -224,6 +240,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
       TMD_TRY(alloc_replica<R>(ctx, rp, est));
     }
     for (int k = 0; k < 3; ++k) rp.box[k] = box[k];
+    rp.pad_rows = plan_pad_rows(ctx, box);
     force = 1;
   }
   for (int attempt = 0; attempt < 8; ++attempt) {
@@ -286,7 +303,8 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
   }
   const int overwrite = (flags & TMDHIP_OVERWRITE_FORCES) ? 1 : 0;
   // list duties of the pair launch's first thread: rp.step counts the NEXT step by now
-  const int lmode = ((flags & kViolationCheck) ? kLmViolation : 0) | (((rp.step - 1) & 1) ? kLmParity : 0);
+  const int lmode = ((flags & kViolationCheck) ? kLmViolation : 0) | (((rp.step - 1) & 1) ? kLmParity : 0) |
+                    (rp.pad_rows ? kLmPadded : 0);
   FusedLaunch fl{};
   if (fused) {
     fl = *fused;

@@ -14,6 +14,19 @@
 // The receiver needs no unpack kernel: the exchange writes straight into the halo rows of its engine's
 // position buffer.
 //
+// tmdhip_dd_run's own loop (round 4) folds the small launches around those two into them — a brick of 125 000 + 50 000
+// atoms is launch-bound: twelve 2-5 us launches per step beside a 20-us pair kernel — leaving three kernels and the
+// exchange per step:
+//   dd_own_kernel     dd_step_kernel's update of the owned atoms + the engine's list displacement test for them + their
+//                     records of the cell-sorted copy the pair kernel gathers + the rows of the outgoing messages (an
+//                     atom writes its own rows through a per-atom index of the send list built once per migration);
+//   (exchange)
+//   dd_halo_kernel    displacement test and cell-sorted records of the halo rows that just arrived;
+//   pair kernel       with the rebuild chain left out while no atom is near its limit (the host paces itself one step
+//                     behind the device exactly like tmdhip_md_run: ListCheck in engine.h).
+// Same arithmetic, same rebuild decisions: trajectories are bit-identical to the loop of separate launches
+// (TMDHIP_DD_FUSED=0).
+//
 // Exchange and step loop from C (tmdhip_comm_*, tmdhip_dd_run): RCCL point-to-point between the ranks of the
 // brick grid — a brick of a 2 x 2 x 2 grid has 7 distinct neighbour ranks, one per xGMI link — as ONE group of
 // ncclSend/ncclRecv per step, enqueued on the same stream as the kernels (no cross-stream events, no host
@@ -29,9 +42,7 @@
 #include <mutex>
 #include <vector>
 
-#include "common.h"
-#include "pair_math.h"
-#include "rng.h"
+#include "engine.h"
 
 using namespace tmd;
 
@@ -112,6 +123,155 @@ __global__ void halo_pack_kernel(int64_t n3, const R *__restrict__ pos, const in
   const int64_t row = t / 3;
   const int k = (int)(t - 3 * row);
   out[t] = pos[3 * (int64_t)index[row] + k] + shift[t];
+}
+
+// ---- the brick step of tmdhip_dd_run in three launches (see the head comment) -----------------------------------
+template <typename R>
+struct DdOwnArgs {
+  int64_t nown;
+  R *pos, *vel;
+  const R *f, *mass, *vcoeff;
+  R dt, half_dt, gamma;
+  uint64_t seed, step;
+  int phases;
+  const R *ref_mig;  // positions at the last migration (the halo's skin)
+  unsigned *disp2;
+  ListCheck<R> chk;  // the engine's list: reference positions of its last build, original row order
+  typename Vec<R>::T4 *sorted;
+  const int *inv;
+  const R *qs;
+  const int *csr_off, *csr_row;  // send rows of every owned atom (tmdhip_comm: built once per migration)
+  const R *shift;
+  R *out;
+};
+
+template <typename R, bool LANGEVIN>
+__global__ __launch_bounds__(256) void dd_own_kernel(DdOwnArgs<R> a, PairConsts<R> c) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool drift = a.phases & 2;
+  if (i == 0 && drift) list_check_clear(a.chk.flags, a.chk.parity);
+  float d2 = 0.f;
+  if (i < a.nown) {
+    // every load of the update in one batch (the kernel is a chain of memory round trips per wave)
+    const R m = a.mass[i];
+    R vc = 0, v[3], fk[3], p[3] = {0, 0, 0}, rm[3] = {0, 0, 0}, rl[3] = {0, 0, 0}, q = 0, h2 = 0;
+    int slot = 0, s0 = 0, s1 = 0;
+    if (LANGEVIN && (a.phases & 1)) vc = a.vcoeff[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      v[k] = a.vel[3 * i + k];
+      fk[k] = a.f[3 * i + k];
+      if (drift) {
+        p[k] = a.pos[3 * i + k];
+        rm[k] = a.ref_mig[3 * i + k];
+        rl[k] = a.chk.ref[3 * i + k];
+      }
+    }
+    if (drift) {
+      q = a.qs[i];
+      h2 = list_check_limit(a.chk, (int)i);
+      slot = a.inv[i];
+      s0 = a.csr_off[i];
+      s1 = a.csr_off[i + 1];
+    }
+    R g[3] = {0, 0, 0};
+    if (LANGEVIN && (a.phases & 1)) normal3<R>(a.seed, a.step, (uint64_t)i, g[0], g[1], g[2]);
+    R dd = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // the expressions of dd_step_kernel, in its order
+      const R acc = fk[k] / m;
+      R vk = v[k];
+      if (a.phases & 1) {
+        if (LANGEVIN) vk += -a.gamma * vk * a.dt + g[k] * vc;
+        vk += a.half_dt * acc;
+      }
+      if (drift) {
+        p[k] = p[k] + (vk * a.dt + R(0.5) * acc * a.dt * a.dt);
+        vk = vk + a.half_dt * acc;
+        a.pos[3 * i + k] = p[k];
+        const R d = p[k] - rm[k];
+        dd += d * d;
+      }
+      a.vel[3 * i + k] = vk;
+    }
+    d2 = sizeof(R) == 4 ? (float)dd : __double2float_ru((double)dd);
+    if (drift) {
+      typename Vec<R>::T4 sv;
+      sv.x = p[0];
+      sv.y = p[1];
+      sv.z = p[2];
+      sv.w = q;
+      a.sorted[slot] = sv;
+      extent_note<R>(a.chk.ext, p[0], p[1], p[2]);
+      list_check_point<R>(a.chk, c, p[0] - rl[0], p[1] - rl[1], p[2] - rl[2], h2);
+      for (int s = s0; s < s1; ++s) {  // this atom's rows of the outgoing messages (halo_pack_kernel's expression)
+        const int64_t k = a.csr_row[s];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) a.out[3 * k + x] = p[x] + a.shift[3 * k + x];
+      }
+    }
+  }
+  if (a.disp2 && drift) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o, 64));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > *a.disp2) atomicMax(a.disp2, __float_as_uint(d2));
+  }
+}
+
+// halo rows [first, n) of the position buffer, just received: displacement test + cell-sorted records
+template <typename R>
+__global__ __launch_bounds__(256) void dd_halo_kernel(int first, int n, const R *__restrict__ pos, ListCheck<R> chk,
+                                                      PairConsts<R> c, const int *__restrict__ inv, const R *__restrict__ qs,
+                                                      typename Vec<R>::T4 *__restrict__ sorted) {
+  const int i = first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const R x = pos[3 * (size_t)i + 0], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
+  typename Vec<R>::T4 rec;
+  rec.x = x;
+  rec.y = y;
+  rec.z = z;
+  rec.w = qs[i];
+  const int slot = inv[i];
+  list_check_atom<R>(chk, c, i, x, y, z);
+  extent_note<R>(chk.ext, x, y, z);
+  sorted[slot] = rec;
+}
+
+// per-atom index of the send list (CSR over the owned atoms): count, scan (one block), fill
+__global__ void csr_count_kernel(int64_t nsend, const int32_t *__restrict__ index, int *__restrict__ cnt) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nsend) atomicAdd(&cnt[index[k]], 1);
+}
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int n, int *__restrict__ cnt, int *__restrict__ off) {
+  // cnt[0 .. n) -> off[0 .. n] (exclusive prefix), cnt := off (the fill cursors)
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int per = (n + 1023) / 1024, c0 = t * per;
+  int mine = 0;
+  for (int k = c0; k < min(c0 + per, n); ++k) mine += cnt[k];
+  int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int run = inc - mine;
+  for (int k = 0; k < w; ++k) run += wsum[k];
+  for (int k = c0; k < min(c0 + per, n); ++k) {
+    const int v = cnt[k];
+    off[k] = run;
+    cnt[k] = run;
+    run += v;
+  }
+  if (t == 1023) off[n] = run;
+}
+__global__ void csr_fill_kernel(int64_t nsend, const int32_t *__restrict__ index, int *__restrict__ cursor,
+                                int *__restrict__ row) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nsend) row[atomicAdd(&cursor[index[k]], 1)] = (int)k;
 }
 
 inline dim3 blocks_for(int64_t n, int t) { return dim3((unsigned)((n + t - 1) / t)); }
@@ -247,6 +407,15 @@ struct tmdhip_comm {
   int cur = 0;
   bool pending = false;
   int64_t at = 0;
+  // per-atom index of the brick's send list (dd_own_kernel writes an atom's outgoing rows itself): valid until the
+  // next migration (tmdhip_dd_reset) for the send list it was built from
+  DevBuf csr_off, csr_row, csr_cur;
+  const void *csr_index = nullptr;
+  int64_t csr_nsend = -1, csr_nown = -1;
+  // displacement-test state of the brick step in flight (dd_fused_front -> dd_fused_back)
+  unsigned chk_seq = 0;
+  unsigned *chk_near = nullptr;
+  int chk_skipped = 0;
 };
 
 #define TMD_NCCL(c, expr)                                                                                   \
@@ -334,6 +503,129 @@ int allreduce_max(tmdhip_comm *c, void *buf, hipStream_t st) {
   if (c->hub) return local_allreduce_max(c, (float *)buf, st);
   TMD_NCCL(c, c->api.all_reduce(buf, buf, 1, ncclFloat32, ncclMax, c->comm, st));
   return 0;
+}
+
+// per-atom index of the send list, rebuilt when the list has changed (three short launches once per migration)
+int dd_send_csr(tmdhip_comm *c, const tmdhip_dd_desc *d, hipStream_t st) {
+  if (c->csr_index == d->send_index_dev && c->csr_nsend == d->nsend && c->csr_nown == d->nown) return 0;
+  if (d->nown + 1 >= ((int64_t)1 << 31) || d->nsend >= ((int64_t)1 << 31)) return fail("tmdhip_dd_run: brick too large");
+  TMD_TRY(c->csr_off.ensure(sizeof(int) * ((size_t)d->nown + 1)));
+  TMD_TRY(c->csr_cur.ensure(sizeof(int) * ((size_t)d->nown + 1)));
+  TMD_TRY(c->csr_row.ensure(sizeof(int) * (size_t)d->nsend));
+  TMD_HIP(hipMemsetAsync(c->csr_cur.p, 0, sizeof(int) * ((size_t)d->nown + 1), st));
+  const dim3 gs((unsigned)((d->nsend + 255) / 256));
+  hipLaunchKernelGGL(csr_count_kernel, gs, dim3(256), 0, st, d->nsend, d->send_index_dev, c->csr_cur.as<int>());
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, (int)d->nown, c->csr_cur.as<int>(), c->csr_off.as<int>());
+  hipLaunchKernelGGL(csr_fill_kernel, gs, dim3(256), 0, st, d->nsend, d->send_index_dev, c->csr_cur.as<int>(), c->csr_row.as<int>());
+  TMD_HIP(hipGetLastError());
+  c->csr_index = d->send_index_dev;
+  c->csr_nsend = d->nsend;
+  c->csr_nown = d->nown;
+  return 0;
+}
+
+constexpr double kDdChainNear = 0.75;  // as tmdhip_md_run's kChainSkipNear (md_loop.hip)
+
+// front half of a fused brick step: the pacing decision (leave the rebuild chain out?) and dd_own_kernel
+template <typename R>
+int dd_fused_front(tmdhip_ctx *ctx, Replica &rp, tmdhip_comm *c, const tmdhip_dd_desc *d, int phases, uint64_t kick_step,
+                   bool chain_skip_on, bool &pace_timed_out, bool &skip_chain, hipStream_t st) {
+  using R4 = typename Vec<R>::T4;
+  const double box0[3] = {0, 0, 0};
+  const PairConsts<R> pc = make_consts<R>(ctx, box0);
+  DdOwnArgs<R> a{};
+  a.nown = d->nown;
+  a.pos = (R *)d->pos_dev;
+  a.vel = (R *)d->vel_dev;
+  a.f = (const R *)d->forces_dev;
+  a.mass = (const R *)d->mass_dev;
+  a.vcoeff = (const R *)d->vcoeff_dev;
+  a.dt = (R)d->dt;
+  a.half_dt = (R)(0.5 * d->dt);
+  a.gamma = d->vcoeff_dev ? (R)d->gamma : R(0);
+  a.seed = d->seed;
+  a.step = kick_step;
+  a.phases = phases;
+  a.ref_mig = (const R *)d->ref_dev;
+  a.disp2 = d->disp2_dev;
+  a.chk = make_check<R>(ctx, rp);
+  skip_chain = false;
+  if (chain_skip_on) {  // (tmdhip_md_run's scheme, md_loop.hip: the host stays one step behind the device)
+    if (!rp.hostpub) {
+      TMD_HIP(hipHostMalloc((void **)&rp.hostpub, 8 * sizeof(unsigned), hipHostMallocMapped));
+      for (int w = 0; w < 8; ++w) rp.hostpub[w] = 0u;
+      rp.seq = 0;
+      rp.seq_valid = false;
+    }
+    volatile unsigned *hp = rp.hostpub;
+    if (rp.seq_valid && !pace_timed_out && !wait_published(hp, rp.seq)) pace_timed_out = true;
+    if (rp.seq_valid && !pace_timed_out) {
+      const bool near = hp[1 + (rp.seq & 1u)] == rp.seq, rebuilt = hp[3 + (rp.seq & 1u)] == rp.seq;
+      skip_chain = !near || (rebuilt && !rp.prev_skipped);
+    }
+    rp.prev_skipped = skip_chain;
+    rp.seq += 1;
+    if (rp.seq == 0) rp.seq = 1;
+    a.chk.near_host = rp.hostpub + 1 + (rp.seq & 1u);
+    a.chk.seq = rp.seq;
+    a.chk.near_frac2 = (R)(kDdChainNear * kDdChainNear);
+    a.chk.skipped = skip_chain ? 1 : 0;
+    rp.seq_valid = true;
+    rp.pub_ptr = rp.hostpub;
+    rp.pub_val = rp.seq;
+  } else {
+    rp.seq_valid = false;
+    rp.pub_ptr = nullptr;
+  }
+  a.sorted = rp.sorted.as<R4>();
+  a.inv = rp.inv.as<int>();
+  a.qs = ctx->qs.as<R>();
+  a.csr_off = c->csr_off.as<int>();
+  a.csr_row = c->csr_row.as<int>();
+  a.shift = (const R *)d->send_shift_dev;
+  a.out = (R *)d->send_buf_dev;
+  if (d->nsend == 0) {  // nothing to send: every atom's row range is empty
+    TMD_TRY(c->csr_off.ensure(sizeof(int) * ((size_t)d->nown + 1)));
+    if (c->csr_nsend != 0 || c->csr_nown != d->nown) {
+      TMD_HIP(hipMemsetAsync(c->csr_off.p, 0, sizeof(int) * ((size_t)d->nown + 1), st));
+      c->csr_nsend = 0;
+      c->csr_nown = d->nown;
+      c->csr_index = nullptr;
+    }
+    a.csr_off = c->csr_off.as<int>();
+  }
+  // the step's displacement-test state, kept for the halo rows (dd_fused_back)
+  c->chk_seq = a.chk.seq;
+  c->chk_near = a.chk.near_host;
+  c->chk_skipped = a.chk.skipped;
+  const dim3 grid((unsigned)((d->nown + 255) / 256));
+  if (d->vcoeff_dev) hipLaunchKernelGGL((dd_own_kernel<R, true>), grid, dim3(256), 0, st, a, pc);
+  else hipLaunchKernelGGL((dd_own_kernel<R, false>), grid, dim3(256), 0, st, a, pc);
+  TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+// back half: the halo rows the exchange has delivered (test + cell-sorted records), then the pair launch with the
+// displacement test already made and, where the front half said so, without the rebuild chain
+template <typename R>
+int dd_fused_back(tmdhip_ctx *ctx, Replica &rp, tmdhip_comm *c, const tmdhip_dd_desc *d, bool skip_chain, hipStream_t st) {
+  using R4 = typename Vec<R>::T4;
+  const double box0[3] = {0, 0, 0};
+  const PairConsts<R> pc = make_consts<R>(ctx, box0);
+  const int n = ctx->d.natoms;
+  if (d->nhalo > 0) {
+    ListCheck<R> chk = make_check<R>(ctx, rp);
+    chk.near_host = c->chk_near;
+    chk.seq = c->chk_seq;
+    chk.near_frac2 = (R)(kDdChainNear * kDdChainNear);
+    chk.skipped = c->chk_skipped;
+    hipLaunchKernelGGL((dd_halo_kernel<R>), dim3((unsigned)((d->nhalo + 255) / 256)), dim3(256), 0, st, (int)d->nown, n,
+                       (const R *)d->pos_dev, chk, pc, rp.inv.as<int>(), ctx->qs.as<R>(), rp.sorted.as<R4>());
+    TMD_HIP(hipGetLastError());
+  }
+  rp.n_compute++;
+  return compute_list<R>(ctx, rp, d->pos_dev, box0, d->forces_dev, nullptr,
+                         TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES | kPrechecked | (skip_chain ? kSkipChain : 0), st);
 }
 
 int comm_alloc_trigger(tmdhip_comm *c) {
@@ -429,6 +721,9 @@ void tmdhip_comm_destroy(tmdhip_comm *c) {
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->host_flag) (void)hipHostFree(c->host_flag);
+  c->csr_off.release();
+  c->csr_row.release();
+  c->csr_cur.release();
   delete c;
 }
 
@@ -444,6 +739,7 @@ int tmdhip_dd_reset(tmdhip_comm *c) {
   if (!c) return fail("tmdhip_dd_reset: null argument");
   c->pending = false;
   c->at = 0;
+  c->csr_index = nullptr;  // the send list changes with the migration
   return 0;
 }
 
@@ -467,10 +763,31 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
     return tmdhip_dd_step(d->dtype, d->nown, d->pos_dev, d->vel_dev, d->forces_dev, d->mass_dev, d->vcoeff_dev, d->dt,
                           d->gamma, d->seed, kick_step, phases, d->ref_dev, d->disp2_dev, stream);
   };
+  // The three-launch step (head comment) needs a cell-list context that holds a list of exactly these rows in an open
+  // box; anything else (first call after a migration without a force evaluation, all-pairs bricks) takes the loop of
+  // separate launches.  TMDHIP_DD_FUSED=0 forces that loop (A/B, bit-identity tests).
+  Replica &rp = ctx->rep[0];
+  const char *e_fused = std::getenv("TMDHIP_DD_FUSED");
+  bool fused = !(e_fused && std::atoi(e_fused) == 0) && ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0 &&
+               ctx->d.dtype == d->dtype && d->nown > 0 && (int64_t)ctx->d.natoms == d->nown + d->nhalo &&
+               ctx->d.natoms < (1 << 30) && !ctx->half_skin.p;
+  if (fused && d->nsend > 0) TMD_TRY(dd_send_csr(c, d, st));
+  const char *e_skip = std::getenv("TMDHIP_CHAIN_SKIP");
+  const bool chain_skip_on = !(e_skip && std::atoi(e_skip) == 0);
+  bool pace_timed_out = false;
+  rp.seq_valid = false;  // whatever ran between two calls (migration, plain evaluations) published nothing
   for (int it = 0; it < d->niter; ++it) {
     // the kick belongs to the previous iteration (noise counter step0 + it - 1), the drift to this one
     const uint64_t kick_step = d->step0 + (uint64_t)it > 0 ? d->step0 + (uint64_t)it - 1 : 0;
-    TMD_TRY(kick_drift(it == 0 ? d->first_phases : 3, kick_step));
+    const int phases = it == 0 ? d->first_phases : 3;
+    const bool fuse_now = fused && rp.have_list && rp.box[0] == 0 && rp.box[1] == 0 && rp.box[2] == 0;
+    bool skip_chain = false;
+    if (fuse_now) {
+      TMD_TRY(d->dtype == TMDHIP_F32 ? dd_fused_front<float>(ctx, rp, c, d, phases, kick_step, chain_skip_on, pace_timed_out, skip_chain, st)
+                                     : dd_fused_front<double>(ctx, rp, c, d, phases, kick_step, chain_skip_on, pace_timed_out, skip_chain, st));
+    } else {
+      TMD_TRY(kick_drift(phases, kick_step));
+    }
     ++since;
     if (since % d->check_every == 0) {
       const double limit = 0.5 * d->skin;
@@ -481,6 +798,7 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
         // (hot atoms, a larger check_every, a changed time step): halo atoms would be missing, forces silently wrong
         if (moved > limit) {
           c->pending = false;
+          rp.pub_ptr = nullptr;
           return fail("tmdhip_dd_run: an atom moved " + std::to_string(moved) + " A since the last migration, beyond the "
                       "halo's half skin of " + std::to_string(limit) + " A, before a migration was requested: the forces of "
                       "the last steps are invalid (use a larger halo skin or a smaller check_every)");
@@ -489,6 +807,7 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
         if (moved * ahead > limit) {
           c->pending = false;
           *iters_done = it;
+          rp.pub_ptr = nullptr;
           return 1;  // this iteration has drifted; the caller migrates, evaluates the forces and comes back
         }
       }
@@ -506,6 +825,7 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
         const double moved = std::sqrt((double)c->host_flag[c->cur]);
         if (moved > limit) {
           c->pending = false;
+          rp.pub_ptr = nullptr;
           return fail("tmdhip_dd_run: an atom moved " + std::to_string(moved) + " A in the first " + std::to_string(since) +
                       " steps after a migration, beyond the halo's half skin of " + std::to_string(limit) + " A");
         }
@@ -513,14 +833,22 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
         if (moved * ahead > limit) {
           c->pending = false;
           *iters_done = it;
+          rp.pub_ptr = nullptr;
           return 1;
         }
       }
     }
-    TMD_TRY(tmdhip_halo_pack(d->dtype, d->nsend, d->pos_dev, d->send_index_dev, d->send_shift_dev, d->send_buf_dev, stream));
+    if (!fuse_now || d->nsend == 0)
+      TMD_TRY(tmdhip_halo_pack(d->dtype, d->nsend, d->pos_dev, d->send_index_dev, d->send_shift_dev, d->send_buf_dev, stream));
     TMD_TRY(exchange_rows(c, d->dtype, d->send_buf_dev, d->send_counts_host, halo_rows, d->recv_counts_host, 3, st));
-    TMD_TRY(tmdhip_compute_nonbonded(ctx, 0, d->pos_dev, box0, d->forces_dev, nullptr,
-                                     TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES, stream));
+    if (fuse_now) {
+      const int rc = d->dtype == TMDHIP_F32 ? dd_fused_back<float>(ctx, rp, c, d, skip_chain, st) : dd_fused_back<double>(ctx, rp, c, d, skip_chain, st);
+      rp.pub_ptr = nullptr;
+      if (rc) return rc < 0 ? rc : fail("tmdhip_dd_run: the brick's box holds too few cells for the list path");
+    } else {
+      TMD_TRY(tmdhip_compute_nonbonded(ctx, 0, d->pos_dev, box0, d->forces_dev, nullptr,
+                                       TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES, stream));
+    }
     *iters_done = it + 1;
   }
   if (d->niter > 0 || d->first_phases == 3) {

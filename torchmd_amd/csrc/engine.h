@@ -327,6 +327,7 @@ constexpr int kAuxVolatile = (int)0x80000000;  // bit 31 of a raw-buffer intrins
 constexpr int kLmViolation = 1;  // the chain of this step was left out and its displacement test ran in the previous
                                  // launch's epilogue, which could not know that: a rebuild request found now = F_VIOLATION
 constexpr int kLmParity = 2;     // parity of this step
+constexpr int kLmPadded = 4;     // the list's padding slots hold harmless entries (Replica::pad_rows): no per-lane validity
 constexpr int kFastThreads = 256;  // threads of a block of the lean fp32 pair kernel (step blocks are four waves)
 
 // ---- the step in the lean fp32 pair kernel's epilogue (see FusedStep above the kernel) -------------------------
@@ -411,6 +412,10 @@ struct Replica {
   DevBuf fbond;            // bonded force of a fused launch's positions (heavy topologies), original atom order
   unsigned fused_gen = 0;  // number of the last fused launch
   int64_t fused_launches = 0;  // fused launches of this replica (test knob TMDHIP_DEBUG_STEP_TIMEOUT counts them)
+  // Padded list rows (list_build.hip: pad_rows_kernel; fp32 contexts of <= 2^20 - 2 atoms whose box keeps the dummy
+  // records out of reach): the padding slots of every wave group hold a harmless entry, the lean fp32 pair kernel runs
+  // all of a wave's groups in its unchecked loop (kLmPadded).  Decided when the grid is planned (a forced rebuild follows).
+  bool pad_rows = false;
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf extent;  // int[6]: keys of the coordinate extent of sorted_xyzq (extent_note)
   DevBuf paircount;  // unsigned long long
@@ -617,6 +622,8 @@ int launch_pair_lean_f64(tmdhip_ctx *ctx, Replica &rp, const PairConsts<double> 
 // md_loop.hip
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st);
+// chain skipping: spin until the device has published sequence number `target` (Replica::hostpub[0]); false after 0.2 s
+bool wait_published(volatile unsigned *hp, unsigned target);
 // energies, kinetic energies and list flags of every replica through host-mapped memory + a sequence word the host
 // spins on (<= 16 replicas); returns when the device has written them
 int publish_observables(tmdhip_ctx *ctx, const double *energies_dev, const double *ke_dev, bool lists, double *host_e,

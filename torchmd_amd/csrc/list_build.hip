@@ -47,13 +47,47 @@ __global__ void bin_count_kernel(int n, const R *__restrict__ pos, Grid g, int *
   slot[i] = atomicAdd(&count[cidx], 1);
 }
 
-// single block of 1024 threads; cell_start[ncell] = n afterwards; counts are zeroed for the next rebuild
+// single block of 1024 threads; cell_start[ncell] = n afterwards; counts are zeroed for the next rebuild.
+// Up to 32 cells per thread (grids of <= 32 768 cells; C3: 6 859 cells, 7 per thread) a thread owns a run of consecutive
+// cells: its counts in registers, one scan of the 1 024 run sums (wave shuffles + 16 LDS words, two barriers) — the
+// chunk-by-chunk loop below makes four barriers per 1 024 cells (10.8 us per rebuild at C3, three times the rest of its work).
+constexpr int kScanRun = 32;
 __global__ __launch_bounds__(1024) void scan_cells_kernel(int ncell, int *__restrict__ count,
                                                           int *__restrict__ cell_start, const int *flag) {
   if (*flag == 0) return;
   __shared__ int wsum[16];
   __shared__ int carry;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int per = (ncell + 1023) / 1024;
+  if (per <= kScanRun) {
+    int v[kScanRun], mine = 0;
+    const int c0 = t * per;
+#pragma unroll
+    for (int k = 0; k < kScanRun; ++k) {
+      v[k] = (k < per && c0 + k < ncell) ? count[c0 + k] : 0;
+      mine += v[k];
+    }
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int run = inc - mine;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < kScanRun; ++k) {
+      if (k < per && c0 + k < ncell) {
+        cell_start[c0 + k] = run;
+        count[c0 + k] = 0;
+      }
+      run += v[k];
+    }
+    if (t == 1023) cell_start[ncell] = run;
+    return;
+  }
   if (t == 0) carry = 0;
   __syncthreads();
   for (int base = 0; base < ncell; base += 1024) {
@@ -559,6 +593,60 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   if (lane == 0 && wmax > 0) atomicMax(status, wmax);
 }
 
+// ---- padded rows (Replica::pad_rows) -------------------------------------------------------------------------
+// A pair wave runs as long as the longest list of its APW atoms, rounded up to whole 16-byte list words: 19 % of the
+// slots a C3 launch evaluates are padding, and the lean fp32 kernel used to run every group that holds any of it in
+// its per-lane-checked, unpipelined loop (3 of ~14 groups per wave).  This kernel fills the padding slots of every
+// wave group with an entry that is harmless to evaluate unchecked: one of two dummy records behind the last atom
+// (slots n and n + 1 of the cell-sorted position arrays; charge 0, LJ class 0) — the one further away from the atom
+// under the minimum image.  The two sit half a box diagonal apart, so one of them is at least a quarter of the
+// diagonal away from any point (triangle inequality on the torus); the host enables the padding only where that is
+// beyond cutoff + 2 skins (plan_pad_rows), an open dimension puts them 10^6 A out.  All arithmetic on such an entry
+// stays finite and its cutoff factor is 0.  One wave per wave group; runs behind the build on its stream.
+__global__ __launch_bounds__(256) void pad_rows_kernel(int n, float4 *__restrict__ sorted, float4 *__restrict__ sorted_alt,
+                                                       const int *__restrict__ nneigh, ListGeom lg, PairConsts<float> c,
+                                                       unsigned *__restrict__ nlist, const int *flag) {
+  if (*flag == 0) return;
+  float d0[3], d1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const bool open = !(c.box[k] > 0.f);
+    d0[k] = open ? 1.0e6f : 0.25f * c.box[k];
+    d1[k] = open ? 1.0e6f : 0.75f * c.box[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    const float4 rec = threadIdx.x == 0 ? make_float4(d0[0], d0[1], d0[2], 0.f) : make_float4(d1[0], d1[1], d1[2], 0.f);
+    sorted[n + threadIdx.x] = rec;
+    if (sorted_alt) sorted_alt[n + threadIdx.x] = rec;
+  }
+  const int lane = threadIdx.x & 63;
+  const int g = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (g >= (n + lg.apw - 1) / lg.apw) return;  // (wave-uniform)
+  const int a = g * lg.apw + (lane >> lg.lpa_shift), sub = lane & (lg.lpa - 1);
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  int nn = 0;
+  if (a < n) {
+    p = sorted[a];
+    nn = min(nneigh[a], lg.maxn);
+  }
+  const int myiters = (nn - sub + lg.lpa - 1) >> lg.lpa_shift;
+  int itmax = myiters;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) itmax = max(itmax, __shfl_xor(itmax, o, 64));
+  const int padded = (itmax + 3) & ~3;
+  float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float pk = k == 0 ? p.x : (k == 1 ? p.y : p.z);
+    const float e0 = min_image(pk - d0[k], c.box[k], c.invbox[k]), e1 = min_image(pk - d1[k], c.box[k], c.invbox[k]);
+    r0 += e0 * e0;
+    r1 += e1 * e1;
+  }
+  const unsigned entry = (unsigned)(n + (r1 > r0 ? 1 : 0)) << 4;
+  unsigned *row = nlist + ((size_t)g * lg.maxn << (6 - lg.lpa_shift));
+  for (int kk = myiters; kk < padded; ++kk) row[(((kk >> 2) << 6) + lane) * 4 + (kk & 3)] = entry;
+}
+
 // TMDHIP_DEBUG_TIMELINE=1: every block of the list build records its entry / exit cycle counters (4 x u64 per block),
 // read back with tmdhip_debug_build_timeline (tools/build_timeline.py).  Null otherwise: the kernel stores nothing.
 static DevBuf g_dbg_timeline;
@@ -653,6 +741,14 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const ListTarget &T, cons
   } else {
     if (wskin) launch_build(build_list_kernel<R, true, true>, kMaxBuildBlocks);
     else launch_build(build_list_kernel<R, true, false>, kMaxBuildBlocks);
+  }
+  if constexpr (std::is_same<R, float>::value) {
+    if (rp.pad_rows) {
+      const int groups = (n + rp.lg.apw - 1) / rp.lg.apw;
+      hipLaunchKernelGGL(pad_rows_kernel, dim3((groups + 3) / 4), dim3(256), 0, st_build, n, T.sorted->as<float4>(),
+                         T.sorted == &rp.sorted ? rp.sorted_alt.as<float4>() : nullptr, T.nneigh->as<int>(), rp.lg, c,
+                         T.nlist->as<unsigned>(), flag);
+    }
   }
   TMD_HIP(hipGetLastError());
   return 0;

@@ -151,13 +151,15 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   const int nkk = __builtin_amdgcn_readfirstlane(itmax);
   // iterations every lane has entries for.  The unchecked loop takes the table offset as `entry >> 24`, which needs
   // the slot's bits 20..22 to be zero: systems of more than 2^20 atoms run all their iterations in the checked
-  // loop, which masks the offset
-  const int nfull = n > (1 << 20) ? 0 : __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL;
+  // loop, which masks the offset.  Padded rows (kLmPadded; pad_rows_kernel): the slots between a lane's last entry and
+  // the end of the wave's last group hold a harmless entry (a dummy record out of reach), so EVERY group is unchecked.
+  const int nfull = (lmode & kLmPadded) ? (nkk + UNROLL - 1) / UNROLL * UNROLL
+                                        : (n > (1 << 20) ? 0 : __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL);
   // bounds-checked raw buffer over sorted_xyzq: lanes past the end of their list read whatever the
   // (uninitialised) padding entry points at — out-of-range offsets return 0 instead of faulting — and
   // are discarded by `valid`
   const __amdgpu_buffer_rsrc_t srsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(sorted), 0, n * 16, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(sorted), 0, (n + 2) * 16, 0x00020000);  // (+ the two dummy records)
   const char *tbase = reinterpret_cast<const char *>(stab);
   const float two_krf = 2.0f * c.krf;
   const float qi2k = pi.w * two_krf;
