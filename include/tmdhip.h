@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TMDHIP_ABI_VERSION 5
+#define TMDHIP_ABI_VERSION 6
 
 /* dtype */
 #define TMDHIP_F32 0
@@ -324,6 +324,10 @@ int tmdhip_comm_exchange(tmdhip_comm *comm, int dtype, const void *send_dev, con
  *   per iteration: tmdhip_dd_step (kick of the previous iteration + drift of this one) -> tmdhip_halo_pack ->
  *   tmdhip_comm_exchange into the halo rows of pos_dev -> nonbonded forces on the owned atoms (ctx: open
  *   boundaries, atoms >= nown passive, see tmdhip_update_atoms);  after the last iteration the owed kick.
+ *   (Since ABI 6 the loop runs these as three launches + the exchange per iteration — the update of the owned atoms
+ *   with the list's displacement test, their cell-sorted records and their outgoing rows; the same for the halo rows
+ *   that arrived; the pair kernel, with the rebuild chain left out while no atom is near its limit — same results
+ *   bit for bit; TMDHIP_DD_FUSED=0 in the environment keeps the separate launches.)
  * Every `check_every` iterations the maximum squared displacement since the last migration is max-reduced over
  * the ranks and copied to the host asynchronously; it is examined one check later, so the loop never waits for
  * the device.  When the projected displacement exceeds skin/2 the call returns 1 with *iters_done = the number
@@ -359,6 +363,47 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *comm, const tmdhip_dd_desc *desc
                   void *stream);
 /* Forget the pending displacement read-back (call after every migration). */
 int tmdhip_dd_reset(tmdhip_comm *comm);
+
+/* ---- atom migration of a brick, on the device (ABI 6) ----
+ * When tmdhip_dd_run returns 1 the caller re-assigns atoms to bricks.  tmdhip_dd_migrate does that for one rank's
+ * brick entirely in the library (every rank of the communicator must call it): the brick of every owned atom and
+ * the counts per destination, an exchange of the atoms' state rows (id, position in the caller's periodic image,
+ * velocity, charge, type, mass) over the communicator, the new owned set in the order of the global ids, the halo
+ * plan (which owned atoms each of the 26 neighbour directions sees, with which periodic shift: send_index /
+ * send_shift / send_counts in the order tmdhip_dd_run expects), the first halo exchange (positions, charges, types)
+ * and the atom set of the force engine `ctx` (what tmdhip_update_atoms does from host arrays; atoms >= nown passive).
+ * The arrays are the caller's, with capacities in rows; they are rewritten in place.  All communication happens
+ * before anything is overwritten: when a capacity is too small the call returns 2 with need_own / need_rows /
+ * need_send set and nothing lost — grow the arrays (their contents need not be kept when need_send == 0: the owned
+ * rows are then still in the library's scratch; with need_send > 0 keep the first `nown` rows) and call again with
+ * the same struct.  The forces have to be evaluated afterwards (the next tmdhip_compute_nonbonded re-plans the
+ * engine's grid and rebuilds its list).  Returns 0, 2 (see above) or a negative error. */
+typedef struct tmdhip_dd_brick {
+  int32_t struct_size;
+  int32_t dtype;
+  int32_t rank, world;
+  int32_t dims[3];           /* brick grid px, py, pz (rank = (cx py + cy) pz + cz)                           */
+  int32_t ntypes_map;        /* entries of type_map_host                                                       */
+  double box[3];
+  double halo;               /* cutoff + halo skin                                                             */
+  int64_t cap_own, cap_rows, cap_send; /* capacities in rows: per-owned-atom arrays, pos_dev, the send list    */
+  int64_t nown, nhalo, nsend;          /* in: nown; out: all three                                             */
+  int64_t *ids_dev;          /* [cap_own] global atom ids                                                      */
+  void *pos_dev;             /* real [cap_rows, 3]: owned rows (wrapped frame), then halo rows                 */
+  void *unwrap_dev;          /* real [cap_own, 3]: caller's periodic image - wrapped position                  */
+  void *vel_dev;             /* real [cap_own, 3]                                                              */
+  void *charge_dev;          /* real [cap_own]                                                                 */
+  int32_t *type_dev;         /* [cap_own]                                                                      */
+  void *mass_dev;            /* real [cap_own]                                                                 */
+  void *ref_dev;             /* real [cap_own, 3]: positions at this migration (tmdhip_dd_desc::ref_dev)       */
+  uint32_t *disp2_dev;       /* zeroed                                                                         */
+  int32_t *send_index_dev;   /* [cap_send]                                                                     */
+  void *send_shift_dev;      /* real [cap_send, 3]                                                             */
+  int64_t *send_counts_host, *recv_counts_host; /* [world], written                                            */
+  const int32_t *type_map_host; /* [ntypes_map]: atom type -> LJ class of the context, or NULL (identity)      */
+  int64_t need_own, need_rows, need_send; /* written on return 2                                               */
+} tmdhip_dd_brick;
+int tmdhip_dd_migrate(tmdhip_ctx *ctx, tmdhip_comm *comm, tmdhip_dd_brick *brick, void *stream);
 
 /* ---- debug aid (not needed by any caller of the path) ----
  * With TMDHIP_DEBUG_TIMELINE=1 in the environment every block of the list build records {entry cycle, exit cycle,

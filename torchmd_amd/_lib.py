@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # TMDHIP_LIB: developer knob for A/B runs of differently built libraries (kernel experiments)
 LIBPATH = os.environ.get("TMDHIP_LIB") or os.path.join(PKG, "lib", "libtmdhip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, F64 = 0, 1
 TERM_LJ, TERM_ELECTROSTATICS, TERM_REPULSION, TERM_REPULSIONCG = 1, 2, 4, 8
 E_LJ, E_ELECTROSTATICS, E_REPULSION, E_REPULSIONCG, E_BONDS, E_ANGLES, E_DIHEDRALS, E_IMPROPERS = range(8)
@@ -145,6 +145,42 @@ class DdDesc(C.Structure):
     ]
 
 
+class DdBrick(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("dtype", C.c_int32),
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("dims", C.c_int32 * 3),
+        ("ntypes_map", C.c_int32),
+        ("box", C.c_double * 3),
+        ("halo", C.c_double),
+        ("cap_own", C.c_int64),
+        ("cap_rows", C.c_int64),
+        ("cap_send", C.c_int64),
+        ("nown", C.c_int64),
+        ("nhalo", C.c_int64),
+        ("nsend", C.c_int64),
+        ("ids_dev", C.c_void_p),
+        ("pos_dev", C.c_void_p),
+        ("unwrap_dev", C.c_void_p),
+        ("vel_dev", C.c_void_p),
+        ("charge_dev", C.c_void_p),
+        ("type_dev", C.c_void_p),
+        ("mass_dev", C.c_void_p),
+        ("ref_dev", C.c_void_p),
+        ("disp2_dev", C.c_void_p),
+        ("send_index_dev", C.c_void_p),
+        ("send_shift_dev", C.c_void_p),
+        ("send_counts_host", C.c_void_p),
+        ("recv_counts_host", C.c_void_p),
+        ("type_map_host", C.c_void_p),
+        ("need_own", C.c_int64),
+        ("need_rows", C.c_int64),
+        ("need_send", C.c_int64),
+    ]
+
+
 COMM_ID_BYTES = 128
 
 
@@ -242,6 +278,7 @@ SIGNATURES = {
     ),
     "tmdhip_dd_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(DdDesc), C.POINTER(C.c_int32), C.c_void_p]),
     "tmdhip_dd_reset": (C.c_int, [C.c_void_p]),
+    "tmdhip_dd_migrate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(DdBrick), C.c_void_p]),
     "tmdhip_local_hub_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "tmdhip_local_hub_destroy": (None, [C.c_void_p]),
     "tmdhip_comm_create_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]),

@@ -206,7 +206,12 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     const bool periodic = !(box[0] == 0 && box[1] == 0 && box[2] == 0);
     double volume;
-    if (!periodic) {
+    if (!periodic && ctx->open_bounds_valid) {
+      for (int k = 0; k < 3; ++k) lo[k] = ctx->open_lo[k], hi[k] = ctx->open_hi[k];
+      ctx->open_bounds_valid = false;
+      volume = std::max(hi[0] - lo[0], ctx->rlist) * std::max(hi[1] - lo[1], ctx->rlist) *
+               std::max(hi[2] - lo[2], ctx->rlist);
+    } else if (!periodic) {
       std::vector<R> h(3 * (size_t)n);
       TMD_HIP(hipMemcpyAsync(h.data(), pos, sizeof(R) * 3 * n, hipMemcpyDeviceToHost, st));
       TMD_HIP(hipStreamSynchronize(st));
@@ -236,6 +241,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     if (!rp.have_list) {
       const double dens = n / volume;
       int est = (int)(dens * 4.18879 * ctx->rlist * ctx->rlist * ctx->rlist * 1.3) + 32;
+      est = std::max(est, rp.maxn_keep);
       est = std::min(est, std::max(n - 1, 1));
       TMD_TRY(alloc_replica<R>(ctx, rp, est));
     }
@@ -568,6 +574,7 @@ int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, 
   const int n = natoms;
   ctx->d.natoms = n;
   ctx->nactive = nactive > 0 ? nactive : 0x7fffffff;
+  ctx->open_bounds_valid = false;
   TMD_TRY(ctx->types.ensure(sizeof(int) * n));
   TMD_HIP(hipMemcpy(ctx->types.p, types_host, sizeof(int) * n, hipMemcpyHostToDevice));
   const double s = std::sqrt(kElecFactor);
@@ -589,6 +596,7 @@ int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, 
   ctx->mean_list_scale = 1;
   for (auto &rp : ctx->rep) {  // the next compute re-plans the grid, re-sizes the buffers and rebuilds
     rp.have_list = false;
+    if (rp.lg.maxn > 0) rp.maxn_keep = rp.lg.maxn;
     rp.lg.maxn = 0;
   }
   return 0;

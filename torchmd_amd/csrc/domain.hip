@@ -42,30 +42,11 @@
 #include <mutex>
 #include <vector>
 
-#include "engine.h"
+#include <hipcub/hipcub.hpp>
+
+#include "dd_comm.h"
 
 using namespace tmd;
-
-// The handful of RCCL declarations this file needs, stated locally (values and signatures of the stable NCCL 2 ABI,
-// rccl.h): librccl is opened with dlopen at run time, so the library must also BUILD on a machine without the RCCL
-// headers — the single-GPU paths do not depend on them at all.
-extern "C" {
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
-typedef enum { ncclMax = 2 } ncclRedOp_t;
-ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
-ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
-ncclResult_t ncclCommDestroy(ncclComm_t comm);
-const char *ncclGetErrorString(ncclResult_t result);
-ncclResult_t ncclGroupStart();
-ncclResult_t ncclGroupEnd();
-ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
-ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
-ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
-                           ncclComm_t comm, hipStream_t stream);
-}
 
 namespace {
 
@@ -238,35 +219,10 @@ __global__ __launch_bounds__(256) void dd_halo_kernel(int first, int n, const R 
   sorted[slot] = rec;
 }
 
-// per-atom index of the send list (CSR over the owned atoms): count, scan (one block), fill
+// per-atom index of the send list (CSR over the owned atoms): count, scan (hipcub), fill
 __global__ void csr_count_kernel(int64_t nsend, const int32_t *__restrict__ index, int *__restrict__ cnt) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nsend) atomicAdd(&cnt[index[k]], 1);
-}
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int n, int *__restrict__ cnt, int *__restrict__ off) {
-  // cnt[0 .. n) -> off[0 .. n] (exclusive prefix), cnt := off (the fill cursors)
-  __shared__ int wsum[16];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int per = (n + 1023) / 1024, c0 = t * per;
-  int mine = 0;
-  for (int k = c0; k < min(c0 + per, n); ++k) mine += cnt[k];
-  int inc = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int up = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += up;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  int run = inc - mine;
-  for (int k = 0; k < w; ++k) run += wsum[k];
-  for (int k = c0; k < min(c0 + per, n); ++k) {
-    const int v = cnt[k];
-    off[k] = run;
-    cnt[k] = run;
-    run += v;
-  }
-  if (t == 1023) off[n] = run;
 }
 __global__ void csr_fill_kernel(int64_t nsend, const int32_t *__restrict__ index, int *__restrict__ cursor,
                                 int *__restrict__ row) {
@@ -292,18 +248,6 @@ int launch_dd_step(int64_t nown, void *pos, void *vel, const void *forces, const
   return 0;
 }
 
-struct RcclApi {
-  void *handle = nullptr;
-  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
-  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
-  decltype(&ncclCommDestroy) comm_destroy = nullptr;
-  decltype(&ncclGetErrorString) error_string = nullptr;
-  decltype(&ncclGroupStart) group_start = nullptr;
-  decltype(&ncclGroupEnd) group_end = nullptr;
-  decltype(&ncclSend) send = nullptr;
-  decltype(&ncclRecv) recv = nullptr;
-  decltype(&ncclAllReduce) all_reduce = nullptr;
-};
 
 int load_rccl(const char *path, RcclApi &api) {
   const char *names[] = {path, "librccl.so.1", "librccl.so"};
@@ -334,55 +278,6 @@ int load_rccl(const char *path, RcclApi &api) {
 
 }  // namespace
 
-// ---- in-process transport: all ranks of the brick grid inside ONE process on ONE device ------------------------
-// What RCCL does between processes, between host threads: one thread per rank drives its brick's loop
-// (tmdhip_dd_run) on a stream of its own; an exchange is a rendezvous of the threads on the host (a reusable barrier)
-// around device-side copies ordered by events:
-//   every rank publishes {send buffer, counts} and records `ready` on its stream (its pack kernel is in front of it);
-//   barrier;  every rank makes its stream wait for the senders' `ready` events and copies its rows out of their send
-//   buffers into its own halo rows, then records `done`;  barrier;  every rank makes its stream wait for the `done` of
-//   the ranks that read from it, so that its next pack cannot overwrite rows still being copied.
-// The host threads only enqueue; nothing waits for the device.  A rank that does not arrive within 30 s (its loop
-// returned with an error) breaks the hub: every later call fails instead of hanging.
-// Purpose: the library's own step loop at world 2 / 4 / 8 on a one-GPU box (tests), with the same decisions
-// (migration trigger from the max over ranks) as over RCCL.
-struct LocalSlot {
-  const void *send = nullptr;
-  const int64_t *send_counts = nullptr;
-  float *red = nullptr;          // this rank's operand of the max reduction (device)
-  float *red_tmp = nullptr;      // hub-owned device word the rank reduces into before copying back
-  hipEvent_t ready = nullptr, done = nullptr;
-};
-
-struct tmdhip_local_hub {
-  int world = 1;
-  std::mutex m;
-  std::condition_variable cv;
-  int arrived = 0;
-  uint64_t phase = 0;
-  bool broken = false;
-  int attached = 0;
-  std::vector<LocalSlot> slot;
-  // false: somebody did not arrive (the hub is broken from then on)
-  bool barrier() {
-    std::unique_lock<std::mutex> lk(m);
-    if (broken) return false;
-    const uint64_t my = phase;
-    if (++arrived == world) {
-      arrived = 0;
-      ++phase;
-      cv.notify_all();
-      return true;
-    }
-    if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return phase != my || broken; })) {
-      broken = true;
-      cv.notify_all();
-      return false;
-    }
-    return !broken;
-  }
-};
-
 struct MaxPtrs {
   const float *p[64];
 };
@@ -394,35 +289,6 @@ __global__ void local_max_kernel(MaxPtrs src, int world, float *out) {
   }
 }
 
-// halo-exchange communicator of one rank + the state of the asynchronous migration trigger
-struct tmdhip_comm {
-  RcclApi api;                       // RCCL transport (hub == nullptr)
-  ncclComm_t comm = nullptr;
-  tmdhip_local_hub *hub = nullptr;   // in-process transport
-  int rank = 0, world = 1;
-  // displacement read-back: two pinned slots / events used alternately; `pending` = slot `cur` holds the
-  // maximum squared displacement measured `at` steps after the last migration
-  float *host_flag = nullptr;
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  int cur = 0;
-  bool pending = false;
-  int64_t at = 0;
-  // per-atom index of the brick's send list (dd_own_kernel writes an atom's outgoing rows itself): valid until the
-  // next migration (tmdhip_dd_reset) for the send list it was built from
-  DevBuf csr_off, csr_row, csr_cur;
-  const void *csr_index = nullptr;
-  int64_t csr_nsend = -1, csr_nown = -1;
-  // displacement-test state of the brick step in flight (dd_fused_front -> dd_fused_back)
-  unsigned chk_seq = 0;
-  unsigned *chk_near = nullptr;
-  int chk_skipped = 0;
-};
-
-#define TMD_NCCL(c, expr)                                                                                   \
-  do {                                                                                                      \
-    ncclResult_t _r = (expr);                                                                               \
-    if (_r != ncclSuccess) return ::tmd::fail(std::string(#expr) + ": " + (c)->api.error_string(_r));       \
-  } while (0)
 
 namespace {
 
@@ -479,6 +345,10 @@ int local_allreduce_max(tmdhip_comm *c, float *buf, hipStream_t st) {
   return 0;
 }
 
+}  // namespace
+
+namespace tmd {
+
 int exchange_rows(tmdhip_comm *c, int dtype, const void *send, const int64_t *send_counts, void *recv,
                   const int64_t *recv_counts, int width, hipStream_t st) {
   const ncclDataType_t dt = dtype == TMDHIP_F32 ? ncclFloat32 : ncclFloat64;
@@ -505,8 +375,56 @@ int allreduce_max(tmdhip_comm *c, void *buf, hipStream_t st) {
   return 0;
 }
 
-// per-atom index of the send list, rebuilt when the list has changed (three short launches once per migration)
-int dd_send_csr(tmdhip_comm *c, const tmdhip_dd_desc *d, hipStream_t st) {
+// all-to-all of one count per peer between the hosts (migrations: how many rows will arrive from whom)
+int exchange_counts(tmdhip_comm *c, const int64_t *send_counts, int64_t *recv_counts, hipStream_t st) {
+  if (c->world == 1) {
+    recv_counts[0] = send_counts[0];
+    return 0;
+  }
+  if (c->hub) {
+    tmdhip_local_hub *h = c->hub;
+    h->slot[c->rank].counts = send_counts;
+    if (!h->barrier()) return fail("in-process communicator: a rank did not arrive at the count exchange");
+    for (int p = 0; p < c->world; ++p) recv_counts[p] = h->slot[p].counts[c->rank];
+    if (!h->barrier()) return fail("in-process communicator: a rank did not arrive behind the count exchange");
+    return 0;
+  }
+  // RCCL: the counts travel as 8-byte words through a small device buffer
+  TMD_TRY(c->cnt_dev.ensure(sizeof(int64_t) * 2 * (size_t)c->world));
+  if (!c->cnt_host && hipHostMalloc((void **)&c->cnt_host, sizeof(int64_t) * 2 * (size_t)c->world, hipHostMallocDefault) != hipSuccess)
+    return fail("exchange_counts: pinned allocation failed");
+  int64_t *dev = c->cnt_dev.as<int64_t>();
+  for (int p = 0; p < c->world; ++p) c->cnt_host[p] = send_counts[p];
+  TMD_HIP(hipMemcpyAsync(dev, c->cnt_host, sizeof(int64_t) * c->world, hipMemcpyHostToDevice, st));
+  TMD_NCCL(c, c->api.group_start());
+  for (int p = 0; p < c->world; ++p) {
+    TMD_NCCL(c, c->api.send(dev + p, 1, ncclFloat64, p, c->comm, st));
+    TMD_NCCL(c, c->api.recv(dev + c->world + p, 1, ncclFloat64, p, c->comm, st));
+  }
+  TMD_NCCL(c, c->api.group_end());
+  TMD_HIP(hipMemcpyAsync(c->cnt_host + c->world, dev + c->world, sizeof(int64_t) * c->world, hipMemcpyDeviceToHost, st));
+  TMD_HIP(hipStreamSynchronize(st));
+  for (int p = 0; p < c->world; ++p) recv_counts[p] = c->cnt_host[c->world + p];
+  return 0;
+}
+
+}  // namespace tmd
+
+namespace {
+
+// per-atom index of the send list, rebuilt when the list has changed (a few short launches once per migration)
+int dd_csr_ready(tmdhip_comm *c, const tmdhip_dd_desc *d, hipStream_t st) {
+  if (d->nsend == 0) {  // nothing to send: every atom's row range is empty
+    TMD_TRY(c->csr_off.ensure(sizeof(int) * ((size_t)d->nown + 1)));
+    if (c->csr_nsend != 0 || c->csr_nown != d->nown) {
+      TMD_HIP(hipMemsetAsync(c->csr_off.p, 0, sizeof(int) * ((size_t)d->nown + 1), st));
+      c->csr_nsend = 0;
+      c->csr_nown = d->nown;
+      c->csr_index = nullptr;
+    }
+    TMD_TRY(c->csr_row.ensure(sizeof(int)));
+    return 0;
+  }
   if (c->csr_index == d->send_index_dev && c->csr_nsend == d->nsend && c->csr_nown == d->nown) return 0;
   if (d->nown + 1 >= ((int64_t)1 << 31) || d->nsend >= ((int64_t)1 << 31)) return fail("tmdhip_dd_run: brick too large");
   TMD_TRY(c->csr_off.ensure(sizeof(int) * ((size_t)d->nown + 1)));
@@ -515,7 +433,13 @@ int dd_send_csr(tmdhip_comm *c, const tmdhip_dd_desc *d, hipStream_t st) {
   TMD_HIP(hipMemsetAsync(c->csr_cur.p, 0, sizeof(int) * ((size_t)d->nown + 1), st));
   const dim3 gs((unsigned)((d->nsend + 255) / 256));
   hipLaunchKernelGGL(csr_count_kernel, gs, dim3(256), 0, st, d->nsend, d->send_index_dev, c->csr_cur.as<int>());
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, (int)d->nown, c->csr_cur.as<int>(), c->csr_off.as<int>());
+  // exclusive prefix over the nown + 1 counts (the last one is 0): off[0 .. nown]; the fill cursors start as a copy
+  size_t tmp = 0;
+  TMD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, c->csr_cur.as<int>(), c->csr_off.as<int>(), (int)d->nown + 1, st));
+  TMD_TRY(c->csr_tmp.ensure(std::max<size_t>(tmp, 16)));
+  tmp = c->csr_tmp.bytes;
+  TMD_HIP(hipcub::DeviceScan::ExclusiveSum(c->csr_tmp.p, tmp, c->csr_cur.as<int>(), c->csr_off.as<int>(), (int)d->nown + 1, st));
+  TMD_HIP(hipMemcpyAsync(c->csr_cur.p, c->csr_off.p, sizeof(int) * ((size_t)d->nown + 1), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(csr_fill_kernel, gs, dim3(256), 0, st, d->nsend, d->send_index_dev, c->csr_cur.as<int>(), c->csr_row.as<int>());
   TMD_HIP(hipGetLastError());
   c->csr_index = d->send_index_dev;
@@ -526,10 +450,11 @@ int dd_send_csr(tmdhip_comm *c, const tmdhip_dd_desc *d, hipStream_t st) {
 
 constexpr double kDdChainNear = 0.75;  // as tmdhip_md_run's kChainSkipNear (md_loop.hip)
 
-// front half of a fused brick step: the pacing decision (leave the rebuild chain out?) and dd_own_kernel
+// front half of a fused brick step: the pacing decision (leave the rebuild chain out?) and — unless the previous pair
+// launch has made this iteration's update itself (step blocks) — dd_own_kernel
 template <typename R>
 int dd_fused_front(tmdhip_ctx *ctx, Replica &rp, tmdhip_comm *c, const tmdhip_dd_desc *d, int phases, uint64_t kick_step,
-                   bool chain_skip_on, bool &pace_timed_out, bool &skip_chain, hipStream_t st) {
+                   bool chain_skip_on, bool stepped, bool &pace_timed_out, bool &skip_chain, hipStream_t st) {
   using R4 = typename Vec<R>::T4;
   const double box0[3] = {0, 0, 0};
   const PairConsts<R> pc = make_consts<R>(ctx, box0);
@@ -577,27 +502,19 @@ int dd_fused_front(tmdhip_ctx *ctx, Replica &rp, tmdhip_comm *c, const tmdhip_dd
     rp.seq_valid = false;
     rp.pub_ptr = nullptr;
   }
-  a.sorted = rp.sorted.as<R4>();
-  a.inv = rp.inv.as<int>();
-  a.qs = ctx->qs.as<R>();
-  a.csr_off = c->csr_off.as<int>();
-  a.csr_row = c->csr_row.as<int>();
-  a.shift = (const R *)d->send_shift_dev;
-  a.out = (R *)d->send_buf_dev;
-  if (d->nsend == 0) {  // nothing to send: every atom's row range is empty
-    TMD_TRY(c->csr_off.ensure(sizeof(int) * ((size_t)d->nown + 1)));
-    if (c->csr_nsend != 0 || c->csr_nown != d->nown) {
-      TMD_HIP(hipMemsetAsync(c->csr_off.p, 0, sizeof(int) * ((size_t)d->nown + 1), st));
-      c->csr_nsend = 0;
-      c->csr_nown = d->nown;
-      c->csr_index = nullptr;
-    }
-    a.csr_off = c->csr_off.as<int>();
-  }
   // the step's displacement-test state, kept for the halo rows (dd_fused_back)
   c->chk_seq = a.chk.seq;
   c->chk_near = a.chk.near_host;
   c->chk_skipped = a.chk.skipped;
+  if (stepped) return 0;  // the step blocks of the previous pair launch have done the rest
+  a.sorted = rp.sorted.as<R4>();
+  a.inv = rp.inv.as<int>();
+  a.qs = ctx->qs.as<R>();
+  TMD_TRY(dd_csr_ready(c, d, st));
+  a.csr_off = c->csr_off.as<int>();
+  a.csr_row = c->csr_row.as<int>();
+  a.shift = (const R *)d->send_shift_dev;
+  a.out = (R *)d->send_buf_dev;
   const dim3 grid((unsigned)((d->nown + 255) / 256));
   if (d->vcoeff_dev) hipLaunchKernelGGL((dd_own_kernel<R, true>), grid, dim3(256), 0, st, a, pc);
   else hipLaunchKernelGGL((dd_own_kernel<R, false>), grid, dim3(256), 0, st, a, pc);
@@ -606,26 +523,90 @@ int dd_fused_front(tmdhip_ctx *ctx, Replica &rp, tmdhip_comm *c, const tmdhip_dd
 }
 
 // back half: the halo rows the exchange has delivered (test + cell-sorted records), then the pair launch with the
-// displacement test already made and, where the front half said so, without the rebuild chain
+// displacement test already made and, where the front half said so, without the rebuild chain.  `fuse_next`: the pair
+// launch makes the NEXT iteration's update of the owned atoms itself (step blocks behind the pair blocks, FusedStep in
+// engine.h: kick of this iteration + drift of the next, the list's displacement test, the cell-sorted records, the
+// migration trigger's maximum and the outgoing halo rows) — fp32 bricks on the lean kernel, never the last iteration
+// of a call (its forces are wanted in `forces_dev`).  Set on return when it did.
 template <typename R>
-int dd_fused_back(tmdhip_ctx *ctx, Replica &rp, tmdhip_comm *c, const tmdhip_dd_desc *d, bool skip_chain, hipStream_t st) {
+int dd_fused_back(tmdhip_ctx *ctx, Replica &rp, tmdhip_comm *c, const tmdhip_dd_desc *d, bool skip_chain, bool was_stepped,
+                  bool want_fuse_next, uint64_t next_kick_step, bool &fused_next, hipStream_t st) {
   using R4 = typename Vec<R>::T4;
   const double box0[3] = {0, 0, 0};
   const PairConsts<R> pc = make_consts<R>(ctx, box0);
   const int n = ctx->d.natoms;
+  ListCheck<R> chk = make_check<R>(ctx, rp);
+  chk.near_host = c->chk_near;
+  chk.seq = c->chk_seq;
+  chk.near_frac2 = (R)(kDdChainNear * kDdChainNear);
+  chk.skipped = c->chk_skipped;
   if (d->nhalo > 0) {
-    ListCheck<R> chk = make_check<R>(ctx, rp);
-    chk.near_host = c->chk_near;
-    chk.seq = c->chk_seq;
-    chk.near_frac2 = (R)(kDdChainNear * kDdChainNear);
-    chk.skipped = c->chk_skipped;
     hipLaunchKernelGGL((dd_halo_kernel<R>), dim3((unsigned)((d->nhalo + 255) / 256)), dim3(256), 0, st, (int)d->nown, n,
                        (const R *)d->pos_dev, chk, pc, rp.inv.as<int>(), ctx->qs.as<R>(), rp.sorted.as<R4>());
     TMD_HIP(hipGetLastError());
   }
   rp.n_compute++;
-  return compute_list<R>(ctx, rp, d->pos_dev, box0, d->forces_dev, nullptr,
-                         TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES | kPrechecked | (skip_chain ? kSkipChain : 0), st);
+  fused_next = false;
+  FusedLaunch fl{};
+  if constexpr (std::is_same<R, float>::value) {
+    if (want_fuse_next && fused_step_possible<float>(ctx, rp, pc) && ctx->fused_step_timeouts == 0) {
+      TMD_TRY(dd_csr_ready(c, d, st));
+      FusedStatic now;
+      std::memset(&now, 0, sizeof(now));
+      now.s.n = n;
+      now.s.vel = (float *)d->vel_dev;
+      now.s.mass = (const float *)d->mass_dev;
+      now.s.vcoeff = (const float *)d->vcoeff_dev;
+      now.s.dt = (float)d->dt;
+      now.s.half_dt = (float)(0.5 * d->dt);
+      now.s.gamma = d->vcoeff_dev ? (float)d->gamma : 0.f;
+      now.s.seed = d->seed;
+      now.s.row0 = 0;
+      now.s.qs = ctx->qs.as<float>();
+      now.s.inv = rp.inv.as<int>();
+      now.s.chk.ref = chk.ref;
+      now.s.chk.hard2 = chk.hard2;
+      now.s.chk.hs2 = chk.hs2;
+      now.s.chk.flags = chk.flags;
+      now.s.chk.near_frac2 = (float)(kDdChainNear * kDdChainNear);
+      now.s.chk.ext = chk.ext;
+      now.nactive = (int)d->nown;
+      now.dd_ref = (const float *)d->ref_dev;
+      now.dd_disp2 = d->disp2_dev;
+      now.dd_csr_off = c->csr_off.as<int>();
+      now.dd_csr_row = c->csr_row.as<int>();
+      now.dd_shift = (const float *)d->send_shift_dev;
+      now.dd_out = (float *)d->send_buf_dev;
+      TMD_TRY(upload_fused_static(rp, now, st));
+      fl.fst = rp.fused_dev.as<FusedStatic>();
+      fl.langevin = d->vcoeff_dev != nullptr;
+      fl.step.pos_in = (const float *)d->pos_dev;  // (no bonded terms: the update reads the cell-sorted records, so it
+      fl.step.pos_out = (float *)d->pos_dev;       // can store the owned rows in place)
+      fl.step.sorted_out = rp.sorted_alt.as<float4>();
+      fl.step.noise_step = next_kick_step;
+      fl.step.bonded = 0;
+      if (rp.pub_ptr) {  // pacing on: the next iteration's sequence number
+        unsigned nseq = rp.seq + 1;
+        if (nseq == 0) nseq = 1;
+        fl.step.seq = nseq;
+        fl.step.near_host = rp.hostpub + 1 + (nseq & 1u);
+      }
+      fused_next = true;
+    }
+  }
+  const int rc = compute_list<R>(ctx, rp, d->pos_dev, box0, d->forces_dev, nullptr,
+                                 TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES | kPrechecked | (skip_chain ? kSkipChain : 0) |
+                                     (skip_chain && was_stepped ? kViolationCheck : 0),
+                                 st, fused_next ? &fl : nullptr);
+  if (rc != 0) {
+    fused_next = false;
+    return rc;
+  }
+  if (fused_next) {
+    std::swap(rp.sorted, rp.sorted_alt);
+    rp.steps_in_pair_launch++;
+  }
+  return 0;
 }
 
 int comm_alloc_trigger(tmdhip_comm *c) {
@@ -721,7 +702,11 @@ void tmdhip_comm_destroy(tmdhip_comm *c) {
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->host_flag) (void)hipHostFree(c->host_flag);
+  if (c->cnt_host) (void)hipHostFree(c->cnt_host);
+  c->cnt_dev.release();
+  c->mig.release();
   c->csr_off.release();
+  c->csr_tmp.release();
   c->csr_row.release();
   c->csr_cur.release();
   delete c;
@@ -765,13 +750,13 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
   };
   // The three-launch step (head comment) needs a cell-list context that holds a list of exactly these rows in an open
   // box; anything else (first call after a migration without a force evaluation, all-pairs bricks) takes the loop of
-  // separate launches.  TMDHIP_DD_FUSED=0 forces that loop (A/B, bit-identity tests).
+  // separate launches.  TMDHIP_DD_FUSED=0 forces that loop, 1 the three-launch loop without step blocks (A/B, tests).
   Replica &rp = ctx->rep[0];
   const char *e_fused = std::getenv("TMDHIP_DD_FUSED");
-  bool fused = !(e_fused && std::atoi(e_fused) == 0) && ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0 &&
-               ctx->d.dtype == d->dtype && d->nown > 0 && (int64_t)ctx->d.natoms == d->nown + d->nhalo &&
-               ctx->d.natoms < (1 << 30) && !ctx->half_skin.p;
-  if (fused && d->nsend > 0) TMD_TRY(dd_send_csr(c, d, st));
+  const int mode = e_fused ? std::max(0, std::min(std::atoi(e_fused), 2)) : 2;  // 0 separate launches, 1 three launches, 2 + step blocks
+  const bool fused = mode >= 1 && ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0 && ctx->d.dtype == d->dtype &&
+                     d->nown > 0 && (int64_t)ctx->d.natoms == d->nown + d->nhalo && ctx->d.natoms < (1 << 30) && !ctx->half_skin.p;
+  bool stepped = false;  // the previous pair launch has made this iteration's update of the owned atoms (step blocks)
   const char *e_skip = std::getenv("TMDHIP_CHAIN_SKIP");
   const bool chain_skip_on = !(e_skip && std::atoi(e_skip) == 0);
   bool pace_timed_out = false;
@@ -782,9 +767,13 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
     const int phases = it == 0 ? d->first_phases : 3;
     const bool fuse_now = fused && rp.have_list && rp.box[0] == 0 && rp.box[1] == 0 && rp.box[2] == 0;
     bool skip_chain = false;
+    const bool was_stepped = stepped;
+    stepped = false;
+    if (was_stepped && !fuse_now) return fail("tmdhip_dd_run: the brick's list vanished between two iterations");
     if (fuse_now) {
-      TMD_TRY(d->dtype == TMDHIP_F32 ? dd_fused_front<float>(ctx, rp, c, d, phases, kick_step, chain_skip_on, pace_timed_out, skip_chain, st)
-                                     : dd_fused_front<double>(ctx, rp, c, d, phases, kick_step, chain_skip_on, pace_timed_out, skip_chain, st));
+      TMD_TRY(d->dtype == TMDHIP_F32
+                  ? dd_fused_front<float>(ctx, rp, c, d, phases, kick_step, chain_skip_on, was_stepped, pace_timed_out, skip_chain, st)
+                  : dd_fused_front<double>(ctx, rp, c, d, phases, kick_step, chain_skip_on, was_stepped, pace_timed_out, skip_chain, st));
     } else {
       TMD_TRY(kick_drift(phases, kick_step));
     }
@@ -842,7 +831,11 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
       TMD_TRY(tmdhip_halo_pack(d->dtype, d->nsend, d->pos_dev, d->send_index_dev, d->send_shift_dev, d->send_buf_dev, stream));
     TMD_TRY(exchange_rows(c, d->dtype, d->send_buf_dev, d->send_counts_host, halo_rows, d->recv_counts_host, 3, st));
     if (fuse_now) {
-      const int rc = d->dtype == TMDHIP_F32 ? dd_fused_back<float>(ctx, rp, c, d, skip_chain, st) : dd_fused_back<double>(ctx, rp, c, d, skip_chain, st);
+      const bool want_next = mode == 2 && it + 1 < d->niter;
+      const uint64_t next_kick = d->step0 + (uint64_t)it;  // (= the next iteration's kick_step)
+      const int rc = d->dtype == TMDHIP_F32
+                         ? dd_fused_back<float>(ctx, rp, c, d, skip_chain, was_stepped, want_next, next_kick, stepped, st)
+                         : dd_fused_back<double>(ctx, rp, c, d, skip_chain, was_stepped, want_next, next_kick, stepped, st);
       rp.pub_ptr = nullptr;
       if (rc) return rc < 0 ? rc : fail("tmdhip_dd_run: the brick's box holds too few cells for the list path");
     } else {

@@ -338,6 +338,15 @@ struct FusedStatic {
                    // 2: heavy topology, the bonded force of this launch's positions is in `fbond` (bonded_wave_kernel
                    // ran in front of the launch: it depends on the positions only)
   const float *fbond;  // [3N], original atom order
+  int nactive;         // atoms with original index >= nactive are not integrated (the halo rows of a brick); INT_MAX otherwise
+  // Brick of a domain decomposition (tmdhip_dd_run; all null otherwise): the step blocks also keep the migration
+  // trigger's displacement maximum (against the positions at the last migration) and write the atom's rows of the
+  // outgoing halo messages (per-atom index of the send list), i.e. all of dd_own_kernel's work (domain.hip)
+  const float *dd_ref;
+  unsigned *dd_disp2;
+  const int *dd_csr_off, *dd_csr_row;
+  const float *dd_shift;
+  float *dd_out;
 };
 
 struct DevBuf {
@@ -387,6 +396,8 @@ struct Replica {
   Grid grid{};
   int ncell = 0;
   ListGeom lg{1, 64, 0, 0};
+  int maxn_keep = 0;  // list capacity before the last atom swap (tmdhip_update_atoms / tmdhip_dd_migrate): a floor for the next
+                      // estimate, so that a swap between atom sets of the same density does not build its first list twice
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
   DevBuf sorted_hs;  // per-atom half skins in cell-sorted order (contexts with skin weights)
@@ -475,6 +486,11 @@ struct tmdhip_ctx {
   std::vector<double> boxes_host;  // what `boxes` currently holds
   int max_excl = 0;
   int nactive = 0x7fffffff;  // atoms with original index >= nactive get empty lists (tmdhip_update_atoms)
+  // Open-boundary contexts plan their cell grid over the bounding box of the positions, read back from the device —
+  // unless the caller knows it (a brick of the domain decomposition: brick + halo, tmdhip_dd_migrate); consumed by
+  // the next re-plan.  Atoms outside the bounds are binned into the edge cells (cell_coord clamps), which is safe.
+  bool open_bounds_valid = false;
+  double open_lo[3] = {0, 0, 0}, open_hi[3] = {0, 0, 0};
   int nexcl = 0;             // entries of the exclusion CSR
   std::vector<tmd::Replica> rep;
   // bonded part lives in bonded.hip
@@ -622,6 +638,11 @@ int launch_pair_lean_f64(tmdhip_ctx *ctx, Replica &rp, const PairConsts<double> 
 // md_loop.hip
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st);
+// device copy of a replica's FusedStatic, re-uploaded (one-thread kernel, stream-ordered) only when a field has changed
+int upload_fused_static(Replica &rp, const FusedStatic &now, hipStream_t st);
+// can the pair launch of this replica integrate the next step itself?  (lean fp32 kernel, 4 .. 64 lanes per atom)
+template <typename R>
+bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairConsts<R> &c);
 // chain skipping: spin until the device has published sequence number `target` (Replica::hostpub[0]); false after 0.2 s
 bool wait_published(volatile unsigned *hp, unsigned target);
 // energies, kinetic energies and list flags of every replica through host-mapped memory + a sequence word the host

@@ -208,6 +208,17 @@ __global__ void fused_upload_kernel(FusedStatic v, FusedStatic *dst) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
 }
 
+int upload_fused_static(Replica &rp, const FusedStatic &now, hipStream_t st) {
+  TMD_TRY(rp.fused_dev.ensure(sizeof(FusedStatic)));
+  if (!rp.fused_host_valid || std::memcmp(&rp.fused_host, &now, sizeof(now)) != 0) {
+    hipLaunchKernelGGL(fused_upload_kernel, dim3(1), dim3(64), 0, st, now, rp.fused_dev.as<FusedStatic>());
+    TMD_HIP(hipGetLastError());
+    std::memcpy(&rp.fused_host, &now, sizeof(now));
+    rp.fused_host_valid = true;
+  }
+  return 0;
+}
+
 // can the pair launch of this replica integrate the next step itself?  (lean fp32 kernel, 4 .. 64 lanes per atom: a
 // pair block's atoms fit one wave of a step block)
 template <typename R>
@@ -510,13 +521,9 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               if (bm == 1) std::memcpy(&now.A, &A, sizeof(A));
               now.has_bonded = bm;
               now.fbond = bm == 2 ? rp.fbond.as<float>() : nullptr;
-              TMD_TRY(rp.fused_dev.ensure(sizeof(FusedStatic)));
+              now.nactive = 0x7fffffff;
               TMD_TRY(rp.pos_alt.ensure(sizeof(R) * stride));
-              if (!rp.fused_host_valid || std::memcmp(&rp.fused_host, &now, sizeof(now)) != 0) {
-                hipLaunchKernelGGL(fused_upload_kernel, dim3(1), dim3(64), 0, st, now, rp.fused_dev.as<FusedStatic>());
-                std::memcpy(&rp.fused_host, &now, sizeof(now));
-                rp.fused_host_valid = true;
-              }
+              TMD_TRY(upload_fused_static(rp, now, st));
               fl.fst = rp.fused_dev.as<FusedStatic>();
               fl.langevin = langevin;
               fl.step.pos_in = pos;
@@ -586,6 +593,8 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   return 0;
 }
 
+template bool fused_step_possible<float>(const tmdhip_ctx *, const Replica &, const PairConsts<float> &);
+template bool fused_step_possible<double>(const tmdhip_ctx *, const Replica &, const PairConsts<double> &);
 template int md_run<float>(tmdhip_ctx *, const tmdhip_md_desc *, hipStream_t);
 template int md_run<double>(tmdhip_ctx *, const tmdhip_md_desc *, hipStream_t);
 

@@ -464,7 +464,8 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
   s.chk.seq = fs.seq;
   s.chk.parity = fs.parity;
   s.chk.skipped = 0;  // (unknown here: the next launch's first thread looks, kLmViolation)
-  const bool integrates = (w == 0 || !bonded) && exists;
+  // (a brick of a domain decomposition integrates the atoms it owns: the halo rows behind them are passive)
+  const bool integrates = (w == 0 || !bonded) && exists && o < fst->nactive;
   AtomIn<float> x{};
   if (integrates) {  // every load of the update but the force, in flight during the bonded part
     x.m = s.mass[o];
@@ -533,6 +534,25 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict_
   if (!integrates) return;
   x.f[0] = __uint_as_float(f.x), x.f[1] = __uint_as_float(f.y), x.f[2] = __uint_as_float(f.z);
   md_step_atom<float, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, fs.bonded != 0, LANGEVIN ? g : nullptr);
+  if (fst->dd_out) {
+    // brick of a domain decomposition (dd_own_kernel's extras, same expressions): the running maximum of the squared
+    // displacement since the last migration and this atom's rows of the outgoing halo messages
+#pragma clang fp contract(off)
+    float p[3], dd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p[k] = s.pos_out[3 * o + k];  // (this lane's own store of a moment ago)
+      const float d = p[k] - fst->dd_ref[3 * o + k];
+      dd += d * d;
+    }
+    if (__float_as_uint(dd) > *fst->dd_disp2) atomicMax(fst->dd_disp2, __float_as_uint(dd));
+    const int s0 = fst->dd_csr_off[o], s1 = fst->dd_csr_off[o + 1];
+    for (int q = s0; q < s1; ++q) {
+      const long long k = fst->dd_csr_row[q];
+#pragma unroll
+      for (int xk = 0; xk < 3; ++xk) fst->dd_out[3 * k + xk] = p[xk] + fst->dd_shift[3 * k + xk];
+    }
+  }
 }
 
 // host side: one launch of the lean fp32 kernel over the replica's list (fl: with step blocks behind the pair blocks)

@@ -333,8 +333,9 @@ class Domain:
         """Take ownership of a set of atoms.  Own positions are kept in the WRAPPED frame (the frame the
         halo images live in) and are integrated in place inside the engine's local position buffer, so
         a step moves no own-atom data around; `unwrap` restores the caller's periodic image on gather."""
+        self._bufs = None  # (fresh tensors: the capacity buffers of a native migration are history)
         self.ids, self.vel = ids, vel.contiguous()
-        self.charges, self.types, self.masses = charges.contiguous(), types.contiguous(), masses.contiguous()
+        self.charges, self.types, self.masses = charges.contiguous(), types.long().contiguous(), masses.contiguous()
         self.nown = len(ids)
         _, w = self.grid.owner(pos)
         self.unwrap = (pos - w).contiguous()
@@ -417,6 +418,97 @@ class Domain:
         self.forces_engine.update_atoms(par, nactive=self.nown)
         self.local_forces = torch.zeros(1, n, 3, dtype=self.dtype, device=self.device)
         self.zero_box = torch.zeros(1, 3, 3, dtype=self.dtype, device=self.device)
+
+    # -- migration in the library (tmdhip_dd_migrate) ---------------------------------------------
+    _OWN_ARRAYS = ("ids", "unwrap", "vel", "charge", "type", "mass", "ref")
+
+    def _alloc_buffers(self, cap_own, cap_rows, cap_send):
+        dev, dt = self.device, self.dtype
+        z = lambda *shape, dtype=dt: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        return dict(cap_own=cap_own, cap_rows=cap_rows, cap_send=cap_send, ids=z(cap_own, dtype=torch.int64), pos=z(cap_rows, 3),
+                    unwrap=z(cap_own, 3), vel=z(cap_own, 3), charge=z(cap_own), type=z(cap_own, dtype=torch.int32), mass=z(cap_own),
+                    ref=z(cap_own, 3), send_index=z(cap_send, dtype=torch.int32), send_shift=z(cap_send, 3), send_buf=z(cap_send, 3),
+                    forces=z(cap_rows, 3))
+
+    def _to_buffers(self):
+        """Move the brick's state into capacity buffers (first native migration, or after a Python one)."""
+        n = self.nown
+        nrows = self.local_pos.shape[1] if getattr(self, "local_pos", None) is not None else n
+        nsend = len(self.send_index32)
+        b = self._alloc_buffers(int(1.2 * n) + 4096, int(1.2 * nrows) + 8192, int(1.25 * nsend) + 4096)
+        b["ids"][:n], b["pos"][:n], b["unwrap"][:n], b["vel"][:n] = self.ids, self.pos, self.unwrap, self.vel
+        b["charge"][:n], b["type"][:n], b["mass"][:n], b["ref"][:n] = self.charges, self.types.to(torch.int32), self.masses, self.ref
+        self._bufs = b
+
+    def _grow_buffers(self, need_own, need_rows, need_send):
+        """A capacity reported too small by tmdhip_dd_migrate: new buffers, the owned rows copied over."""
+        o = self._bufs
+        n = min(self.nown, o["cap_own"])
+        b = self._alloc_buffers(max(o["cap_own"], int(1.25 * need_own) + 1024), max(o["cap_rows"], int(1.25 * need_rows) + 1024),
+                                max(o["cap_send"], int(1.25 * need_send) + 1024))
+        for k in self._OWN_ARRAYS + ("pos",):
+            b[k][:n] = o[k][:n]
+        self._bufs = b
+
+    def _point_at_buffers(self, nown, nhalo, nsend, send_counts, recv_counts):
+        """The brick's fields as views of the capacity buffers after a native migration."""
+        b = self._bufs
+        n = nown + nhalo
+        self.nown = nown
+        self.ids, self.unwrap, self.vel = b["ids"][:nown], b["unwrap"][:nown], b["vel"][:nown]
+        self.charges, self.types, self.masses, self.ref = b["charge"][:nown], b["type"][:nown], b["mass"][:nown], b["ref"][:nown]
+        self.local_pos = b["pos"][:n].view(1, n, 3)
+        self.local_forces = b["forces"][:n].view(1, n, 3)
+        self.pos = self.local_pos[0, :nown]
+        self._own_init = self.pos
+        self.send_index32, self.send_shift, self.send_buf = b["send_index"][:nsend], b["send_shift"][:nsend], b["send_buf"][:nsend]
+        self.plan = SimpleNamespace(send_counts=list(send_counts))
+        self.recv_counts = list(recv_counts)
+        self.vcoeff_unit = torch.sqrt(1.0 / self.masses).contiguous()
+        self.zero_box = torch.zeros(1, 3, 3, dtype=self.dtype, device=self.device)
+        self.forces_engine._atoms_swapped(n, nown)
+
+    def migrate_native(self, comm, stream):
+        """This rank's part of a migration, in the library (every rank of the communicator calls it).  `stream`: the
+        raw HIP stream everything is enqueued on."""
+        import ctypes as C
+
+        from . import _lib as L
+
+        if getattr(self, "_bufs", None) is None:
+            self._to_buffers()
+        eng = self.forces_engine._engine(self.local_pos)
+        world = self.grid.world
+        sc, rc = (C.c_int64 * world)(), (C.c_int64 * world)()
+        tmap = eng.type_map
+        tm = np.ascontiguousarray(tmap, dtype=np.int32) if tmap is not None else None
+        nown_in = self.nown
+        for _ in range(8):
+            b = self._bufs
+            br = L.DdBrick(
+                struct_size=C.sizeof(L.DdBrick), dtype=L.dtype_code(self.dtype), rank=self.rank, world=world,
+                dims=(C.c_int32 * 3)(*self.grid.dims), ntypes_map=len(tm) if tm is not None else 0,
+                box=(C.c_double * 3)(*[float(x) for x in self.grid.box]), halo=self.halo,
+                cap_own=b["cap_own"], cap_rows=b["cap_rows"], cap_send=b["cap_send"], nown=nown_in,
+                ids_dev=b["ids"].data_ptr(), pos_dev=b["pos"].data_ptr(), unwrap_dev=b["unwrap"].data_ptr(),
+                vel_dev=b["vel"].data_ptr(), charge_dev=b["charge"].data_ptr(), type_dev=b["type"].data_ptr(),
+                mass_dev=b["mass"].data_ptr(), ref_dev=b["ref"].data_ptr(), disp2_dev=self.disp2.data_ptr(),
+                send_index_dev=b["send_index"].data_ptr(), send_shift_dev=b["send_shift"].data_ptr(),
+                send_counts_host=C.addressof(sc), recv_counts_host=C.addressof(rc),
+                type_map_host=tm.ctypes.data if tm is not None else None,
+            )
+            with torch.cuda.device(self.device):
+                rcode = L.check(L.load().tmdhip_dd_migrate(eng.ctx, comm, C.byref(br), stream), "tmdhip_dd_migrate")
+            if rcode == 0:
+                self._point_at_buffers(int(br.nown), int(br.nhalo), int(br.nsend), list(sc), list(rc))
+                return
+            # a capacity was too small (nothing is lost: the call resumes where it stopped)
+            if br.need_send > 0:
+                self.nown = nown_in = int(br.nown)  # the owned rows are in place already and must be kept
+            else:
+                self.nown = 0  # the owned rows are still in the library's scratch
+            self._grow_buffers(int(br.need_own), int(br.need_rows), int(br.need_send))
+        raise RuntimeError("tmdhip_dd_migrate: capacities did not settle")
 
     def compute(self, want_energy=False):
         """Forces on the owned atoms from own + halo atoms (open boundaries: images are explicit).
@@ -554,8 +646,52 @@ class DomainSet:
                 due = measured(host) * (1.0 + 2.0 * k / self._since_migration) > limit
         return due
 
+    def _native_migration(self):
+        """Migration in the library (tmdhip_dd_migrate) where the library's communicator exists: over RCCL (one brick
+        per process) or in-process (one host thread per brick).  TMDHIP_DD_MIGRATE=python keeps the torch version."""
+        import os
+        import threading
+
+        if os.environ.get("TMDHIP_DD_MIGRATE", "native") == "python" or self.device.type != "cuda":
+            return False
+        if not self.local:
+            comm = self.transport.native()
+            if comm is None:
+                return False
+            d = next(iter(self.domains.values()))
+            d.migrate_native(comm, torch.cuda.current_stream(self.device).cuda_stream)
+            self._recv_counts["halo"] = d.recv_counts
+            return True
+        if not self.transport.native_threads:
+            return False
+        comms, streams = self.transport.native(self.device)
+        torch.cuda.synchronize(self.device)
+        errors = {}
+
+        def work(r):
+            try:
+                with torch.cuda.device(self.device), torch.cuda.stream(streams[r]):
+                    self.domains[r].migrate_native(comms[r], streams[r].cuda_stream)
+            except Exception as exc:  # noqa: BLE001
+                errors[r] = repr(exc)
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in self.domains]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize(self.device)
+        if errors:
+            raise RuntimeError(f"tmdhip_dd_migrate failed on ranks {sorted(errors)}: {next(iter(errors.values()))}")
+        return True
+
     def migrate(self):
         """Re-assign atoms to bricks, rebuild halo plans and engines."""
+        if self._native_migration():
+            self.migrations += 1
+            self._since_migration = 0
+            self._pending = None
+            return
         payloads, counts = {}, {}
         for r, d in self.domains.items():
             owner, _ = self.grid.owner(d.pos)
@@ -715,7 +851,7 @@ class DomainSet:
             first = 3
         for d in self.domains.values():
             if not d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos):
-                raise RuntimeError("a neighbour list of a brick was truncated during the batch (capacity has been grown): "
+                raise RuntimeError(f"a neighbour list of a brick became invalid during the batch ({L.last_error()}): "
                                    "repeat the batch")
 
     def _step_native(self, comm, niter, dt, gamma, vnoise, seed):
@@ -746,7 +882,7 @@ class DomainSet:
             remaining -= 1
             first = 3
         if not d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos):
-            raise RuntimeError("a neighbour list of the brick was truncated during the batch (capacity has been grown): "
+            raise RuntimeError(f"a neighbour list of the brick became invalid during the batch ({L.last_error()}): "
                                "repeat the batch")
 
     # -- gathering (tests / output) ---------------------------------------------------------------

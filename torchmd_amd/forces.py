@@ -356,6 +356,16 @@ class Forces:
             eng.ebuf.zero_()
         self._nactive = nactive
 
+    def _atoms_swapped(self, natoms, nactive):
+        """Host-side bookkeeping of an atom swap the library has made itself (tmdhip_dd_migrate wrote the contexts'
+        per-atom arrays on the device): what `update_atoms` does around its C call."""
+        self.natoms = int(natoms)
+        self._excl_csr = (np.zeros(self.natoms + 1, dtype=np.int32), np.zeros(0, dtype=np.int32))
+        self._ava_idx = None
+        self._nactive = nactive
+        for eng in self._engines.values():
+            eng.ebuf.zero_()
+
     def close(self):
         """Release the device contexts (they are re-created on the next compute())."""
         for eng in self._engines.values():
