@@ -157,6 +157,13 @@ bool plan_pad_rows(const tmdhip_ctx *ctx, const double *box) {
   return 0.25 * std::sqrt(diag2) > ctx->rlist + 2.0 * ctx->skin;
 }
 
+// kLmStream: lists whose rows exceed 384 MB in total (capacity: ~1.4 x the entries) cannot live in the 256 MiB Infinity
+// Cache from one launch to the next.  TMDHIP_LIST_STREAM=0 / 1 overrides (A/B).
+bool list_streams(const tmdhip_ctx *ctx, const Replica &rp) {
+  if (const char *e = std::getenv("TMDHIP_LIST_STREAM")) return std::atoi(e) != 0;
+  return (size_t)ctx->d.natoms * (size_t)rp.lg.maxn * 4u > ((size_t)384 << 20);
+}
+
 template <typename R>
 int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   using R4 = typename Vec<R>::T4;
@@ -310,7 +317,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
   const int overwrite = (flags & TMDHIP_OVERWRITE_FORCES) ? 1 : 0;
   // list duties of the pair launch's first thread: rp.step counts the NEXT step by now
   const int lmode = ((flags & kViolationCheck) ? kLmViolation : 0) | (((rp.step - 1) & 1) ? kLmParity : 0) |
-                    (rp.pad_rows ? kLmPadded : 0);
+                    (rp.pad_rows ? kLmPadded : 0) | (list_streams(ctx, rp) ? kLmStream : 0);
   FusedLaunch fl{};
   if (fused) {
     fl = *fused;

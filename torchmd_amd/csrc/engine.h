@@ -216,6 +216,31 @@ constexpr int kEntryTypes = 32;                  // LJ classes that fit the entr
 constexpr int kEntryTypeShift = 27;
 constexpr float kR2Floor = 1.0e-2f;  // (0.1 A)^2: keeps 1/r^14 finite for the self entries that pad a column
 
+// Padded list rows (Replica::pad_rows): the entry that fills the padding slots of atom `a`'s row — one of the two dummy
+// records behind the last atom (slots n, n + 1 of the cell-sorted copy), the one further away under the minimum image.
+// p = the atom's record (zero for the lanes past the last atom).
+__device__ __forceinline__ void pad_dummy_positions(const PairConsts<float> &c, float (&d0)[3], float (&d1)[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const bool open = !(c.box[k] > 0.f);
+    d0[k] = open ? 1.0e6f : 0.25f * c.box[k];
+    d1[k] = open ? 1.0e6f : 0.75f * c.box[k];
+  }
+}
+__device__ __forceinline__ unsigned pad_entry_for(const PairConsts<float> &c, int n, float px, float py, float pz) {
+  float d0[3], d1[3];
+  pad_dummy_positions(c, d0, d1);
+  const float p[3] = {px, py, pz};
+  float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float e0 = min_image(p[k] - d0[k], c.box[k], c.invbox[k]), e1 = min_image(p[k] - d1[k], c.box[k], c.invbox[k]);
+    r0 += e0 * e0;
+    r1 += e1 * e1;
+  }
+  return (unsigned)(n + (r1 > r0 ? 1 : 0)) << 4;
+}
+
 struct ListGeom {
   int lpa;        // lanes per atom in the pair kernel (power of two, 1..64)
   int apw;        // atoms per wave = 64 / lpa
@@ -327,6 +352,7 @@ constexpr int kAuxVolatile = (int)0x80000000;  // bit 31 of a raw-buffer intrins
 constexpr int kLmViolation = 1;  // the chain of this step was left out and its displacement test ran in the previous
                                  // launch's epilogue, which could not know that: a rebuild request found now = F_VIOLATION
 constexpr int kLmParity = 2;     // parity of this step
+constexpr int kLmStream = 8;     // the list does not fit the Infinity Cache: stream it with the non-temporal hint (pair_fast_f32.hip)
 constexpr int kLmPadded = 4;     // the list's padding slots hold harmless entries (Replica::pad_rows): no per-lane validity
 constexpr int kFastThreads = 256;  // threads of a block of the lean fp32 pair kernel (step blocks are four waves)
 

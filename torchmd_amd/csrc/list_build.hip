@@ -608,12 +608,7 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(int n, float4 *__restrict
                                                        unsigned *__restrict__ nlist, const int *flag) {
   if (*flag == 0) return;
   float d0[3], d1[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const bool open = !(c.box[k] > 0.f);
-    d0[k] = open ? 1.0e6f : 0.25f * c.box[k];
-    d1[k] = open ? 1.0e6f : 0.75f * c.box[k];
-  }
+  pad_dummy_positions(c, d0, d1);
   if (blockIdx.x == 0 && threadIdx.x < 2) {
     const float4 rec = threadIdx.x == 0 ? make_float4(d0[0], d0[1], d0[2], 0.f) : make_float4(d1[0], d1[1], d1[2], 0.f);
     sorted[n + threadIdx.x] = rec;
@@ -634,15 +629,7 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(int n, float4 *__restrict
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) itmax = max(itmax, __shfl_xor(itmax, o, 64));
   const int padded = (itmax + 3) & ~3;
-  float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float pk = k == 0 ? p.x : (k == 1 ? p.y : p.z);
-    const float e0 = min_image(pk - d0[k], c.box[k], c.invbox[k]), e1 = min_image(pk - d1[k], c.box[k], c.invbox[k]);
-    r0 += e0 * e0;
-    r1 += e1 * e1;
-  }
-  const unsigned entry = (unsigned)(n + (r1 > r0 ? 1 : 0)) << 4;
+  const unsigned entry = pad_entry_for(c, n, p.x, p.y, p.z);
   unsigned *row = nlist + ((size_t)g * lg.maxn << (6 - lg.lpa_shift));
   for (int kk = myiters; kk < padded; ++kk) row[(((kk >> 2) << 6) + lane) * 4 + (kk & 3)] = entry;
 }

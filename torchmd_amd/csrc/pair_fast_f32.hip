@@ -120,8 +120,8 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   const __amdgpu_buffer_rsrc_t lrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(wrow), 0, maxn * APW * 4 + 4096, 0x00020000);
   const unsigned lvoff = (unsigned)lane * 16u;
-  auto list_word = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * 1024, 0); };
-  v4u word = list_word(0);  // list word of the next group to be gathered (in flight)
+  auto list_word_raw = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * 1024, 0); };
+  v4u word = list_word_raw(0);  // list word of the next group to be gathered (in flight)
   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
   int nn = 0, oi = 0;
   unsigned trow = 0;  // byte offset of this atom's row of the LDS table
@@ -268,6 +268,26 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   };
   const int gall = (nkk + UNROLL - 1) / UNROLL;  // groups of this wave
   int g = 0;                                     // next group to evaluate; `word` = its list word
+  // (a request past the wave's last group — the look-ahead of its last iterations — would stream 1 KB of padding per
+  // wave for nothing: 64 MB of the 560 MB a 10^6-atom LJ launch moves, 12 MB of 222 at C3; scalar branch, wave-uniform)
+  // Lists that do not fit the 256 MiB Infinity Cache anyway (kLmStream: 10^6 LJ atoms, large water boxes) are streamed
+  // with the non-temporal hint, so that they do not displace the position records from the L2s: 10^6-atom LJ launch
+  // 138 -> 127 us.  (At C3, whose 162 MB list lives in the Infinity Cache, the hint costs 35 %: hence a run-time choice;
+  // wave-uniform scalar branch.)  Not fetching the words of a group that hold nothing but padding was tried too
+  // (offset out of range for those lanes, padding entry formed in the kernel): no gain, removed.
+  const bool stream_list = lmode & kLmStream;
+  auto list_word = [&](int gg) {
+    v4u w = (v4u){0u, 0u, 0u, 0u};
+#ifdef TMD_AB_NO_TAIL_GUARD  // A/B build switch (tools/ab_pair.py): request unconditionally, as before round 4
+    w = list_word_raw(gg);
+#else
+    if (gg < gall) {
+      if (stream_list) w = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, gg * 1024, 2 /* nt */);
+      else w = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, gg * 1024, 0);
+    }
+#endif
+    return w;
+  };
   // A list word is requested AFTER the gathers issued in the same breath (see the head comment); sched_barrier pins
   // that order against the compiler's preference.
   auto checked_loop = [&](auto image) {  // per-lane validity; not pipelined (the tail is short)

@@ -465,7 +465,8 @@ class Domain:
         self.plan = SimpleNamespace(send_counts=list(send_counts))
         self.recv_counts = list(recv_counts)
         self.vcoeff_unit = torch.sqrt(1.0 / self.masses).contiguous()
-        self.zero_box = torch.zeros(1, 3, 3, dtype=self.dtype, device=self.device)
+        if getattr(self, "zero_box", None) is None:  # (the same tensor every time: Forces caches its host copy by object)
+            self.zero_box = torch.zeros(1, 3, 3, dtype=self.dtype, device=self.device)
         self.forces_engine._atoms_swapped(n, nown)
 
     def migrate_native(self, comm, stream):
