@@ -30,7 +30,7 @@ TIMESTEP_FS = 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
+PMC_TRAFFIC_FILES = ("r04_b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 FLOP_PER_PAIR = 50.0             # ~50 FLOP + 1 rsqrt per in-cutoff pair
 SIMDS, NOMINAL_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues over 2 cycles per SIMD
@@ -109,10 +109,10 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
-C5_TRAFFIC_FILES = ("r04_c5_pmc_traffic.json", "r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json")  # newest committed PMC pass first
+C5_TRAFFIC_FILES = ("r04_b_c5_pmc_traffic.json", "r04_c5_pmc_traffic.json", "r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json")  # newest committed PMC pass first
 
 
-def c5_single_gpu(args, device, cpu_budget_s=15.0):
+def c5_single_gpu(args, device, cpu_budget_s=15.0, steps=None, warmup=None):
     """Config C5 on ONE GPU: the whole 10^6-atom argon box on the single-domain engine.  Returns the fields of a bench
     line (value, ms_per_step, roofline, cpu_baseline, ...): `--config c5 --gpus 1` prints them as its line, the default
     run embeds them as `secondary.c5`."""
@@ -135,21 +135,23 @@ def c5_single_gpu(args, device, cpu_budget_s=15.0):
     f = Forces(par, terms=["lj"], cutoff=CUTOFF, **({} if args.skin is None else {"skin": args.skin}))
     f.compute(s.pos, s.box, s.forces)
     integ = Integrator(s, f, TIMESTEP_FS, device, gamma=1.0, T=85.0)
-    integ.step(max(args.warmup, 1))
-    stride = timing_stride(args.steps)
-    f.enable_timing(s.pos, True, every=stride, limit=SHORT_TIMED if args.steps < 128 else 0, skip=1 if args.steps < 128 else 0)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    integ.step(max(warmup, 1))
+    stride = timing_stride(steps)
+    f.enable_timing(s.pos, True, every=stride, limit=SHORT_TIMED if steps < 128 else 0, skip=1 if steps < 128 else 0)
     f.read_timing(s.pos, reset=True)
     st0 = f.stats(s.pos)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ekin, epot, temp = integ.step(args.steps)
+    ekin, epot, temp = integ.step(steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     pair_ms, pair_launches = f.read_timing(s.pos, reset=True)
     st1 = f.stats(s.pos)
     pcut = f.count_pairs(s.pos, s.box)[0]
     # (as in the C3 line: the timed launches also make the MD step -> SURVEY 8(d)'s whole-step bytes)
-    fused = st1["steps_in_pair_launch"] - st0["steps_in_pair_launch"] >= args.steps - 2
+    fused = st1["steps_in_pair_launch"] - st0["steps_in_pair_launch"] >= steps - 2
     alg_bytes = 4.0 * pcut + (132.0 if fused else 28.0) * natoms
     pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
     achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
@@ -163,9 +165,9 @@ def c5_single_gpu(args, device, cpu_budget_s=15.0):
         except Exception:
             continue
     out = {
-        "value": ns_per_day(args.steps, elapsed), "unit": "ns/day", "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f32", "natoms": natoms, "box": [float(x) for x in box],
-        "pairs_in_cutoff": pcut, "pair_interactions_per_s": pcut * args.steps / elapsed,
+        "value": ns_per_day(steps, elapsed), "unit": "ns/day", "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "natoms": natoms, "box": [float(x) for x in box],
+        "pairs_in_cutoff": pcut, "pair_interactions_per_s": pcut * steps / elapsed,
         "roofline": {
             "kernel": "list_pair_fast_f32_kernel (fp32, LJ)" + (" with the MD step in the same launch (step blocks)" if fused else ""),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -552,11 +554,12 @@ def main():
     forces.close()
     if rank == 0 and world == 1 and args.nside == 32 and not args.no_secondary:
         # Secondary configuration in the same line (headline keys untouched): BASELINE.json's config 5 on this one GPU —
-        # the 10^6-atom argon box on the single-domain engine, same --steps / --warmup.  A failure is recorded, not raised.
+        # the 10^6-atom argon box on the single-domain engine, max(--steps, 200) steps.  A failure is recorded, not raised.
         del system, forces, integ
         torch.cuda.empty_cache()
         try:
-            c5 = c5_single_gpu(args, device, cpu_budget_s=8.0)
+            # (at least 200 steps: the list of this box is rebuilt every ~80 steps, a 20-step window would hold none)
+            c5 = c5_single_gpu(args, device, cpu_budget_s=8.0, steps=max(args.steps, 200), warmup=max(args.warmup, 50))
             c5["metric"] = "ns/day, 1M-atom Lennard-Jones box, 9 A cutoff, 1 GPU (the cpu_baseline is extrapolated from a 125k-atom sample)"
             c5["config"] = {"workload": c5_workload(c5["natoms"], c5["box"]), "natoms": c5["natoms"], "timestep_fs": TIMESTEP_FS}
             out["secondary"] = {"c5": c5}
