@@ -726,7 +726,8 @@ def test_fused_launch_timeout_falls_back_to_the_integrator_kernel(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin", "water_counter_wraps",
-                                  "water_32_lanes", "water_64_lanes", "thrombin"])
+                                  "water_32_lanes", "water_64_lanes", "thrombin",
+                                  "water_langevin@f64", "water_nve@f64", "lj_langevin@f64", "water_counter_wraps@f64", "thrombin@f64"])
 def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     """Interior steps of tmdhip_md_run on the lean fp32 pair kernel are made by the pair launch itself ("step blocks"
     behind the pair blocks wait for the pair waves of their atoms: FusedStep in csrc/engine.h, pair_fast_f32.hip) instead of by an
@@ -737,15 +738,17 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     `water_counter_wraps`: the launch number the force records carry starts at 2^32 - 20 and wraps during the run
     (0 is skipped: it means "never written").  `thrombin`: a protein (4 676 atoms, all seven terms, open boundaries) —
     a heavy topology, whose bonded force is evaluated by bonded_wave_kernel in front of the pair launch into a buffer
-    that the step blocks add."""
+    that the step blocks add.  `@f64`: the same through the lean fp64 kernel."""
     from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import Integrator, maxwell_boltzmann
     from torchmd_amd.parameters import Parameters
     from torchmd_amd.systems import System
 
-    dev, dt = _dev(), torch.float32
+    case, _, prec = case.partition("@")  # "@f64": the lean fp64 kernel's step blocks (32-byte force records, round 4)
+    dev, dt = _dev(), (torch.float64 if prec == "f64" else torch.float32)
     monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    monkeypatch.setenv("TMDHIP_FUSED_STEP_F64", "1")  # (fp64 step blocks are opt-in: correct, but slower than the separate kernel)
     if case == "water_counter_wraps":
         monkeypatch.setenv("TMDHIP_DEBUG_FUSED_GEN0", str(2**32 - 20))
     nrep = 2 if case == "water_two_replicas" else 1
@@ -798,7 +801,10 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     assert torch.equal(p1, p0) and torch.equal(v1, v0) and torch.equal(f1, f0)
     for a, b in zip(r1, r0):
         for x, y in zip(a, b):
-            assert np.array_equal(np.asarray(x), np.asarray(y))
+            if prec == "f64":  # (energies are folded with atomics: sums of fp64 terms depend on their order in the last bits)
+                assert np.allclose(np.asarray(x), np.asarray(y), rtol=1e-12, atol=0)
+            else:
+                assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
 @pytest.mark.gpu

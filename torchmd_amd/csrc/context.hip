@@ -201,7 +201,7 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
 
 template <typename R>
 int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces,
-                 double *energies, int flags, hipStream_t st, const FusedLaunch *fused) {
+                 double *energies, int flags, hipStream_t st, const FusedLaunchT<R> *fused) {
   const int n = ctx->d.natoms;
   const R *pos = (const R *)pos_v;
   const PairConsts<R> c = make_consts<R>(ctx, box);
@@ -318,7 +318,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
   // list duties of the pair launch's first thread: rp.step counts the NEXT step by now
   const int lmode = ((flags & kViolationCheck) ? kLmViolation : 0) | (((rp.step - 1) & 1) ? kLmParity : 0) |
                     (rp.pad_rows ? kLmPadded : 0) | (list_streams(ctx, rp) ? kLmStream : 0);
-  FusedLaunch fl{};
+  FusedLaunchT<R> fl{};
   if (fused) {
     fl = *fused;
     fl.step.parity = (int)(rp.step & 1);
@@ -393,9 +393,9 @@ int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
 template int alloc_replica<float>(tmdhip_ctx *, Replica &, int);
 template int alloc_replica<double>(tmdhip_ctx *, Replica &, int);
 template int compute_list<float>(tmdhip_ctx *, Replica &, const void *, const double *, void *, double *, int, hipStream_t,
-                                 const FusedLaunch *);
+                                 const FusedLaunchT<float> *);
 template int compute_list<double>(tmdhip_ctx *, Replica &, const void *, const double *, void *, double *, int, hipStream_t,
-                                  const FusedLaunch *);
+                                  const FusedLaunchT<double> *);
 
 }  // namespace tmd
 

@@ -547,42 +547,42 @@ int dd_fused_back(tmdhip_ctx *ctx, Replica &rp, tmdhip_comm *c, const tmdhip_dd_
   }
   rp.n_compute++;
   fused_next = false;
-  FusedLaunch fl{};
-  if constexpr (std::is_same<R, float>::value) {
-    if (want_fuse_next && fused_step_possible<float>(ctx, rp, pc) && ctx->fused_step_timeouts == 0) {
+  FusedLaunchT<R> fl{};
+  {
+    if (want_fuse_next && fused_step_possible<R>(ctx, rp, pc) && ctx->fused_step_timeouts == 0) {
       TMD_TRY(dd_csr_ready(c, d, st));
-      FusedStatic now;
+      FusedStaticT<R> now;
       std::memset(&now, 0, sizeof(now));
       now.s.n = n;
-      now.s.vel = (float *)d->vel_dev;
-      now.s.mass = (const float *)d->mass_dev;
-      now.s.vcoeff = (const float *)d->vcoeff_dev;
-      now.s.dt = (float)d->dt;
-      now.s.half_dt = (float)(0.5 * d->dt);
-      now.s.gamma = d->vcoeff_dev ? (float)d->gamma : 0.f;
+      now.s.vel = (R *)d->vel_dev;
+      now.s.mass = (const R *)d->mass_dev;
+      now.s.vcoeff = (const R *)d->vcoeff_dev;
+      now.s.dt = (R)d->dt;
+      now.s.half_dt = (R)(0.5 * d->dt);
+      now.s.gamma = d->vcoeff_dev ? (R)d->gamma : R(0);
       now.s.seed = d->seed;
       now.s.row0 = 0;
-      now.s.qs = ctx->qs.as<float>();
+      now.s.qs = ctx->qs.as<R>();
       now.s.inv = rp.inv.as<int>();
       now.s.chk.ref = chk.ref;
       now.s.chk.hard2 = chk.hard2;
       now.s.chk.hs2 = chk.hs2;
       now.s.chk.flags = chk.flags;
-      now.s.chk.near_frac2 = (float)(kDdChainNear * kDdChainNear);
+      now.s.chk.near_frac2 = (R)(kDdChainNear * kDdChainNear);
       now.s.chk.ext = chk.ext;
       now.nactive = (int)d->nown;
-      now.dd_ref = (const float *)d->ref_dev;
+      now.dd_ref = (const R *)d->ref_dev;
       now.dd_disp2 = d->disp2_dev;
       now.dd_csr_off = c->csr_off.as<int>();
       now.dd_csr_row = c->csr_row.as<int>();
-      now.dd_shift = (const float *)d->send_shift_dev;
-      now.dd_out = (float *)d->send_buf_dev;
-      TMD_TRY(upload_fused_static(rp, now, st));
-      fl.fst = rp.fused_dev.as<FusedStatic>();
+      now.dd_shift = (const R *)d->send_shift_dev;
+      now.dd_out = (R *)d->send_buf_dev;
+      TMD_TRY(upload_fused_static<R>(rp, now, st));
+      fl.fst = rp.fused_dev.as<FusedStaticT<R>>();
       fl.langevin = d->vcoeff_dev != nullptr;
-      fl.step.pos_in = (const float *)d->pos_dev;  // (no bonded terms: the update reads the cell-sorted records, so it
-      fl.step.pos_out = (float *)d->pos_dev;       // can store the owned rows in place)
-      fl.step.sorted_out = rp.sorted_alt.as<float4>();
+      fl.step.pos_in = (const R *)d->pos_dev;  // (no bonded terms: the update reads the cell-sorted records, so it
+      fl.step.pos_out = (R *)d->pos_dev;       // can store the owned rows in place)
+      fl.step.sorted_out = rp.sorted_alt.as<R4>();
       fl.step.noise_step = next_kick_step;
       fl.step.bonded = 0;
       if (rp.pub_ptr) {  // pacing on: the next iteration's sequence number

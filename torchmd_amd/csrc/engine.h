@@ -329,12 +329,14 @@ struct AtomIn {
   int slot;
 };
 
-// ---- the MD step inside the pair launch (FUSED variants of the lean fp32 kernel; pair_fast_f32.hip) ----------
-struct FusedStep {   // what does (kernel argument)
-  const float *pos_in;  // positions of this launch's forces, original atom order (partners of the bonded terms)
-  float *pos_out;       // drifted positions
-  float4 *sorted_out;   // their cell-sorted records
-  float4 *fsort;        // {pair force, launch number} per atom, cell-sorted order (pair blocks write, step blocks watch)
+// ---- the MD step inside the pair launch (FUSED variants of the lean kernels; pair_fast_f32.hip, pair_lean_f64.hip) ----
+template <typename R>
+struct FusedStepT {   // what does (kernel argument)
+  const R *pos_in;  // positions of this launch's forces, original atom order (partners of the bonded terms)
+  R *pos_out;       // drifted positions
+  typename Vec<R>::T4 *sorted_out;   // their cell-sorted records
+  typename Vec<R>::T4 *fsort;        // {pair force, launch number} per atom, cell-sorted order (pair blocks write, step blocks
+                                     // watch); fp64: 32 bytes, the launch number in the low word of the fourth double
   unsigned gen;         // number of this launch (never 0): what the pair blocks write beside a force
   unsigned watch_gen;   // what the step blocks wait for: == gen (a test knob makes it differ, so that the wait times out)
   unsigned poll_limit;  // polls of a force record before a step block gives up (F_STEP_TIMEOUT)
@@ -345,6 +347,7 @@ struct FusedStep {   // what does (kernel argument)
   unsigned seq;
   int parity;           // of the next step
 };
+using FusedStep = FusedStepT<float>;
 constexpr int kAuxDeviceScope = 16;  // sc1 of a gfx942/950 buffer access: coherent across the XCDs' L2s
 constexpr int kAuxVolatile = (int)0x80000000;  // bit 31 of a raw-buffer intrinsic's aux operand: a volatile access (the
                                                // compiler must neither hoist it out of a loop nor merge two of them)
@@ -356,24 +359,26 @@ constexpr int kLmStream = 8;     // the list does not fit the Infinity Cache: st
 constexpr int kLmPadded = 4;     // the list's padding slots hold harmless entries (Replica::pad_rows): no per-lane validity
 constexpr int kFastThreads = 256;  // threads of a block of the lean fp32 pair kernel (step blocks are four waves)
 
-// ---- the step in the lean fp32 pair kernel's epilogue (see FusedStep above the kernel) -------------------------
-struct FusedStatic {
-  MdStepArgs<float> s;  // per-launch fields (pos_in/out, sorted, noise_step, chk.near_host/seq/parity) come from FusedStep
-  BondedArgs<float> A;
+// ---- the step in the lean pair kernels' launch (see FusedStepT above) -------------------------------------------
+template <typename R>
+struct FusedStaticT {
+  MdStepArgs<R> s;  // per-launch fields (pos_in/out, sorted, noise_step, chk.near_host/seq/parity) come from FusedStepT
+  BondedArgs<R> A;
   int has_bonded;  // 1: light topology, the atoms' bonded records are evaluated here (md_step_bonded_kernel's job);
                    // 2: heavy topology, the bonded force of this launch's positions is in `fbond` (bonded_wave_kernel
                    // ran in front of the launch: it depends on the positions only)
-  const float *fbond;  // [3N], original atom order
-  int nactive;         // atoms with original index >= nactive are not integrated (the halo rows of a brick); INT_MAX otherwise
+  const R *fbond;  // [3N], original atom order
+  int nactive;     // atoms with original index >= nactive are not integrated (the halo rows of a brick); INT_MAX otherwise
   // Brick of a domain decomposition (tmdhip_dd_run; all null otherwise): the step blocks also keep the migration
   // trigger's displacement maximum (against the positions at the last migration) and write the atom's rows of the
   // outgoing halo messages (per-atom index of the send list), i.e. all of dd_own_kernel's work (domain.hip)
-  const float *dd_ref;
+  const R *dd_ref;
   unsigned *dd_disp2;
   const int *dd_csr_off, *dd_csr_row;
-  const float *dd_shift;
-  float *dd_out;
+  const R *dd_shift;
+  R *dd_out;
 };
+using FusedStatic = FusedStaticT<float>;
 
 struct DevBuf {
   void *p = nullptr;
@@ -443,7 +448,7 @@ struct Replica {
   // the MD step in the pair kernel's epilogue (FusedStep): the second cell-sorted copy (`sorted` is always the current
   // one: the two are swapped after every fused launch) and the static arguments, on the device and as last uploaded
   DevBuf sorted_alt, fused_dev;
-  FusedStatic fused_host;
+  alignas(16) unsigned char fused_host[sizeof(FusedStaticT<double>)];  // last upload (a FusedStaticT of the context's precision)
   bool fused_host_valid = false;
   DevBuf fsort;            // {pair force, launch number} per atom in cell-sorted order (fused launches)
   DevBuf fbond;            // bonded force of a fused launch's positions (heavy topologies), original atom order
@@ -602,12 +607,14 @@ inline void launch_with_events(K kernel, dim3 grid, dim3 block, unsigned shmem, 
   else hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
 }
 
-// a FUSED launch of the lean fp32 pair kernel (see FusedStep): device copy of the static part, this launch's part
-struct FusedLaunch {
-  const FusedStatic *fst;
-  FusedStep step;
+// a FUSED launch of a lean pair kernel (see FusedStepT): device copy of the static part, this launch's part
+template <typename R>
+struct FusedLaunchT {
+  const FusedStaticT<R> *fst;
+  FusedStepT<R> step;
   bool langevin;
 };
+using FusedLaunch = FusedLaunchT<float>;
 
 constexpr size_t kRideMaxAtoms = 2048;  // bonded terms ride on the all-pairs launch up to this many atoms
 constexpr int kForcesZeroed = 1 << 17;  // internal: the integrator kernel has already cleared `forces`
@@ -627,7 +634,7 @@ template <typename R>
 int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn);
 template <typename R>
 int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces, double *energies,
-                 int flags, hipStream_t st, const FusedLaunch *fused = nullptr);
+                 int flags, hipStream_t st, const FusedLaunchT<R> *fused = nullptr);
 // bonded.hip
 void bonded_release(tmdhip_ctx *ctx);
 int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A);
@@ -652,7 +659,7 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
 template <typename R, bool ENERGY>
 int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, int overwrite, double *energies,
                      unsigned long long *paircount, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
-                     int lmode = 0, const FusedLaunch *fl = nullptr, bool fold = true);
+                     int lmode = 0, const FusedLaunchT<R> *fl = nullptr, bool fold = true);
 int halve_pair_count(unsigned long long *count_dev, hipStream_t st);
 // pair_fast_f32.hip / pair_lean_f64.hip: the lean kernels behind launch_list_pair (LJ and/or electrostatics, <= 32 LJ classes)
 template <bool ENERGY>
@@ -660,13 +667,14 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
                          hipEvent_t e0, hipEvent_t e1, int lmode, const FusedLaunch *fl);
 template <bool ENERGY>
 int launch_pair_lean_f64(tmdhip_ctx *ctx, Replica &rp, const PairConsts<double> &c, double *f, int overwrite,
-                         hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+                         hipStream_t st, hipEvent_t e0, hipEvent_t e1, int lmode, const FusedLaunchT<double> *fl);
 // md_loop.hip
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st);
 // device copy of a replica's FusedStatic, re-uploaded (one-thread kernel, stream-ordered) only when a field has changed
-int upload_fused_static(Replica &rp, const FusedStatic &now, hipStream_t st);
-// can the pair launch of this replica integrate the next step itself?  (lean fp32 kernel, 4 .. 64 lanes per atom)
+template <typename R>
+int upload_fused_static(Replica &rp, const FusedStaticT<R> &now, hipStream_t st);
+// can the pair launch of this replica integrate the next step itself?  (lean kernels, 4 .. 64 lanes per atom)
 template <typename R>
 bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairConsts<R> &c);
 // chain skipping: spin until the device has published sequence number `target` (Replica::hostpub[0]); false after 0.2 s

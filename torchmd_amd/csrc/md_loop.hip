@@ -204,26 +204,39 @@ bool wait_published(volatile unsigned *hp, unsigned target) {
 }
 
 // the static arguments of the fused step travel as a kernel argument (stream-ordered, no pinned staging, no host wait)
-__global__ void fused_upload_kernel(FusedStatic v, FusedStatic *dst) {
+template <typename R>
+__global__ void fused_upload_kernel(FusedStaticT<R> v, FusedStaticT<R> *dst) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
 }
 
-int upload_fused_static(Replica &rp, const FusedStatic &now, hipStream_t st) {
-  TMD_TRY(rp.fused_dev.ensure(sizeof(FusedStatic)));
-  if (!rp.fused_host_valid || std::memcmp(&rp.fused_host, &now, sizeof(now)) != 0) {
-    hipLaunchKernelGGL(fused_upload_kernel, dim3(1), dim3(64), 0, st, now, rp.fused_dev.as<FusedStatic>());
+template <typename R>
+int upload_fused_static(Replica &rp, const FusedStaticT<R> &now, hipStream_t st) {
+  static_assert(sizeof(FusedStaticT<R>) <= sizeof(rp.fused_host), "Replica::fused_host holds either precision");
+  TMD_TRY(rp.fused_dev.ensure(sizeof(FusedStaticT<double>)));
+  if (!rp.fused_host_valid || std::memcmp(rp.fused_host, &now, sizeof(now)) != 0) {
+    hipLaunchKernelGGL((fused_upload_kernel<R>), dim3(1), dim3(64), 0, st, now, rp.fused_dev.as<FusedStaticT<R>>());
     TMD_HIP(hipGetLastError());
-    std::memcpy(&rp.fused_host, &now, sizeof(now));
+    std::memcpy(rp.fused_host, &now, sizeof(now));
     rp.fused_host_valid = true;
   }
   return 0;
 }
+template int upload_fused_static<float>(Replica &, const FusedStaticT<float> &, hipStream_t);
+template int upload_fused_static<double>(Replica &, const FusedStaticT<double> &, hipStream_t);
 
-// can the pair launch of this replica integrate the next step itself?  (lean fp32 kernel, 4 .. 64 lanes per atom: a
-// pair block's atoms fit one wave of a step block)
+// can the pair launch of this replica integrate the next step itself?  (lean kernels — fp32, and since round 4 fp64 —
+// 4 .. 64 lanes per atom: a pair block's atoms fit one wave of a step block)
 template <typename R>
 bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairConsts<R> &c) {
-  if (!std::is_same<R, float>::value) return false;
+  // fp64: built and bit-identical in round 4, and measured SLOWER at C3 (pair + step launch 126 us against 82.5 + a 15-us
+  // integrator kernel; 151 against 124.5 us per step): the fp64 kernel's 3 072 pair blocks are exactly three rounds of
+  // the 1 024 that are resident at four waves per SIMD, so there is no partial last round whose idle slots the step
+  // blocks could use — they run behind the pair work, with the fp64 noise and bonded code spilling under the pair
+  // path's 128-register cap.  Opt-in: TMDHIP_FUSED_STEP_F64=1.
+  if (std::is_same<R, double>::value) {
+    const char *e64 = std::getenv("TMDHIP_FUSED_STEP_F64");
+    if (!(e64 && std::atoi(e64) != 0)) return false;
+  }
   const char *e = std::getenv("TMDHIP_FUSED_STEP");  // (read per call: tests switch it within a process)
   if (e && std::atoi(e) == 0) return false;
   if (ctx->fused_off_call || ctx->fused_disabled) return false;  // repetition of a batch whose fused launch timed out
@@ -483,10 +496,10 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       if (ctx->d.terms != 0) {
         rp.n_compute++;
         if (list) {
-          // interior step on the lean fp32 kernel: the pair launch makes the next step itself (FusedStep)
-          FusedLaunch fl{};
+          // interior step on a lean kernel: the pair launch makes the next step itself (FusedStepT)
+          FusedLaunchT<R> fl{};
           bool fuse = false;
-          if constexpr (std::is_same<R, float>::value) {
+          {
             const int bm = (check && it + 1 < d->niter && !en && fused_step_possible<R>(ctx, rp, c))
                                ? tmd::bonded_inline_args(ctx, box, A) : -1;
             if (bm >= 0) {
@@ -498,7 +511,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
                 TMD_TRY(tmdhip_compute_bonded(ctx, r, pos, box, rp.fbond.p, nullptr,
                                               TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES, st));
               }
-              FusedStatic now;
+              FusedStaticT<R> now;
               std::memset(&now, 0, sizeof(now));
               now.s.n = n;
               now.s.vel = a.vel;
@@ -520,11 +533,11 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               now.s.chk.ext = a.chk.ext;
               if (bm == 1) std::memcpy(&now.A, &A, sizeof(A));
               now.has_bonded = bm;
-              now.fbond = bm == 2 ? rp.fbond.as<float>() : nullptr;
+              now.fbond = bm == 2 ? rp.fbond.as<R>() : nullptr;
               now.nactive = 0x7fffffff;
               TMD_TRY(rp.pos_alt.ensure(sizeof(R) * stride));
               TMD_TRY(upload_fused_static(rp, now, st));
-              fl.fst = rp.fused_dev.as<FusedStatic>();
+              fl.fst = rp.fused_dev.as<FusedStaticT<R>>();
               fl.langevin = langevin;
               fl.step.pos_in = pos;
               fl.step.pos_out = pos == home ? rp.pos_alt.as<R>() : home;
@@ -548,7 +561,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
                                          st, fuse ? &fl : nullptr);
           rp.pub_ptr = nullptr;
           if (fuse && rc == 0) {
-            if constexpr (std::is_same<R, float>::value) cur[r] = fl.step.pos_out;
+            cur[r] = fl.step.pos_out;
             std::swap(rp.sorted, rp.sorted_alt);
             stepped[r] = 1;
             rp.steps_in_pair_launch++;

@@ -88,4 +88,158 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
   for (int k = 0; k < 3; ++k) vel[3 * i + k] = v[k];
 }
 
+// ---- the MD step inside a pair launch: step blocks (FusedStepT / FusedStaticT in engine.h) -----------------------------
+constexpr int kStepPollSleep = 4;  // s_sleep argument between two polls of a force record (x 64 cycles)
+
+// The force record a pair wave leaves for the step block that integrates its atom: {fx, fy, fz, launch number}.
+// fp32: ONE 16-byte store written through to device scope (sc1) — the number in .w says the force beside it is this
+// launch's.  fp64: 32 bytes as two 16-byte stores, {fx, fy} first, then — after the first has been acknowledged
+// (s_waitcnt vmcnt(0): stores retire in order behind it) — {fz, number}; the reader polls the second half and fetches
+// the first once the number is there.
+__device__ __forceinline__ void store_force_record(float4 *fsort, int n, int a, float sx, float sy, float sz, unsigned gen) {
+  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fsort, 0, n * 16, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128((v4u){__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(sz), gen}, frsrc, a * 16, 0,
+                                         kAuxDeviceScope);
+}
+__device__ __forceinline__ void store_force_record(double4 *fsort, int n, int a, double sx, double sy, double sz, unsigned gen) {
+  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fsort, 0, n * 32, 0x00020000);
+  const unsigned long long bx = (unsigned long long)__double_as_longlong(sx), by = (unsigned long long)__double_as_longlong(sy),
+                           bz = (unsigned long long)__double_as_longlong(sz);
+  __builtin_amdgcn_raw_buffer_store_b128((v4u){(unsigned)bx, (unsigned)(bx >> 32), (unsigned)by, (unsigned)(by >> 32)}, frsrc, a * 32, 0,
+                                         kAuxDeviceScope);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (expcnt / lgkmcnt left alone): the first half has been written through
+  __builtin_amdgcn_raw_buffer_store_b128((v4u){(unsigned)bz, (unsigned)(bz >> 32), gen, 0u}, frsrc, a * 32 + 16, 0, kAuxDeviceScope);
+}
+// one look at atom slot a's record: true (and the force in f) when it carries launch number `want`
+__device__ __forceinline__ bool load_force_record(const __amdgpu_buffer_rsrc_t &frsrc, float, int a, unsigned want, float (&f)[3]) {
+  const v4u r = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope | kAuxVolatile);
+  if (r.w != want) return false;
+  f[0] = __uint_as_float(r.x), f[1] = __uint_as_float(r.y), f[2] = __uint_as_float(r.z);
+  return true;
+}
+__device__ __forceinline__ bool load_force_record(const __amdgpu_buffer_rsrc_t &frsrc, double, int a, unsigned want, double (&f)[3]) {
+  const v4u hi = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 32 + 16, 0, kAuxDeviceScope | kAuxVolatile);
+  if (hi.z != want) return false;
+  const v4u lo = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 32, 0, kAuxDeviceScope | kAuxVolatile);
+  f[0] = __hiloint2double((int)lo.y, (int)lo.x), f[1] = __hiloint2double((int)lo.w, (int)lo.z);
+  f[2] = __hiloint2double((int)hi.y, (int)hi.x);
+  return true;
+}
+
+// Step block j of a FUSED pair launch (four waves, 64 atoms): the atoms of the 64 / APB pair blocks that run on the
+// same XCD (block ids congruent mod 8) and are neighbours in the cell-sorted order.  Like md_step_bonded_kernel, wave w
+// evaluates bonded record slots w, w + 4, ... of all 64 atoms (lane = atom), the partial forces meet in LDS as
+// (p0 + p1) + (p2 + p3), and the first wave updates — after it has waited for the pair waves of its atoms.
+// s_lds: room for kQuad x 3 x 64 values of R (the pair role's LJ table space).
+template <typename R, bool LANGEVIN, int APB>
+__device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restrict__ fst, const FusedStepT<R> &fs,
+                                                  const PairConsts<R> &c, int n, const typename Vec<R>::T4 *__restrict__ sorted,
+                                                  const int *__restrict__ order, int j, int npair, R *s_lds) {
+  using R4 = typename Vec<R>::T4;
+  constexpr int K = 64 / APB;  // pair blocks per 64 atoms
+  R(*s_part)[3][64] = reinterpret_cast<R(*)[3][64]>(s_lds);  // [kQuad][3][64]
+  const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  // With bonded records a step block is 64 atoms (its four waves share their records); without, every wave is a unit
+  // of 64 atoms of its own (four waves of which three only met at the barrier doubled the waves of a 10^6-atom LJ launch).
+  const bool bonded = fs.bonded == 1;  // (launch-uniform; 2 = the bonded force comes from a buffer: waves are units too)
+  const int xcd = j & 7, q = bonded ? (j >> 3) : (j >> 3) * kQuad + w, g8 = npair >> 3;
+  const int kc = K * q + lane / APB;  // this lane's pair block within the XCD's eighth
+  const int a = (xcd * g8 + kc) * APB + lane % APB;
+  const bool exists = kc < g8 && a < n;
+  const int o = exists ? order[a] : 0;
+  MdStepArgs<R> s = fst->s;
+  s.pos_in = fs.pos_in;
+  s.pos_out = fs.pos_out;
+  s.sorted = fs.sorted_out;
+  s.noise_step = fs.noise_step;
+  s.f_zero = nullptr;
+  s.chk.near_host = fs.near_host;
+  s.chk.seq = fs.seq;
+  s.chk.parity = fs.parity;
+  s.chk.skipped = 0;  // (unknown here: the next launch's first thread looks, kLmViolation)
+  // (a brick of a domain decomposition integrates the atoms it owns: the halo rows behind them are passive)
+  const bool integrates = (w == 0 || !bonded) && exists && o < fst->nactive;
+  AtomIn<R> x{};
+  if (integrates) {  // every load of the update but the force, in flight during the bonded part
+    x.m = s.mass[o];
+    x.vc = LANGEVIN ? s.vcoeff[o] : R(0);
+    const R4 p = sorted[a];  // x, y, z, scaled charge: exactly what the position buffer holds
+    x.p[0] = p.x, x.p[1] = p.y, x.p[2] = p.z;
+    x.q = p.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      x.v[k] = s.vel[3 * o + k];
+      x.r[k] = s.chk.ref[3 * o + k];
+    }
+    x.h2 = list_check_limit(s.chk, o);
+    x.slot = a;
+  }
+  R fb[3] = {0, 0, 0};
+  R g[3] = {0, 0, 0};
+  if (bonded) {
+    R fx = 0, fy = 0, fz = 0;
+    if (exists) {
+      const BondedArgs<R> A = fst->A;
+      double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
+      const AtomRec<R> *rec = A.arec + (size_t)o * A.arec_stride;
+      for (int k = w; k < A.arec_stride; k += kQuad) {
+        const AtomRec<R> r = rec[k];
+        if (r.ent == kNoRec) break;  // records are packed from the front
+        eval_rec<R>(A, s.pos_in, o, r, fx, fy, fz, e);
+      }
+    }
+    s_part[w][0][lane] = fx;
+    s_part[w][1][lane] = fy;
+    s_part[w][2][lane] = fz;
+    if (LANGEVIN && integrates) normal3<R>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
+  } else {
+    if (fs.bonded == 2 && integrates) {
+      const R *fbond = fst->fbond;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fb[k] = fbond[3 * o + k];
+    }
+    if (LANGEVIN && integrates) normal3<R>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
+  }
+  // Wait for this atom's force record of THIS launch.  Its pair block has a lower block id: it was dispatched before
+  // this block (in-order dispatch of a grid's workgroups — what the hardware does, not something HIP promises) and
+  // waits for nothing.  Should that ever not hold, the wait is bounded: the lane gives up, reports F_STEP_TIMEOUT and
+  // does NOT integrate its atom; the caller rewinds the batch and repeats it with the separate integrator kernel
+  // (judge_flags).  The poll is a volatile device-scope load: nothing may hoist it out of the loop.
+  if (!integrates) return;
+  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fs.fsort, 0, n * (int)sizeof(R4), 0x00020000);
+  unsigned spins = 0;
+  while (!load_force_record(frsrc, R(0), a, fs.watch_gen, x.f)) {
+    __builtin_amdgcn_s_sleep(kStepPollSleep);
+    if (++spins > fs.poll_limit) {
+      s.chk.flags[F_STEP_TIMEOUT] = 1;
+      return;  // no update from a stale record
+    }
+  }
+  md_step_atom<R, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, fs.bonded != 0, LANGEVIN ? g : nullptr);
+  if (fst->dd_out) {
+    // brick of a domain decomposition (dd_own_kernel's extras, same expressions): the running maximum of the squared
+    // displacement since the last migration and this atom's rows of the outgoing halo messages
+#pragma clang fp contract(off)
+    R p[3], dd = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p[k] = s.pos_out[3 * o + k];  // (this lane's own store of a moment ago)
+      const R d = p[k] - fst->dd_ref[3 * o + k];
+      dd += d * d;
+    }
+    const float d2 = sizeof(R) == 4 ? (float)dd : __double2float_ru((double)dd);
+    if (__float_as_uint(d2) > *fst->dd_disp2) atomicMax(fst->dd_disp2, __float_as_uint(d2));
+    const int s0 = fst->dd_csr_off[o], s1 = fst->dd_csr_off[o + 1];
+    for (int q2 = s0; q2 < s1; ++q2) {
+      const long long k = fst->dd_csr_row[q2];
+#pragma unroll
+      for (int xk = 0; xk < 3; ++xk) fst->dd_out[3 * k + xk] = p[xk] + fst->dd_shift[3 * k + xk];
+    }
+  }
+}
+
 }  // namespace tmd

@@ -62,12 +62,6 @@ constexpr int kFastWaves = TMD_AB_LDS_GATHER ? 4 : 5;  // waves per SIMD of the 
 // Other blocks still read the positions of this launch, so the new ones go to the OTHER position buffer and the
 // OTHER cell-sorted copy (the host swaps the two after every fused launch).  Same device functions in the same
 // order as md_step_bonded_kernel / md_step_kernel: trajectories are bit-identical to the separate kernels.
-template <bool LANGEVIN, int APB>
-__device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict__ fst, const FusedStep &fs,
-                                                  const PairConsts<float> &c, int n, const float4 *__restrict__ sorted,
-                                                  const int *__restrict__ order, int j, int npair, float *s_lds);
-
-constexpr int kStepPollSleep = 4;  // s_sleep argument between two polls of a force record (x 64 cycles)
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
 // (LJ-only systems — liquid argon, short lists of ~90 entries — run the plain loop at one wave more per SIMD: 10^6 atoms
 // 175.5 -> 168.5 us/step; with charges the pipelined loop at 5 waves wins, section 6c)
@@ -96,8 +90,8 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   // pair blocks of the launch (FUSED: step blocks follow them)
   const unsigned npair = FUSED ? gridDim.x - (unsigned)fstep.nstep_blocks : gridDim.x;
   if (FUSED && blockIdx.x >= npair) {
-    fused_step_blocks<FUSED == 2, kFastThreads / LPA>(fst, fstep, c, n, sorted, order, (int)(blockIdx.x - npair),
-                                                          (int)npair, reinterpret_cast<float *>(stab));
+    fused_step_blocks<float, FUSED == 2, kFastThreads / LPA>(fst, fstep, c, n, sorted, order, (int)(blockIdx.x - npair),
+                                                                 (int)npair, reinterpret_cast<float *>(stab));
     return;
   }
   // XCD-aware block order: consecutive block ids go to the 8 XCDs round-robin, so block b works on
@@ -426,10 +420,7 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     // store written through to device scope (sc1): the number in .w says the force beside it is this launch's.
     // (A flag per wave behind the stores cost a memory round trip more at the end of the launch; an agent-scope
     // release does it with buffer_wbl2, a write-back of the whole L2 per wave: 365 us per launch.)
-    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fstep.fsort, 0, n * 16, 0x00020000);
-    if (active && sub == 0)
-      __builtin_amdgcn_raw_buffer_store_b128((v4u){__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(sz), fstep.gen},
-                                             frsrc, a * 16, 0, kAuxDeviceScope);
+    if (active && sub == 0) store_force_record(fstep.fsort, n, a, sx, sy, sz, fstep.gen);
     return;
   }
   if (active && sub == 0 && forces) {
@@ -451,126 +442,6 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     if (ELEC) {
       const double s = wave_sum((double)e_el);
       if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_ELECTROSTATICS], 0.5 * s);
-    }
-  }
-}
-
-// Step block j of a FUSED pair launch (four waves, 64 atoms): the atoms of the 64 / APB pair blocks that run on the
-// same XCD (block ids congruent mod 8) and are neighbours in the cell-sorted order.  Like md_step_bonded_kernel, wave w
-// evaluates bonded record slots w, w + 4, ... of all 64 atoms (lane = atom), the partial forces meet in LDS as
-// (p0 + p1) + (p2 + p3), and the first wave updates — after it has waited for the pair waves of its atoms.
-template <bool LANGEVIN, int APB>
-__device__ __forceinline__ void fused_step_blocks(const FusedStatic *__restrict__ fst, const FusedStep &fs,
-                                                  const PairConsts<float> &c, int n, const float4 *__restrict__ sorted,
-                                                  const int *__restrict__ order, int j, int npair, float *s_lds) {
-  constexpr int K = 64 / APB;  // pair blocks per 64 atoms
-  float(*s_part)[3][64] = reinterpret_cast<float(*)[3][64]>(s_lds);  // [kQuad][3][64], the pair role's LJ table space
-  const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-  // With bonded records a step block is 64 atoms (its four waves share their records); without, every wave is a unit
-  // of 64 atoms of its own (four waves of which three only met at the barrier doubled the waves of a 10^6-atom LJ launch).
-  const bool bonded = fs.bonded == 1;  // (launch-uniform; 2 = the bonded force comes from a buffer: waves are units too)
-  const int xcd = j & 7, q = bonded ? (j >> 3) : (j >> 3) * kQuad + w, g8 = npair >> 3;
-  const int kc = K * q + lane / APB;  // this lane's pair block within the XCD's eighth
-  const int a = (xcd * g8 + kc) * APB + lane % APB;
-  const bool exists = kc < g8 && a < n;
-  const int o = exists ? order[a] : 0;
-  MdStepArgs<float> s = fst->s;
-  s.pos_in = fs.pos_in;
-  s.pos_out = fs.pos_out;
-  s.sorted = fs.sorted_out;
-  s.noise_step = fs.noise_step;
-  s.f_zero = nullptr;
-  s.chk.near_host = fs.near_host;
-  s.chk.seq = fs.seq;
-  s.chk.parity = fs.parity;
-  s.chk.skipped = 0;  // (unknown here: the next launch's first thread looks, kLmViolation)
-  // (a brick of a domain decomposition integrates the atoms it owns: the halo rows behind them are passive)
-  const bool integrates = (w == 0 || !bonded) && exists && o < fst->nactive;
-  AtomIn<float> x{};
-  if (integrates) {  // every load of the update but the force, in flight during the bonded part
-    x.m = s.mass[o];
-    x.vc = LANGEVIN ? s.vcoeff[o] : 0.f;
-    const float4 p = sorted[a];  // x, y, z, scaled charge: exactly what the position buffer holds
-    x.p[0] = p.x, x.p[1] = p.y, x.p[2] = p.z;
-    x.q = p.w;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      x.v[k] = s.vel[3 * o + k];
-      x.r[k] = s.chk.ref[3 * o + k];
-    }
-    x.h2 = list_check_limit(s.chk, o);
-    x.slot = a;
-  }
-  float fb[3] = {0.f, 0.f, 0.f};
-  float g[3] = {0.f, 0.f, 0.f};
-  if (bonded) {
-    float fx = 0.f, fy = 0.f, fz = 0.f;
-    if (exists) {
-      const BondedArgs<float> A = fst->A;
-      double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
-      const AtomRec<float> *rec = A.arec + (size_t)o * A.arec_stride;
-      for (int k = w; k < A.arec_stride; k += kQuad) {
-        const AtomRec<float> r = rec[k];
-        if (r.ent == kNoRec) break;  // records are packed from the front
-        eval_rec<float>(A, s.pos_in, o, r, fx, fy, fz, e);
-      }
-    }
-    s_part[w][0][lane] = fx;
-    s_part[w][1][lane] = fy;
-    s_part[w][2][lane] = fz;
-    if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
-    __syncthreads();
-    if (w != 0) return;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
-  } else {
-    if (fs.bonded == 2 && integrates) {
-      const float *fbond = fst->fbond;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fb[k] = fbond[3 * o + k];
-    }
-    if (LANGEVIN && integrates) normal3<float>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
-  }
-  // Wait for this atom's force record of THIS launch (.w = launch number; a 16-byte access is one request at the L2).
-  // Its pair block has a lower block id: it was dispatched before this block (in-order dispatch of a grid's workgroups —
-  // what the hardware does, not something HIP promises) and waits for nothing.  Should that ever not hold, the wait is
-  // bounded: the lane gives up, reports F_STEP_TIMEOUT and does NOT integrate its atom; the caller rewinds the batch
-  // and repeats it with the separate integrator kernel (judge_flags).  The poll is a volatile device-scope load:
-  // nothing may hoist it out of the loop.
-  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fs.fsort, 0, n * 16, 0x00020000);
-  v4u f = (v4u){0u, 0u, 0u, fs.watch_gen};
-  if (integrates) {
-    unsigned spins = 0;
-    while (true) {
-      f = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope | kAuxVolatile);
-      if (f.w == fs.watch_gen) break;
-      __builtin_amdgcn_s_sleep(kStepPollSleep);
-      if (++spins > fs.poll_limit) {
-        s.chk.flags[F_STEP_TIMEOUT] = 1;
-        return;  // no update from a stale record
-      }
-    }
-  }
-  if (!integrates) return;
-  x.f[0] = __uint_as_float(f.x), x.f[1] = __uint_as_float(f.y), x.f[2] = __uint_as_float(f.z);
-  md_step_atom<float, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, fs.bonded != 0, LANGEVIN ? g : nullptr);
-  if (fst->dd_out) {
-    // brick of a domain decomposition (dd_own_kernel's extras, same expressions): the running maximum of the squared
-    // displacement since the last migration and this atom's rows of the outgoing halo messages
-#pragma clang fp contract(off)
-    float p[3], dd = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      p[k] = s.pos_out[3 * o + k];  // (this lane's own store of a moment ago)
-      const float d = p[k] - fst->dd_ref[3 * o + k];
-      dd += d * d;
-    }
-    if (__float_as_uint(dd) > *fst->dd_disp2) atomicMax(fst->dd_disp2, __float_as_uint(dd));
-    const int s0 = fst->dd_csr_off[o], s1 = fst->dd_csr_off[o + 1];
-    for (int q = s0; q < s1; ++q) {
-      const long long k = fst->dd_csr_row[q];
-#pragma unroll
-      for (int xk = 0; xk < 3; ++xk) fst->dd_out[3 * k + xk] = p[xk] + fst->dd_shift[3 * k + xk];
     }
   }
 }

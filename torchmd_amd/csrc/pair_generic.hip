@@ -324,7 +324,7 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
 template <typename R, bool ENERGY>
 int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, int overwrite, double *energies,
                      unsigned long long *paircount, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int lmode,
-                     const FusedLaunch *fl, bool fold) {
+                     const FusedLaunchT<R> *fl, bool fold) {
   using R4 = typename Vec<R>::T4;
   using R2 = typename Vec<R>::T2;
   const int n = ctx->d.natoms;
@@ -343,14 +343,14 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
       return 0;
     }
   }
-  if (fl) return fail("fused MD step: the context does not run the lean fp32 pair kernel");
   if constexpr (std::is_same<R, double>::value) {
-    if (lean && (f || ENERGY)) {  // lean fp64 kernel (same conditions as the fp32 one)
-      TMD_TRY(launch_pair_lean_f64<ENERGY>(ctx, rp, c, f, overwrite, st, e0, e1));
+    if (lean && (f || ENERGY || fl)) {  // lean fp64 kernel (same conditions as the fp32 one)
+      TMD_TRY(launch_pair_lean_f64<ENERGY>(ctx, rp, c, f, overwrite, st, e0, e1, lmode, fl));
       if (ENERGY && fold) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
       return 0;
     }
   }
+  if (fl) return fail("fused MD step: the context does not run a lean pair kernel");
 #define TMD_LAUNCH(L, F)                                                                                \
   launch_with_events(list_pair_kernel<R, ENERGY, L, F>, dim3(blocks), dim3(256), shmem, st, e0, e1, n,  \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,          \
@@ -387,7 +387,7 @@ template int launch_allpairs<double>(tmdhip_ctx *, const void *, const double *,
                                      hipStream_t, int, const BondedArgs<double> *);
 #define TMD_INSTANTIATE_LLP(R, E)                                                                                          \
   template int launch_list_pair<R, E>(tmdhip_ctx *, Replica &, const PairConsts<R> &, R *, int, double *, unsigned long long *, \
-                                      hipStream_t, hipEvent_t, hipEvent_t, int, const FusedLaunch *, bool)
+                                      hipStream_t, hipEvent_t, hipEvent_t, int, const FusedLaunchT<R> *, bool)
 TMD_INSTANTIATE_LLP(float, true);
 TMD_INSTANTIATE_LLP(float, false);
 TMD_INSTANTIATE_LLP(double, true);
