@@ -836,6 +836,12 @@ def test_wrong_continuation_hint_is_rewound(monkeypatch):
     integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
     integ.step(12)
     integ.step(12)  # (a call whose hint is right: continuation)
+    # the hint is USED: one-step calls have no interior step, so any chain they leave out is their first step's (six
+    # consecutive steps cannot all follow a near-limit report: the list lives ~9 steps)
+    before = f.stats(s.pos)["chains_skipped"]
+    for _ in range(6):
+        integ.step(1)
+    assert f.stats(s.pos)["chains_skipped"] > before
     skipped0 = f.stats(s.pos)["chains_skipped"]
     version = s.pos._version
     # shear the box by 0.9 A (more than any half skin) along the plane x = L/2: whole molecules move (by their oxygen's

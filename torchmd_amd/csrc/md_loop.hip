@@ -430,7 +430,10 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         rp.pub_ptr = rp.hostpub;
         rp.pub_val = rp.seq;
       } else {
-        rp.seq_valid = false;
+        // (the final kick of a call — it == niter, no drift, no test — leaves the report of the call's last step valid:
+        // that is what the next call's first step looks at when the caller vouches for a continuation.  Round 4: this
+        // branch used to clear it for every iteration without pacing, which made the hint a no-op.)
+        if (first) rp.seq_valid = false;
         rp.pub_ptr = nullptr;
       }
       a.sorted = rp.sorted.as<R4>();
