@@ -654,7 +654,8 @@ def test_every_lanes_per_atom_variant(lpa, monkeypatch):
 
 @pytest.mark.parametrize("case", ["water-4", "water-8", "water-32", "lj-4", "thrombin-open"])
 def test_padded_list_rows_are_bit_identical(case, monkeypatch):
-    """Padded rows (pad_rows_kernel): the padding slots of every wave group point at a dummy record out of reach and the
+    """Padded rows: the padding slots of every wave group point at a dummy record out of reach (written by the pair waves
+    on their first launch after a list build) and the
     lean fp32 kernel runs every group unchecked.  A padding slot contributes exactly 0 and the real entries see the
     same arithmetic in the same order, so forces and energies must equal the unpadded list's (TMDHIP_PAD_ROWS=0) bit
     for bit — plain evaluations and along an MD trajectory (fused pair + step launches, device-side rebuilds).  Water:

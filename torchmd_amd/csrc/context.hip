@@ -142,7 +142,7 @@ bool plan_grid(const tmdhip_ctx *ctx, const double *box, const double *lo, const
   return false;
 }
 
-// Padded list rows (pad_rows_kernel): fp32 contexts whose entries can address the two dummy records with bits 20..22
+// Padded list rows (engine.h: pad_entry_for; the pair waves write the padding, pair_fast_f32.hip): fp32 contexts whose entries can address the two dummy records with bits 20..22
 // of the slot clear, in a box where one of the dummies is always out of reach — they are half a box diagonal apart, so
 // one of them is >= a quarter of the diagonal from any atom at build time, and an atom moves less than one skin before
 // the next build.  A box with an open dimension has them 10^6 A out.  TMDHIP_PAD_ROWS=0 switches the padding off.
@@ -196,6 +196,11 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
     return fail("neighbour list would exceed 2^30 entries per replica (32-bit row offsets)");
   // + 16 wave-rows of padding: the pair kernels prefetch up to three 4-iteration groups past a group's rows
   TMD_TRY(rp.nlist.ensure(sizeof(unsigned) * (groups * maxn * rp.lg.apw + 16 * 64)));
+  // one word per wave group: the rebuild count at which the pair waves padded the group's rows (0: never)
+  if (rp.padgen.bytes < sizeof(int) * (groups + 8)) {  // (+ the surplus waves of the last pair block)
+    TMD_TRY(rp.padgen.ensure(sizeof(int) * (groups + 8)));
+    TMD_HIP(hipMemset(rp.padgen.p, 0, rp.padgen.bytes));
+  }
   return 0;
 }
 

@@ -398,13 +398,14 @@ int exchange_counts(tmdhip_comm *c, const int64_t *send_counts, int64_t *recv_co
   TMD_HIP(hipMemcpyAsync(dev, c->cnt_host, sizeof(int64_t) * c->world, hipMemcpyHostToDevice, st));
   TMD_NCCL(c, c->api.group_start());
   for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;  // (what a rank keeps needs no message)
     TMD_NCCL(c, c->api.send(dev + p, 1, ncclFloat64, p, c->comm, st));
     TMD_NCCL(c, c->api.recv(dev + c->world + p, 1, ncclFloat64, p, c->comm, st));
   }
   TMD_NCCL(c, c->api.group_end());
   TMD_HIP(hipMemcpyAsync(c->cnt_host + c->world, dev + c->world, sizeof(int64_t) * c->world, hipMemcpyDeviceToHost, st));
   TMD_HIP(hipStreamSynchronize(st));
-  for (int p = 0; p < c->world; ++p) recv_counts[p] = c->cnt_host[c->world + p];
+  for (int p = 0; p < c->world; ++p) recv_counts[p] = p == c->rank ? send_counts[p] : c->cnt_host[c->world + p];
   return 0;
 }
 

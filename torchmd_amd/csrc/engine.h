@@ -206,6 +206,9 @@ struct PlaceArgs {
   R vs_floor, vs_time, vs_cap;
   R *hs2_dyn;
   int *ext;
+  // padded rows (fp32): the two dummy records behind the last atom, rewritten with every build (null: none)
+  typename Vec<R>::T4 *dummy_a, *dummy_b;  // sorted + n of the target copy, and of the replica's second copy (or null)
+  R dummy_pos[2][3];
 };
 
 // list entry = type_j << 27 | j << 4 (j = cell-sorted slot, 23 bits): `entry & kEntryOffMask` is the byte offset
@@ -356,7 +359,7 @@ constexpr int kLmViolation = 1;  // the chain of this step was left out and its 
                                  // launch's epilogue, which could not know that: a rebuild request found now = F_VIOLATION
 constexpr int kLmParity = 2;     // parity of this step
 constexpr int kLmStream = 8;     // the list does not fit the Infinity Cache: stream it with the non-temporal hint (pair_fast_f32.hip)
-constexpr int kLmPadded = 4;     // the list's padding slots hold harmless entries (Replica::pad_rows): no per-lane validity
+constexpr int kLmPadded = 4;     // Replica::pad_rows: the dummy records exist; a wave group whose padgen word equals the rebuild count is padded
 constexpr int kFastThreads = 256;  // threads of a block of the lean fp32 pair kernel (step blocks are four waves)
 
 // ---- the step in the lean pair kernels' launch (see FusedStepT above) -------------------------------------------
@@ -411,10 +414,10 @@ struct DevBuf {
 // skins of the displacement test, the list itself (the ACTIVE set of a replica lives in the Replica's members of the
 // same names; swapping two DevBufs swaps pointers)
 struct ListBufs {
-  DevBuf cell_of, slot, order_tmp, count, cell_start, order, inv, stype, ref, sorted_hs, hs2_dyn, nlist, nneigh, sorted;
+  DevBuf cell_of, slot, order_tmp, count, cell_start, order, inv, stype, ref, sorted_hs, hs2_dyn, nlist, nneigh, sorted, padgen;
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &count, &cell_start, &order, &inv, &stype, &ref, &sorted_hs, &hs2_dyn, &nlist,
-                      &nneigh, &sorted})
+                      &nneigh, &sorted, &padgen})
       b->release();
   }
 };
@@ -431,6 +434,7 @@ struct Replica {
                       // estimate, so that a swap between atom sets of the same density does not build its first list twice
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
+  DevBuf padgen;  // int32 per wave group of the list: the rebuild count (flags[F_NREBUILD]) at which the group's rows were padded
   DevBuf sorted_hs;  // per-atom half skins in cell-sorted order (contexts with skin weights)
   DevBuf hs2_dyn;    // (half skin)^2 of the CURRENT list per atom, original order: what the displacement test uses
   const void *skin_vel = nullptr;  // velocities of this replica while tmdhip_md_run is enqueuing (velocity-dependent skins)
@@ -454,9 +458,10 @@ struct Replica {
   DevBuf fbond;            // bonded force of a fused launch's positions (heavy topologies), original atom order
   unsigned fused_gen = 0;  // number of the last fused launch
   int64_t fused_launches = 0;  // fused launches of this replica (test knob TMDHIP_DEBUG_STEP_TIMEOUT counts them)
-  // Padded list rows (list_build.hip: pad_rows_kernel; fp32 contexts of <= 2^20 - 2 atoms whose box keeps the dummy
-  // records out of reach): the padding slots of every wave group hold a harmless entry, the lean fp32 pair kernel runs
-  // all of a wave's groups in its unchecked loop (kLmPadded).  Decided when the grid is planned (a forced rebuild follows).
+  // Padded list rows (pad_entry_for; fp32 contexts of <= 2^20 - 2 atoms whose box keeps the dummy records out of
+  // reach): the padding slots of every wave group hold a harmless entry, the lean fp32 pair kernel runs all of a wave's
+  // groups in its unchecked loop (kLmPadded).  The pair waves write the padding themselves on their first launch after
+  // a list build (`padgen`).  Decided when the grid is planned (a forced rebuild follows, which writes the dummies).
   bool pad_rows = false;
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf extent;  // int[6]: keys of the coordinate extent of sorted_xyzq (extent_note)
@@ -473,7 +478,7 @@ struct Replica {
   int64_t lookahead_builds = 0, lookahead_adopted = 0, lookahead_dropped = 0;
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
-                      &nlist, &nneigh, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond})
+                      &nlist, &nneigh, &padgen, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond})
       b->release();
     shadow.release();
     if (la_binned) (void)hipEventDestroy(la_binned);

@@ -162,10 +162,24 @@ __device__ __forceinline__ void place_atom(const PlaceArgs<R> &P, int a) {
   P.ref[3 * me + 2] = v.z;
 }
 
+// dummy record `which` behind the last atom of the cell-sorted copies (padded rows, engine.h: pad_entry_for)
+template <typename R>
+__device__ __forceinline__ void place_dummy(const PlaceArgs<R> &P, int which) {
+  if (!P.dummy_a) return;
+  typename Vec<R>::T4 v;
+  v.x = P.dummy_pos[which][0];
+  v.y = P.dummy_pos[which][1];
+  v.z = P.dummy_pos[which][2];
+  v.w = R(0);
+  P.dummy_a[which] = v;
+  if (P.dummy_b) P.dummy_b[which] = v;
+}
+
 template <typename R>
 __global__ void place_sorted_kernel(int n, PlaceArgs<R> P, const int *flag) {
   if (*flag == 0) return;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < 2) place_dummy<R>(P, a);
   if (a >= n) return;
   place_atom<R>(P, a);
 }
@@ -234,6 +248,7 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__rest
   __threadfence_block();
   __syncthreads();  // order_tmp and cell_start are complete for the whole block
   for (int a = t; a < n; a += 1024) place_atom<R>(P, a);
+  if (t < 2) place_dummy<R>(P, t);
 }
 
 // ---- K2: Verlet list build ---------------------------------------------------------------------
@@ -593,47 +608,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   if (lane == 0 && wmax > 0) atomicMax(status, wmax);
 }
 
-// ---- padded rows (Replica::pad_rows) -------------------------------------------------------------------------
-// A pair wave runs as long as the longest list of its APW atoms, rounded up to whole 16-byte list words: 19 % of the
-// slots a C3 launch evaluates are padding, and the lean fp32 kernel used to run every group that holds any of it in
-// its per-lane-checked, unpipelined loop (3 of ~14 groups per wave).  This kernel fills the padding slots of every
-// wave group with an entry that is harmless to evaluate unchecked: one of two dummy records behind the last atom
-// (slots n and n + 1 of the cell-sorted position arrays; charge 0, LJ class 0) — the one further away from the atom
-// under the minimum image.  The two sit half a box diagonal apart, so one of them is at least a quarter of the
-// diagonal away from any point (triangle inequality on the torus); the host enables the padding only where that is
-// beyond cutoff + 2 skins (plan_pad_rows), an open dimension puts them 10^6 A out.  All arithmetic on such an entry
-// stays finite and its cutoff factor is 0.  One wave per wave group; runs behind the build on its stream.
-__global__ __launch_bounds__(256) void pad_rows_kernel(int n, float4 *__restrict__ sorted, float4 *__restrict__ sorted_alt,
-                                                       const int *__restrict__ nneigh, ListGeom lg, PairConsts<float> c,
-                                                       unsigned *__restrict__ nlist, const int *flag) {
-  if (*flag == 0) return;
-  float d0[3], d1[3];
-  pad_dummy_positions(c, d0, d1);
-  if (blockIdx.x == 0 && threadIdx.x < 2) {
-    const float4 rec = threadIdx.x == 0 ? make_float4(d0[0], d0[1], d0[2], 0.f) : make_float4(d1[0], d1[1], d1[2], 0.f);
-    sorted[n + threadIdx.x] = rec;
-    if (sorted_alt) sorted_alt[n + threadIdx.x] = rec;
-  }
-  const int lane = threadIdx.x & 63;
-  const int g = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (g >= (n + lg.apw - 1) / lg.apw) return;  // (wave-uniform)
-  const int a = g * lg.apw + (lane >> lg.lpa_shift), sub = lane & (lg.lpa - 1);
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  int nn = 0;
-  if (a < n) {
-    p = sorted[a];
-    nn = min(nneigh[a], lg.maxn);
-  }
-  const int myiters = (nn - sub + lg.lpa - 1) >> lg.lpa_shift;
-  int itmax = myiters;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) itmax = max(itmax, __shfl_xor(itmax, o, 64));
-  const int padded = (itmax + 3) & ~3;
-  const unsigned entry = pad_entry_for(c, n, p.x, p.y, p.z);
-  unsigned *row = nlist + ((size_t)g * lg.maxn << (6 - lg.lpa_shift));
-  for (int kk = myiters; kk < padded; ++kk) row[(((kk >> 2) << 6) + lane) * 4 + (kk & 3)] = entry;
-}
-
 // TMDHIP_DEBUG_TIMELINE=1: every block of the list build records its entry / exit cycle counters (4 x u64 per block),
 // read back with tmdhip_debug_build_timeline (tools/build_timeline.py).  Null otherwise: the kernel stores nothing.
 static DevBuf g_dbg_timeline;
@@ -689,6 +663,16 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const ListTarget &T, cons
   P.vs_cap = (R)ctx->vskin_cap_len;
   P.hs2_dyn = T.hs2_dyn->as<R>();
   P.ext = rp.extent.as<int>();
+  P.dummy_a = P.dummy_b = nullptr;
+  if (rp.pad_rows) {
+    P.dummy_a = T.sorted->as<R4>() + n;
+    if (T.sorted == &rp.sorted && rp.sorted_alt.p) P.dummy_b = rp.sorted_alt.as<R4>() + n;
+    for (int k = 0; k < 3; ++k) {  // (pad_dummy_positions' values)
+      const bool open = !(c.box[k] > R(0));
+      P.dummy_pos[0][k] = open ? R(1.0e6) : R(0.25) * c.box[k];
+      P.dummy_pos[1][k] = open ? R(1.0e6) : R(0.75) * c.box[k];
+    }
+  }
   static const bool prep_small_on = !(std::getenv("TMDHIP_PREP_SMALL") && std::atoi(std::getenv("TMDHIP_PREP_SMALL")) == 0);
   if (prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells) {
     hipLaunchKernelGGL((prep_small_kernel<R>), dim3(1), dim3(1024), 0, st, n, pos, rp.grid, rp.ncell, T.cell_of->as<int>(),
@@ -729,14 +713,6 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const ListTarget &T, cons
     if (wskin) launch_build(build_list_kernel<R, true, true>, kMaxBuildBlocks);
     else launch_build(build_list_kernel<R, true, false>, kMaxBuildBlocks);
   }
-  if constexpr (std::is_same<R, float>::value) {
-    if (rp.pad_rows) {
-      const int groups = (n + rp.lg.apw - 1) / rp.lg.apw;
-      hipLaunchKernelGGL(pad_rows_kernel, dim3((groups + 3) / 4), dim3(256), 0, st_build, n, T.sorted->as<float4>(),
-                         T.sorted == &rp.sorted ? rp.sorted_alt.as<float4>() : nullptr, T.nneigh->as<int>(), rp.lg, c,
-                         T.nlist->as<unsigned>(), flag);
-    }
-  }
   TMD_HIP(hipGetLastError());
   return 0;
 }
@@ -774,6 +750,10 @@ static int ensure_shadow(tmdhip_ctx *ctx, Replica &rp) {
   TMD_TRY(s.nneigh.ensure(rp.nneigh.bytes));
   TMD_TRY(s.sorted.ensure(rp.sorted.bytes));
   TMD_TRY(s.cell_start.ensure(rp.cell_start.bytes));
+  if (s.padgen.bytes < rp.padgen.bytes) {
+    TMD_TRY(s.padgen.ensure(rp.padgen.bytes));
+    TMD_HIP(hipMemset(s.padgen.p, 0, s.padgen.bytes));  // (0: no rebuild count ever equals it)
+  }
   if (s.count.bytes < rp.count.bytes) {
     TMD_TRY(s.count.ensure(rp.count.bytes));
     TMD_HIP(hipMemset(s.count.p, 0, s.count.bytes));  // (scan_cells_kernel leaves the counts zero for the next build)
@@ -855,6 +835,7 @@ int adopt_lookahead_list(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
   std::swap(rp.hs2_dyn, s.hs2_dyn);
   std::swap(rp.nlist, s.nlist);
   std::swap(rp.nneigh, s.nneigh);
+  std::swap(rp.padgen, s.padgen);
   std::swap(rp.sorted, s.sorted);
   rp.la_state = 0;
   rp.lookahead_adopted++;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
     double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext,
-    int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep) {
+    int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep, int *__restrict__ padgen) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
   static_assert(!(FUSED && ENERGY), "the fused step is for interior steps");
@@ -145,10 +145,26 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   const int nkk = __builtin_amdgcn_readfirstlane(itmax);
   // iterations every lane has entries for.  The unchecked loop takes the table offset as `entry >> 24`, which needs
   // the slot's bits 20..22 to be zero: systems of more than 2^20 atoms run all their iterations in the checked
-  // loop, which masks the offset.  Padded rows (kLmPadded; pad_rows_kernel): the slots between a lane's last entry and
-  // the end of the wave's last group hold a harmless entry (a dummy record out of reach), so EVERY group is unchecked.
-  const int nfull = (lmode & kLmPadded) ? (nkk + UNROLL - 1) / UNROLL * UNROLL
-                                        : (n > (1 << 20) ? 0 : __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL);
+  // loop, which masks the offset.
+  // Padded rows (kLmPadded): the slots between a lane's last entry and the end of the wave's last group hold a harmless
+  // entry (a dummy record out of reach, pad_entry_for), so EVERY group is unchecked.  The padding is written by the wave
+  // itself on its first launch after a list build: its group's `padgen` word then differs from the rebuild count; that
+  // launch still runs its tail checked (the entries it has just stored are for the launches that follow).
+  bool padded = false;
+  if (lmode & kLmPadded) {
+    const int now = __builtin_amdgcn_readfirstlane(lflags[F_NREBUILD]);
+    const int have = __builtin_amdgcn_readfirstlane(padgen[wave]);
+    padded = have == now;
+    if (!padded) {
+      const unsigned pad = pad_entry_for(c, n, pi.x, pi.y, pi.z);
+      unsigned *row = const_cast<unsigned *>(wrow);
+      const int upto = (nkk + UNROLL - 1) / UNROLL * UNROLL;
+      for (int kk = myiters; kk < upto; ++kk) row[(((kk >> 2) << 6) + lane) * 4 + (kk & 3)] = pad;
+      if (lane == 0) padgen[wave] = now;
+    }
+  }
+  const int nfull = padded ? (nkk + UNROLL - 1) / UNROLL * UNROLL
+                           : (n > (1 << 20) ? 0 : __builtin_amdgcn_readfirstlane(itmin) / UNROLL * UNROLL);
   // bounds-checked raw buffer over sorted_xyzq: lanes past the end of their list read whatever the
   // (uninitialised) padding entry points at — out-of-range offsets return 0 instead of faulting — and
   // are discarded by `valid`
@@ -465,7 +481,7 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
                      dim3(kFastThreads), 0u, st, e0, e1, n, rp.sorted.as<float4>(), rp.stype.as<int>(), rp.order.as<int>(), \
                      ctx->d.ntypes, ctx->tab.as<float2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
                      overwrite, ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>(),                  \
-                     rp.flags.as<int>(), lmode, F ? fl->fst : nullptr, fstep)
+                     rp.flags.as<int>(), lmode, F ? fl->fst : nullptr, fstep, rp.padgen.as<int>())
 #define TMD_LAUNCH_FAST(L, F)               \
   if (lj && el) {                           \
     TMD_LAUNCH_FAST_T(L, true, true, F);    \
