@@ -120,18 +120,19 @@ struct tmdhip_comm {
   int64_t *cnt_host = nullptr;
   // scratch of the migration (dd_migrate.hip)
   struct MigScratch {
-    tmd::DevBuf dest, counts, rows_out, rows_in, keys_in, keys_out, perm_in, perm_out, sort_tmp, mask, blk_cnt, msg_tot, halo_out,
-        halo_in, typemap, minmax;
+    tmd::DevBuf dest, counts, rows_out, rows_in, keys_in, keys_out, perm_in, perm_out, sort_tmp, mask, blk_cnt, msg_tot, halo_in,
+        typemap, bad;
     int64_t *host = nullptr;  // pinned: counts read back from the device
     void release() {
       for (tmd::DevBuf *b : {&dest, &counts, &rows_out, &rows_in, &keys_in, &keys_out, &perm_in, &perm_out, &sort_tmp, &mask, &blk_cnt,
-                             &msg_tot, &halo_out, &halo_in, &typemap, &minmax})
+                             &msg_tot, &halo_in, &typemap, &bad})
         b->release();
       if (host) (void)hipHostFree(host);
       host = nullptr;
     }
   } mig;
   int mig_stage = 0;  // where a tmdhip_dd_migrate that returned 2 resumes (0: start)
+  bool mig_bad_pending = false;  // the last migration's "atom type outside the map" flag has not been looked at yet
   int64_t mig_nnew = 0, mig_nsend = 0, mig_nhalo = 0, mig_send_counts[64] = {0}, mig_recv_counts[64] = {0};
   // displacement-test state of the brick step in flight (dd_fused_front -> dd_fused_back)
   unsigned chk_seq = 0;

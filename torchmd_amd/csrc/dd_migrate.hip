@@ -508,12 +508,10 @@ int migrate(tmdhip_ctx *ctx, tmdhip_comm *c, tmdhip_dd_brick *b, hipStream_t st)
       return 2;
     }
     if (n <= 0 || n >= (1 << 23)) return fail("tmdhip_dd_migrate: atoms of a brick out of range");
-    const size_t ns1 = (size_t)std::max<int64_t>(nsend, 1);
     if (nsend > 0) {
       TMD_HIP(hipMemcpyAsync(b->send_index_dev, S.perm_in.p, sizeof(int) * (size_t)nsend, hipMemcpyDeviceToDevice, st));
       TMD_HIP(hipMemcpyAsync(b->send_shift_dev, S.rows_out.p, sizeof(R) * 3 * (size_t)nsend, hipMemcpyDeviceToDevice, st));
     }
-    (void)ns1;
     // the engine's atom set (what tmdhip_update_atoms does from host arrays)
     if (ctx->nexcl != 0 || ctx->bonded) return fail("tmdhip_dd_migrate: only for atomic systems (no exclusions, no bonded terms)");
     if (ctx->d.dtype != dtype) return fail("tmdhip_dd_migrate: dtype of the context differs");
@@ -529,9 +527,11 @@ int migrate(tmdhip_ctx *ctx, tmdhip_comm *c, tmdhip_dd_brick *b, hipStream_t st)
       TMD_HIP(hipMemcpyAsync(S.typemap.p, b->type_map_host, sizeof(int) * (size_t)b->ntypes_map, hipMemcpyHostToDevice, st));
       tmap = S.typemap.as<int>();
     }
-    TMD_TRY(S.msg_tot.ensure(sizeof(int) * kMsg));
-    int *bad = S.msg_tot.as<int>();
+    // an atom type outside the map is reported by the next tmdhip_dd_run (no read-back of its own here)
+    TMD_TRY(S.bad.ensure(sizeof(int)));
+    int *bad = S.bad.as<int>();
     TMD_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+    c->mig_bad_pending = true;
     hipLaunchKernelGGL((engine_atoms_kernel<R>), grid_for(n), dim3(256), 0, st, nown, nhalo, charge, b->type_dev, S.halo_in.as<R>(), pos, tmap,
                        b->ntypes_map, std::sqrt(kElecFactor), ctx->qs.as<R>(), ctx->types.as<int>(), bad);
     TMD_HIP(hipGetLastError());

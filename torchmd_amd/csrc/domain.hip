@@ -740,6 +740,13 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
       !d->send_counts_host || !d->recv_counts_host)
     return fail("tmdhip_dd_run: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (c->mig_bad_pending) {  // the last tmdhip_dd_migrate: did an atom carry a type outside the caller's map?
+    c->mig_bad_pending = false;
+    int bad = 0;
+    TMD_HIP(hipMemcpyAsync(&bad, c->mig.bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    TMD_HIP(hipStreamSynchronize(st));
+    if (bad) return fail("tmdhip_dd_migrate: an atom arrived with a type outside type_map_host (the brick's LJ classes are wrong)");
+  }
   const double box0[3] = {0, 0, 0};  // images are explicit halo atoms: open boundaries
   const size_t esz = d->dtype == TMDHIP_F32 ? 4 : 8;
   void *halo_rows = (char *)d->pos_dev + (size_t)d->nown * 3 * esz;
