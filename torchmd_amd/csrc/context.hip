@@ -63,9 +63,14 @@ int pick_lpa(int n, int capacity) {
     const int v = std::atoi(e);
     if (v >= 4 && v <= 64 && (v & (v - 1)) == 0) return v;
   }
-  // (1) enough waves to hide list/gather latency: >= 8192 waves (32 per CU)
+  // (1) enough waves to fill the chip: >= 2 560 (10 per CU).  Rounds 1-3 asked for 8 192 "to hide list / gather latency";
+  //     measured in round 4 on water boxes (us per MD step at 8 / 16 / 32 / 64 lanes): 12 288 atoms 21.9 / 21.0 / 22.7 /
+  //     23.1, 24 000 atoms 27.4 / 29.8 / 32.5 / 35.4, 41 472 atoms 36.3 / 36.5 / 50.5 / 50.4 — fewer, longer waves
+  //     amortise a wave's prologue and reduction better than more waves hide latency.  TMDHIP_LPA_WAVES overrides.
+  int64_t want_waves = 2560;
+  if (const char *e = std::getenv("TMDHIP_LPA_WAVES")) want_waves = std::max(1, std::atoi(e));
   int lpa = 1;
-  while (lpa < 64 && (int64_t)n * lpa < 8192ll * 64) lpa <<= 1;
+  while (lpa < 64 && (int64_t)n * lpa < want_waves * 64) lpa <<= 1;
   // (2) list length: measured optimum LPA = 8 for water (440 entries per atom; 4 and 16 are 10 % slower)
   //     and 4 for liquid argon at 10^6 atoms (90 entries per atom; 1: +25 %, 2: +6 %, 8: +13 %);
   //     capacity = ~1.25 x the expected entries + 32
