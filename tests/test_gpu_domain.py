@@ -364,3 +364,79 @@ def test_brick_loop_variants_are_bit_identical(world, monkeypatch):
         assert fs1 == 0 and mig1 == mig and rb1 == rebuilds, (mode, mig1, rb1)
         assert torch.equal(P, P1) and torch.equal(V, V1) and torch.equal(F, F1), mode
     assert out["1"][6] == skipped and out["0"][6] == 0
+
+
+@pytest.mark.timeout(600)
+def test_library_migration_equals_the_torch_migration_with_mixed_types():
+    """`tmdhip_dd_migrate` against the torch migration of domain.py on a mixture: three atom types of which two share
+    their LJ parameters (the engine merges them into one class: the type -> class map travels to the library), different
+    masses, charges and a reaction field, so that every field of a migrating atom's state row matters.  World 4
+    (2 x 1 x 2), in-process ranks; the library's loop with the library's migration against the same loop with
+    TMDHIP_DD_MIGRATE=python: same migration decisions, same owners, positions / velocities / forces to 1e-9 (the two plan
+    the engine's cell grid over different bounds: another summation order), and both equal the single-domain run."""
+    import os
+
+    from torchmd_amd.builders import Topology
+    from torchmd_amd.domain import DomainSet, LocalTransport
+    from torchmd_amd.forcefields.ff_yaml import YamlForceField
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = torch.device("cuda:0"), torch.float64
+    rng = np.random.default_rng(12)
+    nside, a = 20, 3.6
+    g = np.arange(nside)
+    sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
+    pos = sites * a + a / 2 + rng.uniform(-0.3, 0.3, size=sites.shape)
+    n = len(pos)
+    box = np.array([nside * a] * 3)
+    kinds = np.array(["A1", "A2", "B"], dtype=object)[rng.integers(0, 3, size=n)]
+    ff = {
+        "atomtypes": ["A1", "A2", "B"],
+        "lj": {"A1": {"sigma": 3.345, "epsilon": 0.238}, "A2": {"sigma": 3.345, "epsilon": 0.238}, "B": {"sigma": 3.0, "epsilon": 0.15}},
+        "electrostatics": {"A1": {"charge": 0.1}, "A2": {"charge": -0.1}, "B": {"charge": 0.0}},
+        "masses": {"A1": 39.95, "A2": 20.0, "B": 30.0},
+    }
+    charge = np.array([ff["electrostatics"][k]["charge"] for k in kinds], dtype=np.float32)
+    masses = np.array([ff["masses"][k] for k in kinds], dtype=np.float32)
+    mol = Topology(atomtype=kinds, charge=charge, masses=masses)
+    terms = ["lj", "electrostatics"]
+    par = Parameters(YamlForceField(mol, ff), mol, terms, precision=dt)
+    torch.manual_seed(5)
+    vel = maxwell_boltzmann(par.masses, 3000.0, 1)[0].numpy()
+    A, B = par.get_AB()
+    out = {}
+    try:
+        for how in ("native", "python"):
+            os.environ["TMDHIP_DD_MIGRATE"] = how
+            tr = LocalTransport(4, native_threads=True)
+            ds = DomainSet(box, 4, dev, dt, terms, 9.0, A=A, B=B, skin=1.0, grid=(2, 1, 2), transport=tr, rfa=True)
+            ds.scatter(pos, vel, par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
+            eng = next(iter(ds.domains.values())).forces_engine._engine(next(iter(ds.domains.values())).local_pos)
+            assert eng.type_map is not None and eng.ntypes == 2  # A1 and A2 are one LJ class
+            ds.compute_forces()
+            ds.step(30, timestep_fs=2.0)
+            owners = torch.zeros(n, dtype=torch.long, device=dev)
+            for r, d in ds.domains.items():
+                owners[d.ids] = r
+            out[how] = ds.gather(n) + (ds.migrations, owners.cpu())
+            for d in ds.domains.values():
+                d.forces_engine.close()
+            tr.close()
+    finally:
+        os.environ.pop("TMDHIP_DD_MIGRATE", None)
+    P, V, F, mig, own = out["native"]
+    P0, V0, F0, mig0, own0 = out["python"]
+    assert mig >= 3 and mig == mig0 and torch.equal(own, own0)
+    assert (P - P0).abs().max().item() < 1e-9 and (V - V0).abs().max().item() < 1e-9 and (F - F0).abs().max().item() < 1e-8
+    s = System(n, 1, dt, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    s.set_velocities(torch.tensor(vel)[None])
+    f = Forces(par, terms=terms, cutoff=9.0, rfa=True)
+    f.compute(s.pos, s.box, s.forces)
+    Integrator(s, f, 2.0, dev).step(30)
+    assert (P - s.pos[0]).abs().max().item() < 1e-7 and (V - s.vel[0]).abs().max().item() < 1e-7
+    assert (F - s.forces[0]).abs().max().item() < 1e-6

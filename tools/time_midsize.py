@@ -12,6 +12,7 @@ from torchmd_amd.systems import System
 
 dev = torch.device("cuda:0")
 terms = ["lj", "electrostatics", "bonds", "angles"]
+skin = float(os.environ["MIDSIZE_SKIN"]) if os.environ.get("MIDSIZE_SKIN") else None  # (A/B: Verlet skin in A)
 for nside in [int(a) for a in sys.argv[1:]] or [12, 16, 20, 24]:
     mol, pos, box = tip3p_box(nside, seed=0)
     par = Parameters(water_forcefield(mol), mol, terms, precision=torch.float32)
@@ -19,7 +20,7 @@ for nside in [int(a) for a in sys.argv[1:]] or [12, 16, 20, 24]:
     s.set_positions(pos[:, :, None]); s.set_box(box)
     torch.manual_seed(1)
     s.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
-    f = Forces(par, terms=terms, cutoff=9.0, rfa=True, skin_weights="mass")
+    f = Forces(par, terms=terms, cutoff=9.0, rfa=True, skin_weights="mass", **({"skin": skin} if skin else {}))
     f.compute(s.pos, s.box, s.forces)
     Integrator(s, f, 1.0, dev, gamma=10.0, T=300.0).step(600)
     integ = Integrator(s, f, 1.0, dev, gamma=0.1, T=300.0)
