@@ -713,6 +713,63 @@ def test_padded_list_rows_are_bit_identical(case, monkeypatch):
     assert a[5] == b[5] and a[5] >= 2 and a[6] == b[6] and a[7] == b[7]
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_two_launch_binning_and_its_cell_overflow_fallback(prec, monkeypatch):
+    """The cell binning is two launches (member arrays of 64 atoms per cell + scan and placement in one kernel) instead of
+    four; same cell order, hence identical lists: forces and energies equal the four-launch binning's (TMDHIP_BIN2=0) bit
+    for bit.  A cell that receives more than 64 atoms — here 150 weakly charged atoms inside one 2-A sphere of a larger
+    box, electrostatics only so that nothing overflows numerically — raises F_CELLCAP: the replica falls back to the four
+    launches and the result still equals the oracle's (without the fallback 86 atoms would be missing from the list)."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev, dt = _dev(), PREC[prec]
+    mol, pos, box = tip3p_box(12, seed=31)
+    terms = ["lj", "electrostatics"]
+    par = Parameters(water_forcefield(mol), mol, terms + ["bonds", "angles"], precision=dt)
+    pd, bd = pos_tensor(pos, 1, dt, dev), box_tensor(box, 1, dt, dev)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TMDHIP_BIN2", mode)
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        F = torch.zeros_like(pd)
+        e = f.compute(pd, bd, F, returnDetails=True)
+        out[mode] = (e[0], F.clone().cpu(), f.count_pairs(pd, bd))
+        f.close()
+    assert torch.equal(out["1"][1], out["0"][1]) and out["1"][2] == out["0"][2]
+    for t in terms:  # (fp64 energies are folded with atomics: the order of the terms shows in the last bits)
+        assert abs(out["1"][0][t] - out["0"][0][t]) <= (0.0 if prec == "f32" else 1e-12 * abs(out["0"][0][t])), t
+    # overflow: a dense cluster
+    monkeypatch.setenv("TMDHIP_BIN2", "1")
+    rng = np.random.default_rng(7)
+    n = 4000
+    L = 60.0
+    p = rng.uniform(0, L, size=(n, 3))
+    v = rng.normal(size=(150, 3))
+    p[:150] = 30.0 + 2.0 * rng.uniform(0, 1, size=(150, 1)) ** (1 / 3) * v / np.linalg.norm(v, axis=1, keepdims=True)
+    from torchmd_amd.builders import Topology
+    from torchmd_amd.forcefields.ff_yaml import YamlForceField
+
+    ff = {"atomtypes": ["X"], "lj": {"X": {"sigma": 3.0, "epsilon": 0.1}}, "electrostatics": {"X": {"charge": 0.0}}, "masses": {"X": 10.0}}
+    q = rng.choice([-0.01, 0.01], size=n).astype(np.float32)
+    m2 = Topology(atomtype=np.full(n, "X", dtype=object), charge=q, masses=np.full(n, 10.0, dtype=np.float32))
+    par2 = Parameters(YamlForceField(m2, ff), m2, ["electrostatics"], precision=dt)
+    b3 = np.array([L, L, L])
+    pt = pos_tensor(p, 1, dt)
+    pairs = orc.candidate_pairs(p, b3, 9.6, orc.exclusion_pairs(par2))
+    po, Fo, npairs = orc.compute(par2, pt, box_tensor(b3, 1, dt), ["electrostatics"], pairs=pairs, cutoff=9.0, rfa=True)
+    f = Forces(par2, terms=["electrostatics"], cutoff=9.0, rfa=True, algorithm="celllist")
+    pd2, bd2 = pt.to(dev), box_tensor(b3, 1, dt, dev)
+    F = torch.zeros_like(pd2)
+    e = f.compute(pd2, bd2, F, returnDetails=True)
+    assert f.count_pairs(pd2, bd2) == npairs
+    tol = 1e-8 if prec == "f64" else 2e-3
+    assert (F.cpu() - Fo).abs().max().item() <= tol * max(1.0, Fo.abs().max().item())
+    assert abs(e[0]["electrostatics"] - po[0]["electrostatics"]) <= ERTOL[prec] * EFAC * max(1.0, abs(po[0]["electrostatics"]))
+
+
 def test_box_change_and_capacity_growth():
     """(a) changing the box between calls re-plans the cell grid; (b) a denser configuration makes a
     device-side rebuild overflow the list capacity: tmdhip_check reports it, the capacity grows and the

@@ -255,6 +255,10 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     TMD_TRY(rp.count.ensure(sizeof(int) * (size_t)rp.ncell));
     TMD_TRY(rp.cell_start.ensure(sizeof(int) * ((size_t)rp.ncell + 1)));
     TMD_HIP(hipMemsetAsync(rp.count.p, 0, sizeof(int) * (size_t)rp.ncell, st));
+    if (const char *e = std::getenv("TMDHIP_BIN2"))  // (A/B, tests: 0 = the four-launch binning; read at every re-plan)
+      if (std::atoi(e) == 0) rp.cell_cap_fallback = true;
+    if (rp.ncell <= kScanPlaceMaxCells && !rp.cell_cap_fallback)  // two-launch binning: the cells' member arrays
+      TMD_TRY(rp.members.ensure(sizeof(int) * (size_t)rp.ncell * kCellCap));
     if (!rp.have_list) {
       const double dens = n / volume;
       int est = (int)(dens * 4.18879 * ctx->rlist * ctx->rlist * ctx->rlist * 1.3) + 32;
@@ -281,6 +285,11 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     TMD_HIP(hipMemcpyAsync(h, rp.flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
     TMD_HIP(hipStreamSynchronize(st));
     rp.host_rebuilds++;
+    if (h[F_CELLCAP]) {  // a cell overflowed the member array of the two-launch binning: build again with the four launches
+      TMD_HIP(hipMemsetAsync(rp.flags.as<int>() + F_CELLCAP, 0, sizeof(int), st));
+      rp.cell_cap_fallback = true;
+      continue;
+    }
     int want = (int)(h[F_MAXN] * 1.2) + 8;
     if (const char *e = std::getenv("TMDHIP_DEBUG_LIST_SLACK")) {
       // test knob: size the list for the observed maximum + N entries only, so that a later device-side
@@ -379,6 +388,18 @@ int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
     last_error() = "a step block of the fused pair + step launch timed out waiting for a force record (workgroups not "
                    "dispatched in block order?); the batch is repeated with the separate integrator kernel";
     if (h[F_MAXN] <= rp.lg.maxn) return 1;
+  }
+  if (h[F_CELLCAP]) {
+    // a cell received more atoms than the member array of the two-launch binning holds: the list built from it is
+    // incomplete.  This replica bins with the four launches from now on; the work is repeated.
+    (void)hipMemsetAsync(rp.flags.as<int>() + F_CELLCAP, 0, sizeof(int), st);
+    rp.cell_cap_fallback = true;
+    ctx->no_chain_skip_once = true;
+    rp.seq_valid = false;
+    rp.box[0] = -1;  // re-plan + rebuild
+    last_error() = "a cell holds more atoms than the two-launch binning's member array (the replica switches to the "
+                   "four-launch binning; results since the last check are invalid)";
+    return 1;
   }
   if (h[F_VIOLATION]) {
     // an atom crossed its displacement limit in a step whose rebuild chain had been left out (ListCheck)

@@ -91,7 +91,12 @@ __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
 //   F_STEP_TIMEOUT  a step block of a fused pair launch gave up waiting for a force record (pair_fast_f32.hip): its
 //                 atoms were NOT integrated; the caller rewinds and repeats the batch with the separate integrator kernel
 //   F_ALWAYS      constant 1: the "flag" of a chain that is to run unconditionally (look-ahead builds)
-enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_STEP_TIMEOUT = 5, F_ALWAYS = 6, F_COUNT = 7 };
+//   F_CELLCAP     a cell received more atoms than the member array of the two-launch binning holds (kCellCap): the list of
+//                 this build is incomplete; the caller switches the replica to the four-launch binning and repeats
+enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_STEP_TIMEOUT = 5, F_ALWAYS = 6, F_CELLCAP = 7,
+       F_COUNT = 8 };
+constexpr int kCellCap = 64;             // members per cell of the two-launch binning
+constexpr int kScanPlaceMaxCells = 12288;  // cells whose prefix a block of scan_place_kernel can hold in LDS (48 KB)
 
 // Displacement test that drives the rebuilds: the list (cutoff + skin) is valid while no atom has moved
 // further than skin/2 from `ref`; the test runs on the device (in the fused integrator kernel, or in
@@ -414,10 +419,10 @@ struct DevBuf {
 // skins of the displacement test, the list itself (the ACTIVE set of a replica lives in the Replica's members of the
 // same names; swapping two DevBufs swaps pointers)
 struct ListBufs {
-  DevBuf cell_of, slot, order_tmp, count, cell_start, order, inv, stype, ref, sorted_hs, hs2_dyn, nlist, nneigh, sorted, padgen;
+  DevBuf cell_of, slot, order_tmp, count, cell_start, order, inv, stype, ref, sorted_hs, hs2_dyn, nlist, nneigh, sorted, padgen, members;
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &count, &cell_start, &order, &inv, &stype, &ref, &sorted_hs, &hs2_dyn, &nlist,
-                      &nneigh, &sorted, &padgen})
+                      &nneigh, &sorted, &padgen, &members})
       b->release();
   }
 };
@@ -435,6 +440,8 @@ struct Replica {
   int64_t host_rebuilds = 0;
   DevBuf cell_of, slot, order_tmp, order, inv, count, cell_start, sorted, stype, ref, nlist, nneigh;
   DevBuf padgen;  // int32 per wave group of the list: the rebuild count (flags[F_NREBUILD]) at which the group's rows were padded
+  DevBuf members;  // two-launch binning: int32[ncell x kCellCap], the atoms of every cell in arrival order
+  bool cell_cap_fallback = false;  // a cell overflowed `members` once: this replica bins with the four launches
   DevBuf sorted_hs;  // per-atom half skins in cell-sorted order (contexts with skin weights)
   DevBuf hs2_dyn;    // (half skin)^2 of the CURRENT list per atom, original order: what the displacement test uses
   const void *skin_vel = nullptr;  // velocities of this replica while tmdhip_md_run is enqueuing (velocity-dependent skins)
@@ -478,7 +485,7 @@ struct Replica {
   int64_t lookahead_builds = 0, lookahead_adopted = 0, lookahead_dropped = 0;
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
-                      &nlist, &nneigh, &padgen, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond})
+                      &nlist, &nneigh, &padgen, &members, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond})
       b->release();
     shadow.release();
     if (la_binned) (void)hipEventDestroy(la_binned);

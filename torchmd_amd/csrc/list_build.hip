@@ -126,13 +126,21 @@ __global__ void fill_cells_kernel(int n, const int *__restrict__ cell_of, const 
 // atom at position `a` of the unsorted cell order -> its final slot (rank by original index inside the cell) and every
 // per-slot copy the pair kernels read
 template <typename R>
+__device__ __forceinline__ void place_atom_at(const PlaceArgs<R> &P, int me, int dst);
+
+template <typename R>
 __device__ __forceinline__ void place_atom(const PlaceArgs<R> &P, int a) {
   const int me = P.order_tmp[a];
   const int cidx = P.cell_of[me];
   const int s = P.cell_start[cidx], e = P.cell_start[cidx + 1];
   int rank = 0;
   for (int k = s; k < e; ++k) rank += P.order_tmp[k] < me;
-  const int dst = s + rank;
+  place_atom_at<R>(P, me, s + rank);
+}
+
+// atom `me` at its final slot `dst`: every per-slot copy the pair kernels read
+template <typename R>
+__device__ __forceinline__ void place_atom_at(const PlaceArgs<R> &P, int me, int dst) {
   P.order[dst] = me;
   P.inv[me] = dst;
   typename Vec<R>::T4 v;
@@ -173,6 +181,78 @@ __device__ __forceinline__ void place_dummy(const PlaceArgs<R> &P, int which) {
   v.w = R(0);
   P.dummy_a[which] = v;
   if (P.dummy_b) P.dummy_b[which] = v;
+}
+
+// ---- two-launch binning (round 4) ---------------------------------------------------------------------------------
+// bin_count / scan_cells / fill_cells / place_sorted are four launches — on the steps where the chain is enqueued but
+// nothing is rebuilt (~2 of 11) four early-exit launches, and mid-size boxes are host-bound on exactly those steps.
+// Two launches do the same work for grids of <= kScanPlaceMaxCells cells:
+//   bin_members_kernel   cell of every atom + the cell's member array in arrival order (fixed capacity kCellCap; an
+//                        overflow raises F_CELLCAP and the replica falls back to the four launches)
+//   scan_place_kernel    every block scans ALL cell counts into LDS (27 KB of reads per block at C3: nothing), block 0
+//                        stores cell_start, then thread = atom: final slot = start of its cell + its rank by original
+//                        index among the cell's members (deterministic order), and every per-slot copy (place_atom_at)
+// The counts are cleared for the next build by the build kernel (one cell per block), not here: other blocks of
+// scan_place_kernel may still be reading them.
+template <typename R>
+__global__ void bin_members_kernel(int n, const R *__restrict__ pos, Grid g, int *__restrict__ cell_of, int *__restrict__ count,
+                                   int *__restrict__ members, int *flags, const int *flag) {
+  if (*flag == 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cx = cell_coord(pos[3 * i + 0], g, 0);
+  const int cy = cell_coord(pos[3 * i + 1], g, 1);
+  const int cz = cell_coord(pos[3 * i + 2], g, 2);
+  const int cidx = (cx * g.nc[1] + cy) * g.nc[2] + cz;
+  cell_of[i] = cidx;
+  const int k = atomicAdd(&count[cidx], 1);
+  if (k < kCellCap) members[(size_t)cidx * kCellCap + k] = i;
+  else flags[F_CELLCAP] = 1;
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void scan_place_kernel(int n, int ncell, const int *__restrict__ count,
+                                                         const int *__restrict__ members, int *__restrict__ cell_start_out,
+                                                         PlaceArgs<R> P, const int *flag) {
+  if (*flag == 0) return;
+  extern __shared__ int s_start[];  // [ncell + 1]
+  __shared__ int wsum[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int per = (ncell + 255) / 256, c0 = t * per, c1 = min(c0 + per, ncell);
+  int mine = 0;
+  for (int k = c0; k < c1; ++k) mine += min(count[k], kCellCap);
+  int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int run = inc - mine;
+  for (int k = 0; k < w; ++k) run += wsum[k];
+  for (int k = c0; k < c1; ++k) {
+    s_start[k] = run;
+    run += min(count[k], kCellCap);
+  }
+  if (t == 255) s_start[ncell] = run;
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int k = t; k <= ncell; k += 256) cell_start_out[k] = s_start[k];
+  if (blockIdx.x == 0 && t < 2) place_dummy<R>(P, t);
+  const int me = blockIdx.x * blockDim.x + t;
+  if (me >= n) return;
+  const int cidx = P.cell_of[me];
+  const int cnt = min(count[cidx], kCellCap);
+  const int *m = members + (size_t)cidx * kCellCap;
+  int rank = 0, seen = 0;
+  for (int k = 0; k < cnt; ++k) {
+    const int o = m[k];
+    rank += o < me;
+    seen |= o == me;
+  }
+  if (!seen) return;  // (this atom did not fit its cell's member array: F_CELLCAP is set, the build is thrown away)
+  place_atom_at<R>(P, me, s_start[cidx] + rank);
 }
 
 template <typename R>
@@ -266,7 +346,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
-    int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split) {
+    int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split, int *__restrict__ count_zero) {
   if (*flag == 0) return;
   const unsigned long long dbg_t0 = dbg ? __builtin_readcyclecounter() : 0ull;  // TMDHIP_DEBUG_TIMELINE (tools/build_timeline.py)
   using R4 = typename Vec<R>::T4;
@@ -290,6 +370,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   do {
   int cs = cell_start[cell], ce = cell_start[cell + 1];
   if (cell == 0 && part == 0 && lane == 0) status[1] += 1;  // flags[F_NREBUILD]
+  if (count_zero && part == 0 && lane == 0) count_zero[cell] = 0;  // (two-launch binning: the cell counts of the next build)
   if (!LOOP && split > 1) {  // this block's atoms of the cell (multiples of 4: whole batches)
     const int per = ((ce - cs + split - 1) / split + 3) & ~3;
     cs = min(cs + part * per, ce);
@@ -622,16 +703,16 @@ unsigned long long *debug_timeline_buffer(int blocks) {
 
 // where a rebuild chain reads and writes: the replica's active buffers or its shadow set (look-ahead build)
 struct ListTarget {
-  DevBuf *cell_of, *slot, *order_tmp, *count, *cell_start, *order, *inv, *stype, *ref, *sorted_hs, *hs2_dyn, *nlist, *nneigh, *sorted;
+  DevBuf *cell_of, *slot, *order_tmp, *count, *cell_start, *order, *inv, *stype, *ref, *sorted_hs, *hs2_dyn, *nlist, *nneigh, *sorted, *members;
 };
 static ListTarget active_target(Replica &rp) {
   return {&rp.cell_of, &rp.slot, &rp.order_tmp, &rp.count, &rp.cell_start, &rp.order, &rp.inv, &rp.stype, &rp.ref,
-          &rp.sorted_hs, &rp.hs2_dyn, &rp.nlist, &rp.nneigh, &rp.sorted};
+          &rp.sorted_hs, &rp.hs2_dyn, &rp.nlist, &rp.nneigh, &rp.sorted, &rp.members};
 }
 static ListTarget shadow_target(Replica &rp) {
   ListBufs &s = rp.shadow;
   return {&s.cell_of, &s.slot, &s.order_tmp, &s.count, &s.cell_start, &s.order, &s.inv, &s.stype, &s.ref, &s.sorted_hs,
-          &s.hs2_dyn, &s.nlist, &s.nneigh, &s.sorted};
+          &s.hs2_dyn, &s.nlist, &s.nneigh, &s.sorted, &s.members};
 }
 
 // The rebuild chain into `T`: cell binning on `st` (one launch for small systems, four otherwise) and the list build on
@@ -674,9 +755,16 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const ListTarget &T, cons
     }
   }
   static const bool prep_small_on = !(std::getenv("TMDHIP_PREP_SMALL") && std::atoi(std::getenv("TMDHIP_PREP_SMALL")) == 0);
+  const bool bin2 = !rp.cell_cap_fallback && rp.ncell <= kScanPlaceMaxCells &&
+                    T.members->bytes >= sizeof(int) * (size_t)rp.ncell * kCellCap;
   if (prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells) {
     hipLaunchKernelGGL((prep_small_kernel<R>), dim3(1), dim3(1024), 0, st, n, pos, rp.grid, rp.ncell, T.cell_of->as<int>(),
                        T.slot->as<int>(), T.cell_start->as<int>(), T.order_tmp->as<int>(), P, flag);
+  } else if (bin2) {
+    hipLaunchKernelGGL((bin_members_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, T.cell_of->as<int>(), T.count->as<int>(),
+                       T.members->as<int>(), flags, flag);
+    hipLaunchKernelGGL((scan_place_kernel<R>), dim3(nb), dim3(256), sizeof(int) * ((size_t)rp.ncell + 1), st, n, rp.ncell,
+                       T.count->as<int>(), T.members->as<int>(), T.cell_start->as<int>(), P, flag);
   } else {
     hipLaunchKernelGGL((bin_count_kernel<R>), dim3(nb), dim3(256), 0, st, n, pos, rp.grid, T.cell_of->as<int>(),
                        T.slot->as<int>(), T.count->as<int>(), flag);
@@ -704,7 +792,8 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const ListTarget &T, cons
                        T.stype->as<int>(), T.order->as<int>(), T.cell_start->as<int>(), rp.grid, c, rl * rl,
                        (R)ctx->d.cutoff, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, T.nlist->as<unsigned>(),
                        T.nneigh->as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes,
-                       debug_timeline_buffer(blocks), split);
+                       debug_timeline_buffer(blocks), split,
+                       (bin2 && !(prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells)) ? T.count->as<int>() : nullptr);
   };
   if (rp.ncell <= kMaxBuildBlocks) {
     if (wskin) launch_build(build_list_kernel<R, false, true>, rp.ncell * split);
@@ -750,6 +839,7 @@ static int ensure_shadow(tmdhip_ctx *ctx, Replica &rp) {
   TMD_TRY(s.nneigh.ensure(rp.nneigh.bytes));
   TMD_TRY(s.sorted.ensure(rp.sorted.bytes));
   TMD_TRY(s.cell_start.ensure(rp.cell_start.bytes));
+  if (rp.members.bytes) TMD_TRY(s.members.ensure(rp.members.bytes));
   if (s.padgen.bytes < rp.padgen.bytes) {
     TMD_TRY(s.padgen.ensure(rp.padgen.bytes));
     TMD_HIP(hipMemset(s.padgen.p, 0, s.padgen.bytes));  // (0: no rebuild count ever equals it)
