@@ -18,9 +18,12 @@ integ.step(5)
 if every:
     forces.enable_timing(system.pos, True, every=every)
 rows = []
+pause = float(os.environ.get("SHORT_CALL_PAUSE_MS", "0")) * 1e-3  # idle time in front of every call (clock ramp?)
 for c in range(calls):
     r0 = forces.stats(system.pos)["n_rebuilds"]
     torch.cuda.synchronize()
+    if pause:
+        time.sleep(pause)
     t0 = time.perf_counter()
     integ.step(k)
     torch.cuda.synchronize()
