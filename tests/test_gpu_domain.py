@@ -184,7 +184,7 @@ def test_native_loop_at_world_2_4_8_on_one_gpu(world):
     from torchmd_amd.systems import System
 
     dev, dt = torch.device("cuda:0"), torch.float64
-    mol, pos, box, par = _system(22, dt)
+    mol, pos, box, par = _system(23, dt)  # (odd: brick faces pass through lattice planes, atoms change bricks)
     n = mol.numAtoms
     torch.manual_seed(3)
     vel = maxwell_boltzmann(par.masses, 4000.0, 1)[0].numpy()
@@ -335,7 +335,7 @@ def test_brick_loop_variants_are_bit_identical(world, monkeypatch):
     from torchmd_amd.integrator import maxwell_boltzmann
 
     dev, dt = torch.device("cuda:0"), torch.float32
-    mol, pos, box, par = _system(22, dt)
+    mol, pos, box, par = _system(23, dt)  # (odd: brick faces pass through lattice planes, atoms change bricks at once)
     n = mol.numAtoms
     torch.manual_seed(3)
     vel = maxwell_boltzmann(par.masses, 600.0, 1)[0].numpy()
@@ -386,7 +386,7 @@ def test_library_migration_equals_the_torch_migration_with_mixed_types():
 
     dev, dt = torch.device("cuda:0"), torch.float64
     rng = np.random.default_rng(12)
-    nside, a = 20, 3.6
+    nside, a = 21, 3.6  # odd: the faces of the 2 x 1 x 2 bricks pass THROUGH lattice planes, atoms cross them at once
     g = np.arange(nside)
     sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
     pos = sites * a + a / 2 + rng.uniform(-0.3, 0.3, size=sites.shape)
@@ -408,25 +408,42 @@ def test_library_migration_equals_the_torch_migration_with_mixed_types():
     vel = maxwell_boltzmann(par.masses, 3000.0, 1)[0].numpy()
     A, B = par.get_AB()
     out = {}
+    growths = 0
     try:
-        for how in ("native", "python"):
-            os.environ["TMDHIP_DD_MIGRATE"] = how
+        for how in ("native", "python", "native-tight"):
+            os.environ["TMDHIP_DD_MIGRATE"] = how.split("-")[0]
+            # third pass: capacity buffers without headroom — every brick that gains an atom, a halo row or a send row makes
+            # tmdhip_dd_migrate return 2 (need_*); the caller grows its arrays and the call resumes where it stopped
+            os.environ.pop("TMDHIP_DD_TEST_TIGHT_CAPS", None)
+            if how == "native-tight":
+                os.environ["TMDHIP_DD_TEST_TIGHT_CAPS"] = "1"
             tr = LocalTransport(4, native_threads=True)
             ds = DomainSet(box, 4, dev, dt, terms, 9.0, A=A, B=B, skin=1.0, grid=(2, 1, 2), transport=tr, rfa=True)
             ds.scatter(pos, vel, par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
             eng = next(iter(ds.domains.values())).forces_engine._engine(next(iter(ds.domains.values())).local_pos)
             assert eng.type_map is not None and eng.ntypes == 2  # A1 and A2 are one LJ class
+            owners0 = torch.zeros(n, dtype=torch.long, device=dev)
+            for r, d in ds.domains.items():
+                owners0[d.ids] = r
             ds.compute_forces()
             ds.step(30, timestep_fs=2.0)
             owners = torch.zeros(n, dtype=torch.long, device=dev)
             for r, d in ds.domains.items():
                 owners[d.ids] = r
             out[how] = ds.gather(n) + (ds.migrations, owners.cpu())
+            assert int((owners != owners0).sum()) >= 20  # atoms really changed bricks
+            if how == "native-tight":
+                growths = sum(getattr(d, "capacity_growths", 0) for d in ds.domains.values())
             for d in ds.domains.values():
                 d.forces_engine.close()
             tr.close()
     finally:
         os.environ.pop("TMDHIP_DD_MIGRATE", None)
+        os.environ.pop("TMDHIP_DD_TEST_TIGHT_CAPS", None)
+    assert growths >= 3, growths
+    for a, b in zip(out["native"][:3], out["native-tight"][:3]):  # resumed calls give the same state, bit for bit
+        assert torch.equal(a, b)
+    assert out["native"][3] == out["native-tight"][3] and torch.equal(out["native"][4], out["native-tight"][4])
     P, V, F, mig, own = out["native"]
     P0, V0, F0, mig0, own0 = out["python"]
     assert mig >= 3 and mig == mig0 and torch.equal(own, own0)

@@ -435,7 +435,12 @@ class Domain:
         n = self.nown
         nrows = self.local_pos.shape[1] if getattr(self, "local_pos", None) is not None else n
         nsend = len(self.send_index32)
-        b = self._alloc_buffers(int(1.2 * n) + 4096, int(1.2 * nrows) + 8192, int(1.25 * nsend) + 4096)
+        import os
+
+        if os.environ.get("TMDHIP_DD_TEST_TIGHT_CAPS"):  # test knob: no headroom, so that the "capacity too small" paths run
+            b = self._alloc_buffers(n + 1, nrows + 1, nsend + 1)
+        else:
+            b = self._alloc_buffers(int(1.2 * n) + 4096, int(1.2 * nrows) + 8192, int(1.25 * nsend) + 4096)
         b["ids"][:n], b["pos"][:n], b["unwrap"][:n], b["vel"][:n] = self.ids, self.pos, self.unwrap, self.vel
         b["charge"][:n], b["type"][:n], b["mass"][:n], b["ref"][:n] = self.charges, self.types.to(torch.int32), self.masses, self.ref
         self._bufs = b
@@ -444,8 +449,12 @@ class Domain:
         """A capacity reported too small by tmdhip_dd_migrate: new buffers, the owned rows copied over."""
         o = self._bufs
         n = min(self.nown, o["cap_own"])
-        b = self._alloc_buffers(max(o["cap_own"], int(1.25 * need_own) + 1024), max(o["cap_rows"], int(1.25 * need_rows) + 1024),
-                                max(o["cap_send"], int(1.25 * need_send) + 1024))
+        import os
+
+        tight = bool(os.environ.get("TMDHIP_DD_TEST_TIGHT_CAPS"))
+        grow = (lambda need: need + 1) if tight else (lambda need: int(1.25 * need) + 1024)  # noqa: E731
+        b = self._alloc_buffers(max(o["cap_own"], grow(need_own)), max(o["cap_rows"], grow(need_rows)), max(o["cap_send"], grow(need_send)))
+        self.capacity_growths = getattr(self, "capacity_growths", 0) + 1
         for k in self._OWN_ARRAYS + ("pos",):
             b[k][:n] = o[k][:n]
         self._bufs = b
