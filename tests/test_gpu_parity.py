@@ -770,6 +770,43 @@ def test_two_launch_binning_and_its_cell_overflow_fallback(prec, monkeypatch):
     assert abs(e[0]["electrostatics"] - po[0]["electrostatics"]) <= ERTOL[prec] * EFAC * max(1.0, abs(po[0]["electrostatics"]))
 
 
+def test_streamed_list_reads_are_bit_identical(monkeypatch):
+    """Lists that cannot live in the Infinity Cache are read with the non-temporal hint (kLmStream: a run-time choice
+    between two load instructions in the lean fp32 kernel; by size, or TMDHIP_LIST_STREAM=0 / 1).  A cache hint must not
+    change a single bit: forces, energies and a short fused trajectory with the hint forced on equal those with it off."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(14, seed=2)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    monkeypatch.setenv("TMDHIP_LPA", "8")
+    torch.manual_seed(1)
+    vel0 = maxwell_boltzmann(par.masses, 300.0, 1)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TMDHIP_LIST_STREAM", mode)
+        s = System(mol.numAtoms, 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        s.set_velocities(vel0)
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        e0 = f.compute(s.pos, s.box, s.forces, returnDetails=True)
+        F0 = s.forces.clone().cpu()
+        torch.manual_seed(9)
+        res = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0).step(30)
+        out[mode] = (e0[0], F0, s.pos.cpu(), s.forces.cpu(), res)
+        f.close()
+    a, b = out["1"], out["0"]
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for x, y in zip(a[4], b[4]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 def test_box_change_and_capacity_growth():
     """(a) changing the box between calls re-plans the cell grid; (b) a denser configuration makes a
     device-side rebuild overflow the list capacity: tmdhip_check reports it, the capacity grows and the
