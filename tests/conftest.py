@@ -27,3 +27,18 @@ def pytest_collection_modifyitems(config, items):
                 have_gpu = torch.cuda.is_available()
             if not have_gpu:
                 item.add_marker(pytest.mark.skip(reason="needs a ROCm device (run through gpurun)"))
+
+
+def pytest_report_header(config):
+    """Which box this is: results that differ between boxes of a pool (clocks, partition mode, host) can then be told
+    from results that differ between runs."""
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            return None
+        p = torch.cuda.get_device_properties(0)
+        return (f"device: {p.name}, {p.multi_processor_count} CUs, {p.total_memory / 2**30:.0f} GiB, "
+                f"arch {getattr(p, 'gcnArchName', '?')}, host cores {os.cpu_count()}")
+    except Exception as exc:  # the header is information only
+        return f"device: unknown ({exc})"
