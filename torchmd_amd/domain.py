@@ -348,6 +348,7 @@ class Domain:
         self.send_buf = torch.empty(len(self.send_index32), 3, dtype=self.dtype, device=self.device)
         self.disp2 = torch.zeros(1, dtype=torch.float32, device=self.device)  # max |x - ref|^2 since this migration
         self.vcoeff_unit = torch.sqrt(1.0 / self.masses).contiguous()  # x sqrt(2 gamma kB T dt) at run time
+        self._vc_key = None  # (the scaled copy belongs to the previous atom set)
 
     def state_rows(self):
         """[n_own, 10] float64 rows for migration: id, pos(3), vel(3), charge, type, mass."""
@@ -474,6 +475,7 @@ class Domain:
         self.plan = SimpleNamespace(send_counts=list(send_counts))
         self.recv_counts = list(recv_counts)
         self.vcoeff_unit = torch.sqrt(1.0 / self.masses).contiguous()
+        self._vc_key = None  # (the scaled copy belongs to the previous atom set)
         if getattr(self, "zero_box", None) is None:  # (the same tensor every time: Forces caches its host copy by object)
             self.zero_box = torch.zeros(1, 3, 3, dtype=self.dtype, device=self.device)
         self.forces_engine._atoms_swapped(n, nown)
@@ -749,9 +751,9 @@ class DomainSet:
             """phases 1: second half kick of the step that just got its forces; 2: first half of the next; 3: both."""
             vc = 0
             if T and (phases & 1):
-                if getattr(d, "_vc_key", None) != (vnoise, d.nown, id(d.vcoeff_unit)):
+                if getattr(d, "_vc_key", None) != (vnoise, d.nown):
                     d._vc = (d.vcoeff_unit * vnoise).contiguous()
-                    d._vc_key = (vnoise, d.nown, id(d.vcoeff_unit))
+                    d._vc_key = (vnoise, d.nown)
                 vc = d._vc.data_ptr()
             L.check(lib.tmdhip_dd_step(code, d.nown, d.pos.data_ptr(), d.vel.data_ptr(), d.forces.data_ptr(),
                                        d.masses.data_ptr(), vc, dt, gamma, seed + 7919 * d.rank, max(self._nstep - 1, 0),
@@ -786,9 +788,9 @@ class DomainSet:
             raise RuntimeError("domain decomposition needs the cell-list engine (brick too small)")
         vc = 0
         if vnoise is not None:
-            if getattr(d, "_vc_key", None) != (vnoise, d.nown, id(d.vcoeff_unit)):
+            if getattr(d, "_vc_key", None) != (vnoise, d.nown):
                 d._vc = (d.vcoeff_unit * vnoise).contiguous()
-                d._vc_key = (vnoise, d.nown, id(d.vcoeff_unit))
+                d._vc_key = (vnoise, d.nown)
             vc = d._vc.data_ptr()
         sc = (C.c_int64 * self.grid.world)(*d.plan.send_counts)
         rc_ = (C.c_int64 * self.grid.world)(*recv_counts)
