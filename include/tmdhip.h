@@ -333,7 +333,13 @@ int tmdhip_comm_exchange(tmdhip_comm *comm, int dtype, const void *send_dev, con
  * the device.  When the projected displacement exceeds skin/2 the call returns 1 with *iters_done = the number
  * of complete iterations: the next one has drifted but has neither halo nor forces yet — the caller migrates
  * atoms, evaluates the forces, counts that iteration as done and calls again with first_phases = 3 (a kick is
- * owed; niter may then be 0).  Returns 0 when all niter iterations are done, negative on error. */
+ * owed; niter may then be 0).  Returns 0 when all niter iterations are done, negative on error.
+ * TMDHIP_DD_OVERRUN (2): a displacement that was MEASURED lies beyond skin/2 already — the projection was too
+ * optimistic (hot atoms, a large check_every) and halo atoms were missing in the last iterations, so the state is
+ * invalid; *iters_done = 0, tmdhip_last_error() says how far the atom went.  Every rank returns it at the same
+ * iteration.  The caller goes back to a state it saved at the last migration and repeats with a smaller
+ * check_every (torchmd_amd/domain.py does; counter-based noise makes the repeat reproducible). */
+#define TMDHIP_DD_OVERRUN 2
 typedef struct tmdhip_dd_desc {
   int32_t struct_size;
   int32_t dtype;

@@ -457,3 +457,73 @@ def test_library_migration_equals_the_torch_migration_with_mixed_types():
     Integrator(s, f, 2.0, dev).step(30)
     assert (P - s.pos[0]).abs().max().item() < 1e-7 and (V - s.vel[0]).abs().max().item() < 1e-7
     assert (F - s.forces[0]).abs().max().item() < 1e-6
+
+
+@pytest.mark.timeout(600)
+def test_halo_overrun_is_recovered_from_the_saved_state():
+    """A `check_every` far too large for the temperature: the first displacement that is looked at lies beyond the halo's
+    half skin already, so the steps since the last migration ran with halo atoms missing.  The loop must notice (the
+    measured value, not the extrapolation), go back to the state saved at the entry of `step` / at the last migration,
+    halve `check_every` and repeat — in the Python-driven loop, in the library's loop over the in-process communicator
+    (world 4: `tmdhip_dd_run` returns TMDHIP_DD_OVERRUN on every rank at the same iteration) and over RCCL (one rank) —
+    and still arrive at the single-domain trajectory.  With `recover` off the same run raises."""
+    import socket
+
+    import torch.distributed as dist
+
+    from torchmd_amd.domain import DistTransport, DomainSet, HaloOverrun, LocalTransport
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.systems import System
+
+    dev, dt = torch.device("cuda:0"), torch.float64
+    mol, pos, box, par = _system(23, dt)
+    n = mol.numAtoms
+    torch.manual_seed(3)
+    vel = maxwell_boltzmann(par.masses, 4000.0, 1)[0].numpy()
+    A, B = par.get_AB()
+    s = System(n, 1, dt, dev)
+    s.set_positions(pos[:, :, None])
+    s.set_box(box)
+    s.set_velocities(torch.tensor(vel)[None])
+    f = Forces(par, terms=["lj"], cutoff=9.0)
+    f.compute(s.pos, s.box, s.forces)
+    Integrator(s, f, 2.0, dev).step(40)
+
+    def run(transport, world, recover=True):
+        ds = DomainSet(box, world, dev, dt, ["lj"], 9.0, A=A, B=B, skin=1.0, transport=transport)
+        ds.check_every, ds.recover = 32, recover
+        ds.scatter(pos, vel, par.charges.numpy(), par.mapped_atom_types.numpy(), par.masses.numpy().ravel())
+        ds.compute_forces()
+        try:
+            ds.step(25, timestep_fs=2.0)
+            ds.step(15, timestep_fs=2.0)
+            moved = ds.verify_halo()
+            return ds.gather(n), ds.recoveries, ds.check_every, ds.migrations, moved
+        finally:
+            for d in ds.domains.values():
+                d.forces_engine.close()
+            transport.close()
+
+    with pytest.raises(HaloOverrun, match="half skin"):
+        run(LocalTransport(4), 4, recover=False)
+    legs = {"python loop": lambda: run(LocalTransport(4), 4), "library loop, world 4": lambda: run(LocalTransport(4, native_threads=True), 4)}
+    for name, leg in legs.items():
+        (P, V, F), rec, every, mig, moved = leg()
+        ep, ev, ef = (P - s.pos[0]).abs().max().item(), (V - s.vel[0]).abs().max().item(), (F - s.forces[0]).abs().max().item()
+        print(f"{name}: {rec} recoveries, check_every 32 -> {every}, {mig} migrations, max|dx| {ep:.2e} max|dv| {ev:.2e} max|dF| {ef:.2e}")
+        assert rec >= 1 and every < 32 and mig >= 1 and moved <= 0.5
+        assert ep < 1e-7 and ev < 1e-7 and ef < 1e-6, name
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        (P, V, F), rec, every, mig, moved = run(DistTransport(), 1)
+    finally:
+        dist.destroy_process_group()
+    ep, ev, ef = (P - s.pos[0]).abs().max().item(), (V - s.vel[0]).abs().max().item(), (F - s.forces[0]).abs().max().item()
+    print(f"library loop over RCCL, one rank: {rec} recoveries, check_every 32 -> {every}, {mig} migrations, max|dx| {ep:.2e}")
+    assert rec >= 1 and every < 32 and mig >= 1
+    assert ep < 1e-7 and ev < 1e-7 and ef < 1e-6

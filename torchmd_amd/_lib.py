@@ -20,6 +20,7 @@ E_LJ, E_ELECTROSTATICS, E_REPULSION, E_REPULSIONCG, E_BONDS, E_ANGLES, E_DIHEDRA
 NENERGY = 8
 WANT_ENERGY, WANT_FORCES, COUNT_PAIRS, OVERWRITE_FORCES = 1, 2, 4, 8
 ALL_REPLICAS = -1  # TMDHIP_ALL_REPLICAS
+DD_OVERRUN = 2  # TMDHIP_DD_OVERRUN: tmdhip_dd_run measured a displacement beyond the halo's half skin
 ALGO_AUTO, ALGO_ALLPAIRS, ALGO_CELLLIST = 0, 1, 2
 SWITCH_REFERENCE, SWITCH_EXACT = 0, 1
 

@@ -752,6 +752,13 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
   void *halo_rows = (char *)d->pos_dev + (size_t)d->nown * 3 * esz;
   int64_t since = d->since_migration;
   *iters_done = 0;
+  // an atom outran the halo: not an error of the call but a verdict on the state (every rank reaches it at the same
+  // iteration: the displacement is the maximum over the ranks) — the caller goes back to a state it saved
+  auto overrun = [&](const std::string &msg) {
+    last_error() = msg;
+    *iters_done = 0;
+    return TMDHIP_DD_OVERRUN;
+  };
   auto kick_drift = [&](int phases, uint64_t kick_step) {
     return tmdhip_dd_step(d->dtype, d->nown, d->pos_dev, d->vel_dev, d->forces_dev, d->mass_dev, d->vcoeff_dev, d->dt,
                           d->gamma, d->seed, kick_step, phases, d->ref_dev, d->disp2_dev, stream);
@@ -796,9 +803,9 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
         if (moved > limit) {
           c->pending = false;
           rp.pub_ptr = nullptr;
-          return fail("tmdhip_dd_run: an atom moved " + std::to_string(moved) + " A since the last migration, beyond the "
-                      "halo's half skin of " + std::to_string(limit) + " A, before a migration was requested: the forces of "
-                      "the last steps are invalid (use a larger halo skin or a smaller check_every)");
+          return overrun("tmdhip_dd_run: an atom moved " + std::to_string(moved) + " A since the last migration, beyond the "
+                         "halo's half skin of " + std::to_string(limit) + " A, before a migration was requested: the forces of "
+                         "the last steps are invalid (use a larger halo skin or a smaller check_every)");
         }
         const double ahead = 1.0 + 2.0 * (double)(since + d->check_every - c->at) / (double)c->at;
         if (moved * ahead > limit) {
@@ -823,8 +830,8 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
         if (moved > limit) {
           c->pending = false;
           rp.pub_ptr = nullptr;
-          return fail("tmdhip_dd_run: an atom moved " + std::to_string(moved) + " A in the first " + std::to_string(since) +
-                      " steps after a migration, beyond the halo's half skin of " + std::to_string(limit) + " A");
+          return overrun("tmdhip_dd_run: an atom moved " + std::to_string(moved) + " A in the first " + std::to_string(since) +
+                         " steps after a migration, beyond the halo's half skin of " + std::to_string(limit) + " A");
         }
         const double ahead = 1.0 + 2.0 * (double)d->check_every / (double)since;  // until the next decision
         if (moved * ahead > limit) {

@@ -303,6 +303,18 @@ class LocalTransport:
 # ------------------------------------------------------------------------------------------------
 # one rank's domain
 # ------------------------------------------------------------------------------------------------
+class DomainReplay(RuntimeError):
+    """The steps since the last saved state are invalid; `DomainSet.step` goes back to that state and repeats them."""
+
+
+class HaloOverrun(DomainReplay):
+    """An atom moved further than half the halo skin before a migration was requested (halo atoms were missing)."""
+
+
+class ListInvalid(DomainReplay):
+    """A brick's neighbour list overflowed or outlived its skin during the batch (its capacity has been grown)."""
+
+
 def _local_parameters(charges, types, masses, A, B):
     """Minimal `Parameters`-shaped object for a set of atoms without bonded terms."""
     par = SimpleNamespace()
@@ -551,6 +563,13 @@ class DomainSet:
         self.check_every = 4  # steps between migration-trigger collectives
         self._pending = None  # (event, pinned host value, step since migration) of the last displacement read-back
         self._host_ring, self._ring_pos = None, 0
+        # recovery: the atoms' state is saved at the entry of `step` and after every migration (6 small copies); when a
+        # measured displacement turns out to lie beyond the halo's half skin, or a brick's list turns out invalid, the
+        # steps since then are repeated from that state — after a halo overrun with half the `check_every`
+        self.recover = True
+        self.max_recoveries = 6  # per `step` call
+        self.recoveries = 0  # (total, for reports)
+        self._saved = None
 
     # -- setup: every rank holds the same global arrays and keeps its brick ---------------------
     def scatter(self, pos, vel, charges, types, masses):
@@ -627,9 +646,9 @@ class DomainSet:
             moved = float(host.item()) ** 0.5
             if moved > limit:
                 self._pending = None
-                raise RuntimeError(f"domain decomposition: an atom moved {moved:.3f} A since the last migration, beyond "
-                                   f"the halo's half skin of {limit:.3f} A, before a migration was requested; the forces "
-                                   "of the last steps are invalid (use a larger halo skin or a smaller check_every)")
+                raise HaloOverrun(f"domain decomposition: an atom moved {moved:.3f} A since the last migration, beyond "
+                                  f"the halo's half skin of {limit:.3f} A, before a migration was requested; the forces "
+                                  "of the last steps are invalid (use a larger halo skin or a smaller check_every)")
             return moved
 
         if self._pending is not None:
@@ -697,8 +716,48 @@ class DomainSet:
             raise RuntimeError(f"tmdhip_dd_migrate failed on ranks {sorted(errors)}: {next(iter(errors.values()))}")
         return True
 
-    def migrate(self):
+    # -- saved state / recovery -----------------------------------------------------------------------
+    def _save_state(self, remaining, first):
+        """The atoms of every brick (global id, position in the caller's periodic image, velocity, charge, type, mass)
+        with the step counter and what is left of the running `step` call (`first`: the phases of its next iteration)."""
+        rows = {r: (d.ids.clone(), d.pos + d.unwrap, d.vel.clone(), d.charges.clone(), d.types.clone(), d.masses.clone())
+                for r, d in self.domains.items()}
+        self._saved = (rows, self._nstep, remaining, first)
+
+    def _restore_state(self):
+        """Back to the saved state: its atoms, a migration from there (owners, halo, engines, reference positions),
+        forces.  Returns what was left of the `step` call at that point."""
+        rows, nstep, remaining, first = self._saved
+        for r, d in self.domains.items():
+            ids, pos, vel, q, t, m = rows[r]
+            d.adopt(ids.clone(), pos.clone(), vel.clone(), q.clone(), t.clone(), m.clone())
+        self._nstep = nstep
+        self.migrate(verify=False)  # (adopt has set the reference positions: nothing to verify)
+        self.compute_forces()
+        return remaining, first
+
+    def verify_halo(self):
+        """The displacement since the last migration as it is NOW (maximum over all ranks; one host synchronisation).
+        The step loop looks at a value measured `check_every` steps earlier and extrapolates; this is the exact test,
+        made at every migration and available to a caller that wants the last steps of a batch certified."""
+        doms = list(self.domains.values())
+        if not doms or getattr(doms[0], "disp2", None) is None:
+            return 0.0
+        if self.local:
+            t = torch.stack([d.disp2[0] for d in doms]).max()
+        else:
+            t = self.transport.max_(doms[0].disp2.clone())[0]
+        moved = float(t.item()) ** 0.5
+        limit = 0.5 * doms[0].skin
+        if moved > limit:
+            raise HaloOverrun(f"domain decomposition: an atom has moved {moved:.3f} A since the last migration, beyond the "
+                              f"halo's half skin of {limit:.3f} A; the forces of the last steps are invalid")
+        return moved
+
+    def migrate(self, verify=True):
         """Re-assign atoms to bricks, rebuild halo plans and engines."""
+        if verify and self.recover:
+            self.verify_halo()
         if self._native_migration():
             self.migrations += 1
             self._since_migration = 0
@@ -760,22 +819,54 @@ class DomainSet:
                                        phases, d.ref.data_ptr(), d.disp2.data_ptr(), stream()))
 
         comm = None if self.local else self.transport.native()
-        if comm is not None:
-            return self._step_native(comm, niter, dt, gamma, vnoise if T else None, seed)
-        if self.local and self.transport.native_threads and self.device.type == "cuda":
-            return self._step_native_threads(niter, dt, gamma, vnoise if T else None, seed)
-        for it in range(niter):
-            for d in self.domains.values():
-                dd_step(d, 2 if it == 0 else 3)
-            if self._migration_due():
-                self.migrate()
-            else:
-                self._exchange(static=False)
-            self.compute_forces()
-            self._nstep += 1
-        if niter > 0:  # (nothing was drifted otherwise: a lone second half kick would be applied twice)
-            for d in self.domains.values():
-                dd_step(d, 1)
+
+        def run(remaining, first):
+            if comm is not None:
+                return self._step_native(comm, remaining, first, dt, gamma, vnoise if T else None, seed)
+            if self.local and self.transport.native_threads and self.device.type == "cuda":
+                return self._step_native_threads(remaining, first, dt, gamma, vnoise if T else None, seed)
+            for it in range(remaining):
+                for d in self.domains.values():
+                    dd_step(d, first if it == 0 else 3)
+                migrated = self._migration_due()
+                if migrated:
+                    self.migrate()
+                else:
+                    self._exchange(static=False)
+                self.compute_forces()
+                self._nstep += 1
+                if migrated and self.recover:
+                    self._save_state(remaining - it - 1, 3)
+            if remaining > 0 or first == 3:  # (nothing was drifted otherwise: a lone second half kick would be applied twice)
+                for d in self.domains.values():
+                    dd_step(d, 1)
+            if remaining > 0:
+                self._lists_valid()
+
+        remaining, first = niter, 2
+        if self.recover and niter > 0:
+            self._save_state(remaining, first)
+        recovered = 0
+        while True:
+            try:
+                run(remaining, first)
+                if self.recover and niter > 0:
+                    # the exact test on the way out: a batch that ends between two looks of the loop is certified too, and
+                    # the state saved at the entry of the next call is a valid one
+                    self.verify_halo()
+                return
+            except DomainReplay as exc:
+                # every rank gets here at the same iteration: the displacement is a maximum over the ranks, and a
+                # brick's invalid list is reported to all of them (`_lists_valid`)
+                halo = isinstance(exc, HaloOverrun)
+                if not self.recover or self._saved is None or recovered >= self.max_recoveries or \
+                        (halo and self.check_every == 1):
+                    raise
+                recovered += 1
+                self.recoveries += 1
+                if halo:
+                    self.check_every = max(1, self.check_every // 2)
+                remaining, first = self._restore_state()
 
     def _dd_desc(self, d, recv_counts, remaining, first, dt, gamma, vnoise, seed):
         """The `tmdhip_dd_desc` of one brick (+ the ctypes arrays it points into, which must outlive the call)."""
@@ -806,7 +897,19 @@ class DomainSet:
         )
         return eng, desc, (sc, rc_)
 
-    def _step_native_threads(self, niter, dt, gamma, vnoise, seed):
+    def _lists_valid(self):
+        """The neighbour lists of the batch that just ended, on every rank (a verdict all ranks share)."""
+        from . import _lib as L
+
+        bad = {}
+        for r, d in self.domains.items():
+            ok = d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos)
+            bad[r] = torch.tensor([0.0 if ok else 1.0], device=self.device)
+        if self._any(bad):
+            raise ListInvalid(f"a neighbour list of a brick became invalid during the batch ({L.last_error()}): "
+                              "repeat the batch")
+
+    def _step_native_threads(self, niter, first, dt, gamma, vnoise, seed):
         """All bricks in this process, each brick's loop enqueued from C by a host thread of its own over the
         in-process communicator (`LocalTransport(native_threads=True)`); Python takes over for a migration."""
         import ctypes as C
@@ -817,7 +920,7 @@ class DomainSet:
         lib = L.load()
         comms, streams = self.transport.native(self.device)
         world = self.grid.world
-        remaining, first = niter, 2
+        remaining = niter
         while True:
             jobs = {}
             for r, d in self.domains.items():
@@ -832,7 +935,7 @@ class DomainSet:
                 try:
                     with torch.cuda.device(self.device):
                         rc = lib.tmdhip_dd_run(eng.ctx, comms[r], C.byref(desc), C.byref(done), streams[r].cuda_stream)
-                    results[r] = (rc, done.value, L.last_error() if rc < 0 else "")
+                    results[r] = (rc, done.value, L.last_error() if rc < 0 or rc == L.DD_OVERRUN else "")
                 except Exception as exc:  # noqa: BLE001
                     results[r] = (-99, 0, repr(exc))
 
@@ -851,6 +954,8 @@ class DomainSet:
             rc, done = rcs.pop(), dones.pop()
             for d in self.domains.values():
                 d.forces = d.local_forces[0, : d.nown]
+            if rc == L.DD_OVERRUN:
+                raise HaloOverrun(next(iter(results.values()))[2])
             self._nstep += done
             self._since_migration += done + (1 if rc == 1 else 0)
             remaining -= done
@@ -861,12 +966,11 @@ class DomainSet:
             self._nstep += 1
             remaining -= 1
             first = 3
-        for d in self.domains.values():
-            if not d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos):
-                raise RuntimeError(f"a neighbour list of a brick became invalid during the batch ({L.last_error()}): "
-                                   "repeat the batch")
+            if self.recover:
+                self._save_state(remaining, first)
+        self._lists_valid()
 
-    def _step_native(self, comm, niter, dt, gamma, vnoise, seed):
+    def _step_native(self, comm, niter, first, dt, gamma, vnoise, seed):
         """`niter` iterations enqueued from C (`tmdhip_dd_run`: RCCL send/recv on the compute stream); Python
         only takes over for a migration."""
         import ctypes as C
@@ -875,7 +979,7 @@ class DomainSet:
 
         lib = L.load()
         d = next(iter(self.domains.values()))
-        remaining, first = niter, 2
+        remaining = niter
         done = C.c_int32(0)
         while True:
             eng, desc, _keep = self._dd_desc(d, self._recv_counts["halo"], remaining, first, dt, gamma, vnoise, seed)
@@ -883,6 +987,8 @@ class DomainSet:
                 rc = L.check(lib.tmdhip_dd_run(eng.ctx, comm, C.byref(desc), C.byref(done),
                                                torch.cuda.current_stream(self.device).cuda_stream), "tmdhip_dd_run")
             d.forces = d.local_forces[0, : d.nown]
+            if rc == L.DD_OVERRUN:
+                raise HaloOverrun(L.last_error())
             self._nstep += done.value
             self._since_migration += done.value + (1 if rc == 1 else 0)
             remaining -= done.value
@@ -893,9 +999,9 @@ class DomainSet:
             self._nstep += 1
             remaining -= 1
             first = 3
-        if not d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos):
-            raise RuntimeError(f"a neighbour list of the brick became invalid during the batch ({L.last_error()}): "
-                               "repeat the batch")
+            if self.recover:
+                self._save_state(remaining, first)
+        self._lists_valid()
 
     # -- gathering (tests / output) ---------------------------------------------------------------
     def gather(self, natoms):
