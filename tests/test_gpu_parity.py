@@ -807,6 +807,60 @@ def test_streamed_list_reads_are_bit_identical(monkeypatch):
         assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
+def test_side_stream_equals_the_default_stream():
+    """Everything is enqueued on the caller's stream (`torch.cuda.current_stream`).  A side stream of PyTorch is created
+    non-blocking: it is NOT ordered behind the null stream, through which the library's set-up uploads go (parameters,
+    exclusions, skins, bonded tables, zeroed flags).  Those uploads must be complete when the set-up calls return: a
+    context created and used at once on a side stream gives the default stream's results bit for bit — forces, energies,
+    a fused Langevin trajectory (cell-list path with per-atom skins and bonded terms) and the all-pairs path."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(14, seed=2)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    torch.manual_seed(1)
+    vel0 = maxwell_boltzmann(par.masses, 300.0, 1)
+    g = load("ala2")
+    gpar = GoldenParameters(g, torch.float64)
+
+    def run():
+        s = System(mol.numAtoms, 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        s.set_velocities(vel0)
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        e0 = f.compute(s.pos, s.box, s.forces, returnDetails=True)
+        F0 = s.forces.clone()
+        torch.manual_seed(9)  # (the integrator draws its noise key from torch's generator)
+        res = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0).step(30)
+        pots, F, *_ = _run(gpar, g["pos"], g["box"], ALL_TERMS, prec="f64", cutoff=9.0, switch_dist=7.5, rfa=True)
+        torch.cuda.current_stream(dev).synchronize()
+        out = (e0[0], F0.cpu(), s.pos.cpu(), s.forces.cpu(), res, pots[0], np.asarray(F))
+        f.close()
+        return out
+
+    a = run()
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        b = run()
+    torch.cuda.synchronize()
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    # (energies are folded with fp64 atomics, the all-pairs forces too: the order of the additions is not fixed)
+    for k in a[0]:
+        assert abs(a[0][k] - b[0][k]) <= 1e-12 * max(1.0, abs(a[0][k])), k
+    for x, y in zip(a[4], b[4]):
+        assert np.allclose(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), rtol=1e-12, atol=0)
+    for k in a[5]:
+        assert abs(a[5][k] - b[5][k]) <= 1e-12 * max(1.0, abs(a[5][k])), k
+    assert np.abs(a[6] - b[6]).max() < 1e-9
+
+
 def test_box_change_and_capacity_growth():
     """(a) changing the box between calls re-plans the cell grid; (b) a denser configuration makes a
     device-side rebuild overflow the list capacity: tmdhip_check reports it, the capacity grows and the

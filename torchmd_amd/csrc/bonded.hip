@@ -382,6 +382,7 @@ int tmdhip_set_bonded(tmdhip_ctx *ctx, const tmdhip_bonded_desc *desc) {
     return rc;
   }
   ctx_bonded_slot(ctx) = b;
+  (void)hipStreamSynchronize(nullptr);  // (null-stream uploads complete before a non-blocking stream of the caller uses them)
   return 0;
 }
 

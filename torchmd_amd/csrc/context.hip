@@ -205,6 +205,9 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   if (rp.padgen.bytes < sizeof(int) * (groups + 8)) {  // (+ the surplus waves of the last pair block)
     TMD_TRY(rp.padgen.ensure(sizeof(int) * (groups + 8)));
     TMD_HIP(hipMemset(rp.padgen.p, 0, rp.padgen.bytes));
+    // the caller's stream need not be ordered behind the null stream (a stream created non-blocking — every side stream
+    // of PyTorch — is not), and a memset of device memory may return before it is done: wait for it here (rare path)
+    TMD_HIP(hipStreamSynchronize(nullptr));
   }
   return 0;
 }
@@ -526,6 +529,9 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
   ctx->d.types_host = nullptr;
   ctx->d.charges_host = ctx->d.lj_A_host = ctx->d.lj_B_host = nullptr;
   ctx->d.excl_offsets_host = ctx->d.excl_index_host = nullptr;
+  // the uploads above went through the null stream; the caller's stream need not be ordered behind it (a stream created
+  // non-blocking — every side stream of PyTorch — is not): everything is in place when the call returns
+  (void)hipStreamSynchronize(nullptr);
   *out = ctx;
   return 0;
 }
@@ -637,6 +643,7 @@ int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, 
     if (rp.lg.maxn > 0) rp.maxn_keep = rp.lg.maxn;
     rp.lg.maxn = 0;
   }
+  TMD_HIP(hipStreamSynchronize(nullptr));  // (null-stream uploads complete before a non-blocking stream of the caller uses them)
   return 0;
 }
 
@@ -691,6 +698,7 @@ int tmdhip_set_skin_weights(tmdhip_ctx *ctx, const void *weights_host) {
   ctx->vskin_cap_len = 0.5 * ctx->skin * wmax * ctx->vskin_cap;
   ctx->rlist = ctx->d.cutoff + 2.0 * ctx->vskin_cap_len;  // the largest pair radius: sizes the cells and the stencil reach
   ctx->mean_list_scale = std::pow((ctx->d.cutoff + ctx->skin * wsum / n) / ctx->rlist, 3.0);
+  TMD_HIP(hipStreamSynchronize(nullptr));  // (null-stream uploads complete before a non-blocking stream of the caller uses them)
   return 0;
 }
 

@@ -402,6 +402,15 @@ struct DevBuf {
     bytes = 0;
     TMD_HIP(hipMalloc(&p, need));
     bytes = need;
+    // TMDHIP_DEBUG_POISON=1 (tests): fresh device memory is usually zero on an idle box and arbitrary on a busy one; fill
+    // every new buffer with 0xFF bytes (NaN as a real, -1 as an index, the largest launch number) so that a read of
+    // something nobody wrote shows on every box
+    // (2: zeros instead — the same extra synchronisations without the garbage, to tell the two apart)
+    static const int poison = [] { const char *e = std::getenv("TMDHIP_DEBUG_POISON"); return e ? std::atoi(e) : 0; }();
+    if (poison) {
+      TMD_HIP(hipMemset(p, poison == 2 ? 0x00 : 0xFF, need));
+      TMD_HIP(hipStreamSynchronize(nullptr));  // (a memset of device memory need not be complete when the call returns)
+    }
     return 0;
   }
   void release() {

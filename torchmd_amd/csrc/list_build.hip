@@ -848,6 +848,7 @@ static int ensure_shadow(tmdhip_ctx *ctx, Replica &rp) {
     TMD_TRY(s.count.ensure(rp.count.bytes));
     TMD_HIP(hipMemset(s.count.p, 0, s.count.bytes));  // (scan_cells_kernel leaves the counts zero for the next build)
   }
+  TMD_HIP(hipStreamSynchronize(nullptr));  // (the streams these buffers are used on need not be ordered behind the null stream)
   return 0;
 }
 
