@@ -807,71 +807,6 @@ def test_streamed_list_reads_are_bit_identical(monkeypatch):
         assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
-@pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("shifted", [False, True])
-def test_image_flags_are_exact(prec, shifted, monkeypatch):
-    """Bit 0 of a list entry says whether the raw coordinates of the pair lie in different periodic images of the box
-    (decided by the list build from the atoms' image counts; constant while the list lives).  Wave groups without such
-    an entry skip the minimum-image arithmetic in the lean kernels: `d - box * round(d / box)` with round(...) = 0 is d,
-    bit for bit.  So forces, energies, the pair count and a fused trajectory must equal those with the flags ignored
-    (TMDHIP_IMAGE_FLAGS=0) exactly — in a wrapped box and with half of the molecules moved by up to +-3 box edges
-    (unwrapped coordinates, what a long run without `Wrapper.wrap` produces) — and the oracle within the usual bars."""
-    from oracle import torchmd_oracle as orc
-    from torchmd_amd.builders import tip3p_box, water_forcefield
-    from torchmd_amd.forces import Forces
-    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
-    from torchmd_amd.parameters import Parameters
-    from torchmd_amd.systems import System
-
-    dev, dt = _dev(), PREC[prec]
-    mol, pos, box = tip3p_box(14, seed=4)
-    nb = ["lj", "electrostatics"]
-    terms = nb + ["bonds", "angles"]
-    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
-    pos = np.array(pos, dtype=np.float64)
-    if shifted:
-        rng = np.random.default_rng(11)
-        nmol = pos.shape[0] // 3
-        k = rng.integers(-3, 4, size=(nmol, 3)) * (rng.random(nmol) < 0.5)[:, None]
-        pos = pos + np.repeat(k, 3, axis=0) * np.asarray(box, dtype=np.float64)[None, :]
-    torch.manual_seed(2)
-    vel0 = maxwell_boltzmann(par.masses, 300.0, 1)
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("TMDHIP_IMAGE_FLAGS", mode)
-        s = System(mol.numAtoms, 1, dt, dev)
-        s.set_positions(pos[:, :, None])
-        s.set_box(box)
-        s.set_velocities(vel0)
-        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
-        e0 = f.compute(s.pos, s.box, s.forces, returnDetails=True)
-        F0 = s.forces.clone().cpu()
-        npairs = f.count_pairs(s.pos, s.box)
-        torch.manual_seed(9)
-        res = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0).step(40)
-        out[mode] = (e0[0], F0, npairs, s.pos.cpu(), s.forces.cpu(), res, f.stats(s.pos)["n_rebuilds"])
-        f.close()
-    a, b = out["1"], out["0"]
-    assert torch.equal(a[1], b[1]) and a[2] == b[2] and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and a[6] == b[6] >= 2
-    for k in a[0]:  # (energies are folded with fp64 atomics: the order of the additions is not fixed)
-        assert abs(a[0][k] - b[0][k]) <= 1e-12 * max(1.0, abs(a[0][k])), k
-    for x, y in zip(a[5], b[5]):
-        assert np.allclose(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), rtol=1e-12, atol=0)
-    monkeypatch.delenv("TMDHIP_IMAGE_FLAGS")
-    p = pos_tensor(pos, 1, dt)
-    pairs = orc.candidate_pairs(pos, box, 9.6, orc.exclusion_pairs(par))
-    po, Fo, npo = orc.compute(par, p, box_tensor(box, 1, dt), nb, pairs=pairs, cutoff=9.0, rfa=True)
-    assert a[2] == npo
-    fo = Forces(par, terms=nb, cutoff=9.0, rfa=True, algorithm="celllist")
-    pd, bd = p.to(dev), box_tensor(box, 1, dt, dev)
-    Fn = torch.zeros_like(pd)
-    fo.compute(pd, bd, Fn)
-    # (fp32 with coordinates up to 3 box edges out: the subtraction x_i - x_j itself rounds at ~1e-5 A, as in the reference)
-    tol = 1e-9 if prec == "f64" else (2e-3 if shifted else 6e-5)
-    assert ((Fn.cpu() - Fo).abs() / (1 + Fo.abs())).max().item() < tol
-    fo.close()
-
-
 def test_side_stream_equals_the_default_stream():
     """Everything is enqueued on the caller's stream (`torch.cuda.current_stream`).  A side stream of PyTorch is created
     non-blocking: it is NOT ordered behind the null stream, through which the library's set-up uploads go (parameters,

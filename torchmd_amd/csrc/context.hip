@@ -212,12 +212,6 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   return 0;
 }
 
-// TMDHIP_IMAGE_FLAGS=0 (A/B, tests; read per launch): the pair kernels ignore kEntryImageFlag
-static bool image_flags_off() {
-  const char *e = std::getenv("TMDHIP_IMAGE_FLAGS");
-  return e && std::atoi(e) == 0;
-}
-
 template <typename R>
 int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces,
                  double *energies, int flags, hipStream_t st, const FusedLaunchT<R> *fused) {
@@ -345,7 +339,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
   const int overwrite = (flags & TMDHIP_OVERWRITE_FORCES) ? 1 : 0;
   // list duties of the pair launch's first thread: rp.step counts the NEXT step by now
   const int lmode = ((flags & kViolationCheck) ? kLmViolation : 0) | (((rp.step - 1) & 1) ? kLmParity : 0) |
-                    (rp.pad_rows ? kLmPadded : 0) | (list_streams(ctx, rp) ? kLmStream : 0) | (image_flags_off() ? kLmImageAlways : 0);
+                    (rp.pad_rows ? kLmPadded : 0) | (list_streams(ctx, rp) ? kLmStream : 0);
   FusedLaunchT<R> fl{};
   if (fused) {
     fl = *fused;

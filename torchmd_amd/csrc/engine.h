@@ -168,12 +168,10 @@ __device__ __forceinline__ bool extent_needs_exact_image(const int *__restrict__
 template <typename R>
 __device__ __forceinline__ void list_check_point(const ListCheck<R> &k, const PairConsts<R> &c, R rx, R ry, R rz,
                                                  R h2) {
-  // The RAW displacement, not its minimum image: an atom that is moved by a box vector between two evaluations
-  // (Wrapper.wrap, a caller that folds coordinates) keeps its neighbours but changes the periodic image its raw
-  // coordinates lie in, and the list records exactly that per pair (kEntryImageFlag) — such a move rebuilds the list.
-  // Inside an MD batch positions move continuously, so nothing changes there.
-  (void)c;
-  const R d2 = rx * rx + ry * ry + rz * rz;
+  const R dx = min_image(rx, c.box[0], c.invbox[0]);
+  const R dy = min_image(ry, c.box[1], c.invbox[1]);
+  const R dz = min_image(rz, c.box[2], c.invbox[2]);
+  const R d2 = dx * dx + dy * dy + dz * dz;
   if (!(d2 <= h2)) {  // NaN positions also force a rebuild
     k.flags[F_REBUILD0 + k.parity] = 1;
     if (k.skipped) k.flags[F_VIOLATION] = 1;
@@ -222,23 +220,6 @@ struct PlaceArgs {
 // of atom j's float4 record, `entry >> 24` the byte offset of type j in an 8-byte-stride LDS table row (for
 // n <= 2^20; larger systems mask it).  Contexts with more than kEntryTypes LJ classes leave the type field 0 (kernels read stype[j]).
 constexpr unsigned kEntryOffMask = 0x07FFFFF0u;  // byte offset of atom j's float4 record
-// Bit 0 (the low four bits are free: every reader masks the offset): the raw coordinates of i and j lie in DIFFERENT
-// periodic images of the box, i.e. round((x_i - x_j) / box) != 0 on some axis.  Decided by the list build from the atoms'
-// image counts (image_key) and valid for as long as the list lives: a listed pair stays within cutoff + skins of each
-// other, far below box / 2 (the cell path needs box >= 3 (cutoff + skin)), so that integer cannot change.  A clear bit
-// lets a pair kernel take d = x_i - x_j as it is: the reference's `d - box * round(d / box)` (forces.py:360-365)
-// subtracts box * 0 there — same bits, 9 instructions less per entry.  A set bit only says "do the arithmetic": setting
-// it where it is not needed (atoms more than 500 boxes away from the origin: kImageKeyWild*) costs time, never
-// correctness.  Padding entries (pad_entry_for) leave it clear: the dummy record is out of reach in every image.
-constexpr unsigned kEntryImageFlag = 1u;
-constexpr unsigned kImageKeyWildI = 0xFFFFFFFFu, kImageKeyWildJ = 0xFFFFFFFEu;  // never equal to each other or to a key
-// image counts (floor(x / box) per axis, as floats) of an atom packed into one word: 10 bits per axis around 512
-template <typename R>
-__device__ __forceinline__ unsigned image_key(R nx, R ny, R nz, unsigned wild) {
-  const int ix = (int)nx + 512, iy = (int)ny + 512, iz = (int)nz + 512;
-  const bool ok = fabs(nx) < R(500) && fabs(ny) < R(500) && fabs(nz) < R(500);  // (NaN: not ok)
-  return ok ? ((unsigned)ix | ((unsigned)iy << 10) | ((unsigned)iz << 20)) : wild;
-}
 constexpr int kEntryTypes = 32;                  // LJ classes that fit the entry's type field
 constexpr int kEntryTypeShift = 27;
 constexpr float kR2Floor = 1.0e-2f;  // (0.1 A)^2: keeps 1/r^14 finite for the self entries that pad a column
@@ -307,7 +288,6 @@ __device__ __forceinline__ float min_image_magic(float d, float box, float invbo
 
 using exact_image = std::integral_constant<bool, true>;
 using fused_image = std::integral_constant<bool, false>;
-struct plain_image {};  // no minimum-image arithmetic at all: every entry of the group has kEntryImageFlag clear
 
 // ---- K3d: the same lean kernel for fp64 contexts ----------------------------------------------------
 // 32-byte records (two 16-byte gathers per entry), 16-byte table entries, half-rate arithmetic; 1/r from v_rsq_f64
@@ -384,7 +364,6 @@ constexpr int kLmViolation = 1;  // the chain of this step was left out and its 
                                  // launch's epilogue, which could not know that: a rebuild request found now = F_VIOLATION
 constexpr int kLmParity = 2;     // parity of this step
 constexpr int kLmStream = 8;     // the list does not fit the Infinity Cache: stream it with the non-temporal hint (pair_fast_f32.hip)
-constexpr int kLmImageAlways = 16;  // ignore kEntryImageFlag: minimum-image arithmetic for every entry (TMDHIP_IMAGE_FLAGS=0: A/B, tests)
 constexpr int kLmPadded = 4;     // Replica::pad_rows: the dummy records exist; a wave group whose padgen word equals the rebuild count is padded
 constexpr int kFastThreads = 256;  // threads of a block of the lean fp32 pair kernel (step blocks are four waves)
 

@@ -465,7 +465,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   __shared__ int s_eb[64], s_more[64];
   __shared__ unsigned s_bm[64];
   __shared__ __align__(16) int s_cnt[64];
-  __shared__ __align__(16) unsigned s_key[64];  // image key of atom ib + lane (image_key), see kEntryImageFlag
   const int apw_shift = 6 - lg.lpa_shift;
   const unsigned kmask = (unsigned)lg.lpa - 1u;
   // entry k of a row sits at byte ((k / (4 LPA)) << 10) + ((k % LPA) << 4) + (((k / LPA) % 4) << 2)  (list_slot); the
@@ -481,16 +480,12 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     const int ni = iend - ib;
     __syncthreads();
     int long_rows = 0;
-    unsigned mykey = 0u;
     if (lane < ni) {
       const int a = ib + lane;
       R4 p = sorted[a];
-      // (wrap_into_box with the image count kept: x = w + n box)
-      const R nx = floor(p.x * c.invbox[0]), ny = floor(p.y * c.invbox[1]), nz = floor(p.z * c.invbox[2]);
-      p.x = p.x - nx * c.box[0];
-      p.y = p.y - ny * c.box[1];
-      p.z = p.z - nz * c.box[2];
-      mykey = image_key(nx, ny, nz, kImageKeyWildI);
+      p.x = wrap_into_box(p.x, c.box[0], c.invbox[0]);
+      p.y = wrap_into_box(p.y, c.box[1], c.invbox[1]);
+      p.z = wrap_into_box(p.z, c.box[2], c.invbox[2]);
       const unsigned rowoff = (((unsigned)(a >> apw_shift) * (unsigned)lg.maxn) << apw_shift) +
                               ((unsigned)(a & (lg.apw - 1)) << (lg.lpa_shift + 2));
       p.w = WSKIN ? rcut + sorted_hs[a] : R(0);
@@ -518,11 +513,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     }
     const bool any_long = __ballot(long_rows) != 0ull;
     s_bm[lane] = 0u;
-    s_key[lane] = mykey;
-    // all atoms of the block in the same periodic image of the box (the rule: nobody has wandered around it)?  Then a
-    // chunk whose candidates all carry that key flags nothing, and the batches below skip the key compares.
-    const unsigned key0 = (unsigned)__builtin_amdgcn_readfirstlane((int)mykey);
-    const bool keys_uniform = __ballot(lane < ni && mykey != key0) == 0ull;
     __syncthreads();
     s_cnt[lane] = 0;  // neighbour count of atom ib + lane (lives in LDS: one broadcast read + one
                       // same-value write per iteration instead of cross-lane register traffic)
@@ -572,18 +562,10 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
       // the reference's rounding; the pair kernel's cutoff test does).  Lanes past the end of the
       // candidate list are parked far away so that they can never hit.
-      const R sjx = (R)((code & 3) - 1), sjy = (R)(((code >> 2) & 3) - 1), sjz = (R)(((code >> 4) & 3) - 1);
-      const R njx = floor(pj.x * c.invbox[0]), njy = floor(pj.y * c.invbox[1]), njz = floor(pj.z * c.invbox[2]);
-      pj.x = (pj.x - njx * c.box[0]) + sjx * c.box[0];
-      pj.y = (pj.y - njy * c.box[1]) + sjy * c.box[1];
-      pj.z = (pj.z - njz * c.box[2]) + sjz * c.box[2];
+      pj.x = wrap_into_box(pj.x, c.box[0], c.invbox[0]) + (R)((code & 3) - 1) * c.box[0];
+      pj.y = wrap_into_box(pj.y, c.box[1], c.invbox[1]) + (R)(((code >> 2) & 3) - 1) * c.box[1];
+      pj.z = wrap_into_box(pj.z, c.box[2], c.invbox[2]) + (R)(((code >> 4) & 3) - 1) * c.box[2];
       if (!valid) pj.x = (R)1e18;
-      // kEntryImageFlag: the raw coordinates of i and j differ by (n_i - (n_j - s_j)) box + the short vector tested below;
-      // equal keys = no box edge between them, now and for as long as the list lives (a listed pair stays within
-      // cutoff + skins << box / 2): the pair kernels may then skip the minimum-image arithmetic for the entry
-      const unsigned keyj = image_key(njx - sjx, njy - sjy, njz - sjz, kImageKeyWildJ);
-      const unsigned entry1 = entry | kEntryImageFlag;
-      const bool foreign = !keys_uniform || __builtin_amdgcn_uicmp(valid ? keyj : key0, key0, 33 /* ne */) != 0ull;
       // exclusions, compaction and store of the hits of atom t (mask = lanes whose candidate is in range)
       auto handle = [&](int t, unsigned roff, const R4 &pi, unsigned long long mask) {
         const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + roff);
@@ -602,7 +584,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
         if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
           const unsigned rowoff = (unsigned)ex.w >> 2;
           const unsigned kk = k >> lg.lpa_shift;
-          nlist[rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u)] = s_key[t] != keyj ? entry1 : entry;
+          nlist[rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u)] = entry;
         }
         s_cnt[t] = base + (int)__popcll(mask);  // every lane writes the same value
       };
@@ -634,23 +616,11 @@ __global__ __launch_bounds__(64) void build_list_kernel(
         // candidates that somebody in this block excludes (see s_bm); lanes past the end never hit anyway
         const unsigned bmw = s_bm[(oj & 2047u) >> 5];
         const unsigned long long special = __builtin_amdgcn_uicmp((bmw >> (oj & 31u)) & 1u, 0u, 33 /* ne */);
-        // FOREIGN: some candidate of this chunk (or some atom of this block) lies in another periodic image of the box —
-        // the entries of pairs with different keys get kEntryImageFlag (one LDS word, four compares and four selects
-        // per batch more); otherwise no entry of the chunk is flagged and the batch is what it was
-        auto batches = [&](auto foreign_c) {
-        constexpr bool FOREIGN = decltype(foreign_c)::value;
         for (; t < ni; t += 4, recoff += 64u) {
           const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
           unsigned long long m[4] = {in_range(p0), in_range(p1), in_range(p2), in_range(p3)};
           const unsigned long long any = m[0] | m[1] | m[2] | m[3];
           if (!any) continue;
-          unsigned ent[4] = {entry, entry, entry, entry};
-          if constexpr (FOREIGN) {
-            const uint4 k4 = *reinterpret_cast<const uint4 *>(&s_key[t]);
-            const unsigned kk4[4] = {k4.x, k4.y, k4.z, k4.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ent[u] = kk4[u] != keyj ? entry1 : entry;
-          }
           const int4 base4 = *reinterpret_cast<const int4 *>(&s_cnt[t]);
           const int base[4] = {base4.x, base4.y, base4.z, base4.w};
           int4 ex[4];
@@ -678,14 +648,11 @@ __global__ __launch_bounds__(64) void build_list_kernel(
             // only the lanes with a hit store: exec = the hit mask for the one instruction (every lane of the block is
             // active here); a v_cndmask on an out-of-range offset would cost a half-rate VALU slot instead
             asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_dword %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
-                         :: "v"(ent[u]), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
+                         :: "v"(entry), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
             cnt[u] = base[u] + (int)__popcll(m[u]);
           }
           *reinterpret_cast<int4 *>(&s_cnt[t]) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);  // every lane writes the same values
         }
-        };
-        if (foreign) batches(std::true_type{});
-        else batches(std::false_type{});
       }
       for (; t + 4 <= ni; t += 4, recoff += 64u) {  // (cells with long exclusion rows: the branching path)
         const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
@@ -922,7 +889,9 @@ __global__ void adopt_list_kernel(int n, const R *__restrict__ pos, const R *__r
   if (i == 0) flags[F_REBUILD0 + parity] = 0;
   if (i >= n) return;
   const R x = pos[3 * i + 0], y = pos[3 * i + 1], z = pos[3 * i + 2];
-  const R dx = x - ref[3 * i + 0], dy = y - ref[3 * i + 1], dz = z - ref[3 * i + 2];  // raw, as list_check_point (engine.h)
+  const R dx = min_image(x - ref[3 * i + 0], c.box[0], c.invbox[0]);
+  const R dy = min_image(y - ref[3 * i + 1], c.box[1], c.invbox[1]);
+  const R dz = min_image(z - ref[3 * i + 2], c.box[2], c.invbox[2]);
   const R h2 = hs2 ? hs2[i] : hard2;
   if (!(dx * dx + dy * dy + dz * dz <= h2)) flags[F_VIOLATION] = 1;
   typename Vec<R>::T4 rec;

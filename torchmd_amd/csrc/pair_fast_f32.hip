@@ -195,8 +195,7 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   // one group = this lane's 4 entries of iterations kk0 .. kk0+3 (one 16-byte list word) and their 4 gathered records;
   // tab[u] = byte offset of entry u's {-12 A, 6 B} in the LDS table (row of type i | 8 x type j)
   auto group = [&](auto image, auto unchecked, const auto &tab, const auto &raw, int kk0) {
-    constexpr bool PLAIN = std::is_same<decltype(image), plain_image>::value;  // no entry of the group crosses a box edge
-    constexpr bool EXACT = std::is_same<decltype(image), exact_image>::value;
+    constexpr bool EXACT = decltype(image)::value;
     constexpr bool UNCHECKED = decltype(unchecked)::value;
     constexpr bool ARITH_CUT = UNCHECKED && !ENERGY;
     constexpr int NU = (int)std::extent<std::remove_reference_t<decltype(tab)>>::value;
@@ -204,14 +203,9 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     float dx[NU], dy[NU], dz[NU], r2[NU], rinv[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      dx[u] = pi.x - __uint_as_float(raw[u].x);
-      dy[u] = pi.y - __uint_as_float(raw[u].y);
-      dz[u] = pi.z - __uint_as_float(raw[u].z);
-      if constexpr (!PLAIN) {  // (PLAIN: round(d / box) is 0 on every axis — kEntryImageFlag — and d - box * 0 is d)
-        dx[u] = min_image_magic<EXACT>(dx[u], vbx, vibx);
-        dy[u] = min_image_magic<EXACT>(dy[u], vby, viby);
-        dz[u] = min_image_magic<EXACT>(dz[u], vbz, vibz);
-      }
+      dx[u] = min_image_magic<EXACT>(pi.x - __uint_as_float(raw[u].x), vbx, vibx);
+      dy[u] = min_image_magic<EXACT>(pi.y - __uint_as_float(raw[u].y), vby, viby);
+      dz[u] = min_image_magic<EXACT>(pi.z - __uint_as_float(raw[u].z), vbz, vibz);
       r2[u] = norm2(dx[u], dy[u], dz[u]);
     }
     asm("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7"
@@ -275,29 +269,12 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   static_assert(UNROLL == 4, "one dwordx4 of list per lane and group");
   // issue the 4 gathers of the group whose list word is `w` and form its table offsets (unchecked: n <= 2^20, bits
   // 24..27 of an entry are zero; checked: padding words are garbage, the offset is masked)
-  // Returns whether any entry of the wave's group carries kEntryImageFlag (wave-uniform): only then does the group's
-  // evaluation make the minimum-image arithmetic (`evaluate`).  kLmImageAlways (TMDHIP_IMAGE_FLAGS=0: A/B, tests): always.
-  const bool image_always = lmode & kLmImageAlways;
   auto issue = [&](auto unchecked, const v4u &w, v4u (&raw)[UNROLL], unsigned (&tab)[UNROLL]) {
     const unsigned entry[UNROLL] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) tab[u] = trow | (decltype(unchecked)::value ? entry[u] >> 24 : (entry[u] >> 24) & 0xF8u);
-#ifdef TMD_AB_NO_IMAGE_FLAGS
-    return true;
-#else
-    const unsigned fl = (w.x | w.y | w.z | w.w) & kEntryImageFlag;
-    return image_always || __builtin_amdgcn_uicmp(fl, 0u, 33 /* ne */) != 0ull;
-#endif
-  };
-  auto evaluate = [&](auto image, auto unchecked, bool crosses, const auto &tab, const auto &raw, int kk0) {
-#ifdef TMD_AB_NO_IMAGE_FLAGS  // A/B build switch (tools/ab_pair.py): the kernel as it was before the flags
-    group(image, unchecked, tab, raw, kk0);
-#else
-    if (crosses) group(image, unchecked, tab, raw, kk0);
-    else group(plain_image{}, unchecked, tab, raw, kk0);
-#endif
   };
   const int gall = (nkk + UNROLL - 1) / UNROLL;  // groups of this wave
   int g = 0;                                     // next group to evaluate; `word` = its list word
@@ -327,11 +304,11 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     for (; g < gall; ++g) {
       v4u raw[UNROLL];
       unsigned tab[UNROLL];
-      const bool crosses = issue(checked_t{}, word, raw, tab);
+      issue(checked_t{}, word, raw, tab);
       __builtin_amdgcn_sched_barrier(0);
       word = list_word(g + 1);
       __builtin_amdgcn_sched_barrier(0);
-      evaluate(image, checked_t{}, crosses, tab, raw, g * UNROLL);
+      group(image, checked_t{}, tab, raw, g * UNROLL);
     }
   };
   if (extent_needs_exact_image(ext, c.box)) {  // wave-uniform, rare: atoms more than 2.4 box edges apart
@@ -347,11 +324,11 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
       for (; g < gfull; ++g) {
         v4u raw[UNROLL];
         unsigned tab[UNROLL];
-        const bool crosses = issue(unchecked_t{}, word, raw, tab);
+        issue(unchecked_t{}, word, raw, tab);
         __builtin_amdgcn_sched_barrier(0);
         word = list_word(g + 1);
         __builtin_amdgcn_sched_barrier(0);
-        evaluate(fused_image{}, unchecked_t{}, crosses, tab, raw, g * UNROLL);
+        group(fused_image{}, unchecked_t{}, tab, raw, g * UNROLL);
       }
 #if TMD_AB_LDS_GATHER
     } else if (gfull > 0) {
@@ -414,32 +391,32 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     } else if (gfull > 0) {
       v4u ra[UNROLL], rb[UNROLL];
       unsigned ta[UNROLL], tb[UNROLL];
-      bool ca = issue(unchecked_t{}, word, ra, ta), cb = false;
+      issue(unchecked_t{}, word, ra, ta);
       __builtin_amdgcn_sched_barrier(0);
       word = list_word(1);
       __builtin_amdgcn_sched_barrier(0);
       while (true) {
         if (g + 1 >= gfull) {
-          evaluate(fused_image{}, unchecked_t{}, ca, ta, ra, g * UNROLL);
+          group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
           g += 1;
           break;
         }
-        cb = issue(unchecked_t{}, word, rb, tb);
+        issue(unchecked_t{}, word, rb, tb);
         __builtin_amdgcn_sched_barrier(0);
         word = list_word(g + 2);
         __builtin_amdgcn_sched_barrier(0);
-        evaluate(fused_image{}, unchecked_t{}, ca, ta, ra, g * UNROLL);
+        group(fused_image{}, unchecked_t{}, ta, ra, g * UNROLL);
         __builtin_amdgcn_sched_barrier(0);
         if (g + 2 >= gfull) {
-          evaluate(fused_image{}, unchecked_t{}, cb, tb, rb, (g + 1) * UNROLL);
+          group(fused_image{}, unchecked_t{}, tb, rb, (g + 1) * UNROLL);
           g += 2;
           break;
         }
-        ca = issue(unchecked_t{}, word, ra, ta);
+        issue(unchecked_t{}, word, ra, ta);
         __builtin_amdgcn_sched_barrier(0);
         word = list_word(g + 3);
         __builtin_amdgcn_sched_barrier(0);
-        evaluate(fused_image{}, unchecked_t{}, cb, tb, rb, (g + 1) * UNROLL);
+        group(fused_image{}, unchecked_t{}, tb, rb, (g + 1) * UNROLL);
         __builtin_amdgcn_sched_barrier(0);
         g += 2;
       }

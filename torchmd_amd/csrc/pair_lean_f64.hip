@@ -95,16 +95,12 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 2) void list_pair_lean_f64_kernel(
   double e_lj = 0.0, e_el = 0.0;
 
   auto body = [&](auto image, unsigned tofs, const v4u &lo, const v4u &hi, bool valid) {  // one list entry
-    constexpr bool PLAIN = std::is_same<decltype(image), plain_image>::value;  // kEntryImageFlag clear in the whole group
-    constexpr bool EXACT = std::is_same<decltype(image), exact_image>::value;
+    constexpr bool EXACT = decltype(image)::value;
     const double pjx = __hiloint2double((int)lo.y, (int)lo.x), pjy = __hiloint2double((int)lo.w, (int)lo.z);
     const double pjz = __hiloint2double((int)hi.y, (int)hi.x), pjw = __hiloint2double((int)hi.w, (int)hi.z);
-    double dx = pi.x - pjx, dy = pi.y - pjy, dz = pi.z - pjz;
-    if constexpr (!PLAIN) {  // (PLAIN: round(d / box) is 0 on every axis and d - box * 0 is d)
-      dx = min_image_magic<EXACT>(dx, bx, ibx);
-      dy = min_image_magic<EXACT>(dy, by, iby);
-      dz = min_image_magic<EXACT>(dz, bz, ibz);
-    }
+    const double dx = min_image_magic<EXACT>(pi.x - pjx, bx, ibx);
+    const double dy = min_image_magic<EXACT>(pi.y - pjy, by, iby);
+    const double dz = min_image_magic<EXACT>(pi.z - pjz, bz, ibz);
     const double r2 = norm2(dx, dy, dz);
     const bool hit = valid && (r2 <= r2max);
     // 1/r: v_rsq_f64 (~2^-26 relative) + two Newton steps; rejected entries may produce inf/NaN, discarded below
@@ -151,13 +147,6 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 2) void list_pair_lean_f64_kernel(
   };
 
   static_assert(UNROLL == 4, "one dwordx4 of list per lane and group");
-  // does any entry of the wave's group carry kEntryImageFlag (wave-uniform)?  Only then is the minimum-image arithmetic
-  // made (kLmImageAlways — TMDHIP_IMAGE_FLAGS=0 — : always)
-  const bool image_always = lmode & kLmImageAlways;
-  auto crosses_edge = [&](const v4u &w) {
-    const unsigned fl = (w.x | w.y | w.z | w.w) & kEntryImageFlag;
-    return image_always || __builtin_amdgcn_uicmp(fl, 0u, 33 /* ne */) != 0ull;
-  };
   // index words are fetched two groups (8 entries per lane, 2 KB per wave) ahead of their use
   v4u nxa = row4[0], nxb = row4[64];  // rows are padded: always readable
   int kk0 = 0;
@@ -174,13 +163,8 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 2) void list_pair_lean_f64_kernel(
         lo[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
         hi[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off + 16u, 0, 0);
       }
-      if (crosses_edge(cur)) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) body(image, (entry[u] >> 23) & 0x1F0u, lo[u], hi[u], kk0 + u < myiters);  // padding words are garbage
-      } else {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) body(plain_image{}, (entry[u] >> 23) & 0x1F0u, lo[u], hi[u], kk0 + u < myiters);
-      }
+      for (int u = 0; u < UNROLL; ++u) body(image, (entry[u] >> 23) & 0x1F0u, lo[u], hi[u], kk0 + u < myiters);  // padding words are garbage
     }
   };
   if (extent_needs_exact_image(ext, c.box)) {  // wave-uniform, rare: atoms more than 2.4 box edges apart
@@ -198,13 +182,8 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 2) void list_pair_lean_f64_kernel(
         lo[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
         hi[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off + 16u, 0, 0);
       }
-      if (crosses_edge(cur)) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) body(fused_image{}, (entry[u] >> 23) & 0x1F0u, lo[u], hi[u], true);
-      } else {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) body(plain_image{}, (entry[u] >> 23) & 0x1F0u, lo[u], hi[u], true);
-      }
+      for (int u = 0; u < UNROLL; ++u) body(fused_image{}, (entry[u] >> 23) & 0x1F0u, lo[u], hi[u], true);
     }
     checked_loop(fused_image{});  // tail
   }
