@@ -29,9 +29,9 @@ def test_capi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.tmdhip_abi_version() == _lib.ABI_VERSION
     # struct layouts agree with the C compiler's view of the header
-    src = ('#include "tmdhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", '
+    src = ('#include "tmdhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %d\\n", '
            "sizeof(tmdhip_nonbonded_desc), sizeof(tmdhip_bonded_desc), sizeof(tmdhip_stats), sizeof(tmdhip_md_desc), "
-           "sizeof(tmdhip_dd_desc), sizeof(tmdhip_dd_brick));return 0;}")
+           "sizeof(tmdhip_dd_desc), sizeof(tmdhip_dd_brick), TMDHIP_DD_OVERRUN);return 0;}")
     exe = os.path.join(ROOT, "tests", ".sizeof_probe")
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     try:
@@ -39,7 +39,7 @@ def test_capi_exports_every_declared_symbol():
     finally:
         os.remove(exe)
     assert sizes == [C.sizeof(_lib.NonbondedDesc), C.sizeof(_lib.BondedDesc), C.sizeof(_lib.Stats),
-                     C.sizeof(_lib.MdDesc), C.sizeof(_lib.DdDesc), C.sizeof(_lib.DdBrick)]
+                     C.sizeof(_lib.MdDesc), C.sizeof(_lib.DdDesc), C.sizeof(_lib.DdBrick), _lib.DD_OVERRUN]
 
 
 def test_capi_argument_validation_without_gpu():

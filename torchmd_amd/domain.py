@@ -901,11 +901,12 @@ class DomainSet:
         """The neighbour lists of the batch that just ended, on every rank (a verdict all ranks share)."""
         from . import _lib as L
 
-        bad = {}
-        for r, d in self.domains.items():
-            ok = d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos)
-            bad[r] = torch.tensor([0.0 if ok else 1.0], device=self.device)
-        if self._any(bad):
+        bad = False
+        for d in self.domains.values():
+            bad = bad or not d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos)
+        if not self.local:  # (every rank must take the same way: the verdict is the OR over the ranks)
+            bad = self.transport.any_true(torch.tensor([1.0 if bad else 0.0], device=self.device))
+        if bad:
             raise ListInvalid(f"a neighbour list of a brick became invalid during the batch ({L.last_error()}): "
                               "repeat the batch")
 
