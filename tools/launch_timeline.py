@@ -18,7 +18,7 @@ def main(path):
     for name, start, end in rows:
         if "build_list_kernel" in name and end - start > 50_000:  # a real build (early exits take a few us)
             age = 0
-        elif "list_pair_fast_f32_kernel" in name and ", 2>" in name.split("(")[0] + ">" or ("list_pair_fast_f32_kernel" in name and "false, 2>" in name):
+        elif "list_pair_fast_f32_kernel" in name and name.split("(")[0].rstrip().endswith((", 1>", ", 2>")):  # FUSED = 1 / 2
             if age is not None:
                 by_age.setdefault(min(age, 12), []).append((end - start) / 1e3)
                 age += 1
