@@ -660,3 +660,38 @@ def test_bench_cpu_baseline_c5_sample_and_pmc_provenance():
     traffic, src, commit, valu = bench.pmc_traffic()
     assert traffic and traffic > 5e7 and src.startswith("profiles/") and commit and valu and valu > 1e6
     assert bench.timing_stride(20) == 1 and bench.timing_stride(2000) == 16
+
+
+def test_launch_timeline_tool_on_a_synthetic_trace(tmp_path):
+    """tools/launch_timeline.py groups the fused pair + step launches of a kernel trace by the number of launches since the
+    last real list build (early-exit builds of a few microseconds do not count)."""
+    import sqlite3
+
+    db = tmp_path / "trace_results.db"
+    con = sqlite3.connect(db)
+    con.execute("create table kernels (name text, start integer, end integer)")
+    fused = "void tmd::list_pair_fast_f32_kernel<8, true, true, false, false, 2>(int, HIP_vector_type<float, 4u> const*)"
+    energy = "void tmd::list_pair_fast_f32_kernel<8, true, true, true, false, 0>(int, HIP_vector_type<float, 4u> const*)"
+    build = "void tmd::build_list_kernel<float, false, true>(int, tmd::Vec<float>::T4 const*)"
+    t, rows = 0, []
+
+    def add(name, dur):
+        nonlocal t
+        rows.append((name, t, t + dur))
+        t += dur + 100
+
+    for _ in range(3):
+        add(build, 160_000)
+        add(fused, 50_000)
+        for _ in range(4):
+            add(build, 3_000)  # early exit
+            add(fused, 44_000)
+    add(energy, 52_000)
+    con.executemany("insert into kernels values (?, ?, ?)", rows)
+    con.commit()
+    con.close()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "launch_timeline.py"), str(db)], capture_output=True,
+                         text=True, check=True).stdout
+    lines = {int(ln.split()[0].rstrip("+")): ln.split() for ln in out.splitlines() if ln.startswith("   ") or ln.startswith("  1")}
+    assert float(lines[0][1]) == 50.0 and int(lines[0][4]) == 3
+    assert float(lines[1][1]) == 44.0 and int(lines[4][4]) == 3 and 5 not in lines
