@@ -514,8 +514,6 @@ def main():
             "skin": st2["skin"],
             "skin_weights": args.skin_weights,
             "rebuild_chains_left_out": int(st1["chains_skipped"] - st0["chains_skipped"]),
-            "lookahead_builds": int(st1["lookahead_builds"] - st0["lookahead_builds"]),
-            "lookahead_adopted": int(st1["lookahead_adopted"] - st0["lookahead_adopted"]),
             "capacity_per_atom": int(st2["max_neighbours"]),
             "ncell": list(st2["ncell"]),
         },

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TMDHIP_ABI_VERSION 6
+#define TMDHIP_ABI_VERSION 7
 
 /* dtype */
 #define TMDHIP_F32 0
@@ -137,8 +137,6 @@ typedef struct tmdhip_stats {
   int64_t chains_skipped;   /* MD steps whose rebuild chain the host left out (tmdhip_md_run)  */
   int64_t steps_in_pair_launch; /* MD steps made by step blocks of the pair launch instead of an integrator launch (ABI 4) */
   int64_t fused_step_timeouts;  /* batches rewound because a step block of a fused launch gave up waiting (ABI 5; whole context) */
-  int64_t lookahead_builds;     /* neighbour lists built ahead of their use on the second stream (tmdhip_md_run, ABI 5) */
-  int64_t lookahead_adopted;    /* ... of which adopted at a launch boundary (the rest were dropped)                    */
 } tmdhip_stats;
 
 int tmdhip_abi_version(void);

@@ -439,7 +439,8 @@ def test_list_overflow_is_replayed_not_raised(monkeypatch, skin_weights):
     out_t, cap_t, st_t, ferr_t = run(True)
     assert cap_t < cap_ref and st_t["max_neighbours"] > cap_t, (cap_t, cap_ref, st_t)  # the tight run had to grow its lists
     assert st_t["overflow"] == 0 and st_ref["overflow"] == 0
-    assert ferr_t < 2e-3 and ferr_ref < 2e-3
+    print(f"list overflow replay: max|dF| vs a fresh evaluation {ferr_t:.3e} (tight lists) / {ferr_ref:.3e}")
+    assert ferr_t < 6e-4 and ferr_ref < 6e-4  # (fp32, hot lattice start: FTOL_HOT of test_gpu_parity.py)
     assert abs(out_t[2][0] - out_ref[2][0]) < 15.0  # temperature (K)
     assert abs(out_t[1][0] - out_ref[1][0]) < 0.01 * abs(out_ref[1][0])  # potential energy
 
@@ -495,7 +496,8 @@ def test_rebuild_chain_left_out_and_violation_rewound(monkeypatch):
     assert st0["n_rebuilds"] > 5 and st1["n_rebuilds"] > 5
     for st in (st0, st1, st2):
         assert st["overflow"] == 0
-    assert ferr0 < 2e-3 and ferr1 < 2e-3 and ferr2 < 2e-3
+    print(f"chain skipping: max|dF| vs a fresh evaluation {ferr0:.3e} / {ferr1:.3e} / {ferr2:.3e}")
+    assert ferr0 < 6e-4 and ferr1 < 6e-4 and ferr2 < 6e-4  # (fp32, hot lattice start)
     # regular skipping changes nothing but the launches that would have returned at once: same trajectory
     assert out1[1][0] == out0[1][0] and out1[2][0] == out0[2][0]
     # the rewound run rebuilt its lists at other steps: same physics, different rounding
@@ -544,15 +546,11 @@ def test_rebuild_chain_left_out_with_two_list_replicas(monkeypatch):
     assert (p0[0] - p0[1]).abs().max().item() > 1e-3
 
 
-@pytest.mark.parametrize("lookahead", [False, True])
-def test_aged_lists_hold_every_pair_inside_the_cutoff(lookahead, monkeypatch):
+def test_aged_lists_hold_every_pair_inside_the_cutoff(monkeypatch):
     """Exactness of the skin policy over a trajectory: per-atom skins by mass, skins sized from the velocities at
     every rebuild and rebuild chains left out.  After every few MD steps the number of pairs inside the cutoff
     found through the CURRENT list (aged by several steps, no rebuild forced) must equal the oracle's count at
-    those positions — a pair missing from a list would show — and the forces must be those of a fresh evaluation.
-    `lookahead`: with the next list built ahead of its use on the second stream from a snapshot of the positions and
-    adopted four steps later (opt-in: TMDHIP_LOOKAHEAD, size gate opened for this box): a list in use is then four
-    steps older than its first use suggests, and the test that guards it is the adoption kernel's."""
+    those positions — a pair missing from a list would show — and the forces must be those of a fresh evaluation."""
     from oracle import torchmd_oracle as orc
     from torchmd_amd.builders import tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
@@ -568,11 +566,6 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(lookahead, monkeypatch):
     monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
     monkeypatch.setenv("TMDHIP_CHAIN_SKIP", "1")
     monkeypatch.delenv("TMDHIP_VSKIN", raising=False)
-    if lookahead:
-        monkeypatch.setenv("TMDHIP_DEBUG_LOOKAHEAD_MIN_ENTRIES", "1")
-        monkeypatch.setenv("TMDHIP_LOOKAHEAD", "0.55,4")
-    else:
-        monkeypatch.delenv("TMDHIP_LOOKAHEAD", raising=False)
     s = System(mol.numAtoms, 1, dt, dev)
     s.set_positions(pos[:, :, None])
     s.set_box(box)
@@ -584,6 +577,7 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(lookahead, monkeypatch):
     integ.step(150)  # melt the lattice start
     excl = orc.exclusion_pairs(par)
     aged = 0
+    worst = 0.0
     for k in range(12):
         r0 = f.stats(s.pos)["n_rebuilds"]
         integ.step(4)
@@ -595,72 +589,15 @@ def test_aged_lists_hold_every_pair_inside_the_cutoff(lookahead, monkeypatch):
         assert n_gpu == npairs[0], (k, n_gpu, npairs)
         # forces of the MD run's last step (aged list, lean kernel + inline/separate bonded kernels) vs the oracle
         err = (s.forces.cpu() - Fo).abs().max().item()
-        assert err < 2e-3, (k, err)
+        worst = max(worst, err)
+        assert err < 6e-4, (k, err)  # (fp32, a melted lattice start: FTOL_HOT of test_gpu_parity.py)
     st = f.stats(s.pos)
-    assert (aged >= 3 or lookahead) and st["chains_skipped"] > 20 and st["overflow"] == 0  # (look-ahead: a build every ~5 steps)
-    print(f"lookahead {lookahead}: rebuilds {st['n_rebuilds']}, look-ahead builds {st['lookahead_builds']} (adopted "
-          f"{st['lookahead_adopted']}), chains skipped {st['chains_skipped']}")
-    if lookahead:
-        assert st["lookahead_adopted"] >= 8 and st["lookahead_builds"] - st["lookahead_adopted"] <= 1, st
-    else:
-        assert st["lookahead_builds"] == 0
+    assert aged >= 3 and st["chains_skipped"] > 20 and st["overflow"] == 0
+    print(f"rebuilds {st['n_rebuilds']}, chains skipped {st['chains_skipped']}, worst max|dF| vs the oracle {worst:.3e}")
     fresh = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist", skin_weights=None)
     F2 = torch.zeros_like(s.pos)
     fresh.compute(s.pos, s.box, F2)
     assert (F2 - s.forces).abs().max().item() < 2e-3
-
-
-@pytest.mark.gpu
-def test_lookahead_lists_are_deterministic_and_equal_with_and_without_the_fused_step(monkeypatch):
-    """Look-ahead list builds (opt-in; second stream, adopted a fixed number of steps after their snapshot): which step starts
-    and which adopts a list follows from device-side reports the paced host reads with a fixed lag — not from timing —
-    so a run is reproducible bit for bit, and the fused launch (step blocks) and the separate integrator kernel take
-    the same decisions: identical trajectories, with rebuild counts that show the look-ahead lists were used."""
-    from torchmd_amd.builders import tip3p_box, water_forcefield
-    from torchmd_amd.forces import Forces
-    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
-    from torchmd_amd.parameters import Parameters
-    from torchmd_amd.systems import System
-
-    dev, dt = _dev(), torch.float32
-    mol, pos, box = tip3p_box(14, seed=4)  # 8 232 atoms
-    terms = ["lj", "electrostatics", "bonds", "angles"]
-    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
-    monkeypatch.setenv("TMDHIP_LPA", "8")
-    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
-    monkeypatch.setenv("TMDHIP_DEBUG_LOOKAHEAD_MIN_ENTRIES", "1")
-    monkeypatch.setenv("TMDHIP_LOOKAHEAD", "0.55,4")
-    torch.manual_seed(3)
-    vel0 = maxwell_boltzmann(par.masses, 300.0, 1)
-
-    def run(fused):
-        monkeypatch.setenv("TMDHIP_FUSED_STEP", "1" if fused else "0")
-        s = System(mol.numAtoms, 1, dt, dev)
-        s.set_positions(pos[:, :, None])
-        s.set_box(box)
-        s.set_velocities(vel0)
-        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
-        f.compute(s.pos, s.box, s.forces)
-        torch.manual_seed(9)
-        integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
-        res = [integ.step(50), integ.step(7), integ.step(43)]
-        return s.pos.cpu(), s.vel.cpu(), s.forces.cpu(), res, f.stats(s.pos)
-
-    a = run(True)
-    b = run(True)
-    c = run(False)
-    for other in (b, c):
-        assert torch.equal(a[0], other[0]) and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
-        for x, y in zip(a[3], other[3]):
-            for u, v in zip(x, y):
-                assert np.array_equal(np.asarray(u), np.asarray(v))
-    st = a[4]
-    assert st["lookahead_adopted"] >= 5 and st["overflow"] == 0 and st["fused_step_timeouts"] == 0, st
-    assert a[4]["lookahead_adopted"] == c[4]["lookahead_adopted"] and a[4]["n_rebuilds"] == c[4]["n_rebuilds"]
-    # (97 interior steps; more if a batch was rewound — the unrelaxed lattice start is hot enough for an adoption test to fail — which
-    # must then have happened in every run alike)
-    assert a[4]["steps_in_pair_launch"] >= 97 and a[4]["steps_in_pair_launch"] == b[4]["steps_in_pair_launch"]
-    assert c[4]["steps_in_pair_launch"] == 0
 
 
 @pytest.mark.gpu
@@ -726,8 +663,7 @@ def test_fused_launch_timeout_falls_back_to_the_integrator_kernel(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["water_langevin", "water_nve", "water_two_replicas", "lj_langevin", "water_counter_wraps",
-                                  "water_32_lanes", "water_64_lanes", "thrombin",
-                                  "water_langevin@f64", "water_nve@f64", "lj_langevin@f64", "water_counter_wraps@f64", "thrombin@f64"])
+                                  "water_32_lanes", "water_64_lanes", "thrombin"])
 def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     """Interior steps of tmdhip_md_run on the lean fp32 pair kernel are made by the pair launch itself ("step blocks"
     behind the pair blocks wait for the pair waves of their atoms: FusedStep in csrc/engine.h, pair_fast_f32.hip) instead of by an
@@ -738,17 +674,16 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     `water_counter_wraps`: the launch number the force records carry starts at 2^32 - 20 and wraps during the run
     (0 is skipped: it means "never written").  `thrombin`: a protein (4 676 atoms, all seven terms, open boundaries) —
     a heavy topology, whose bonded force is evaluated by bonded_wave_kernel in front of the pair launch into a buffer
-    that the step blocks add.  `@f64`: the same through the lean fp64 kernel."""
+    that the step blocks add.  (fp64 contexts keep the separate integrator kernel: their step blocks were measured
+    slower in round 4 and removed in round 5.)"""
     from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import Integrator, maxwell_boltzmann
     from torchmd_amd.parameters import Parameters
     from torchmd_amd.systems import System
 
-    case, _, prec = case.partition("@")  # "@f64": the lean fp64 kernel's step blocks (32-byte force records, round 4)
-    dev, dt = _dev(), (torch.float64 if prec == "f64" else torch.float32)
+    dev, dt = _dev(), torch.float32
     monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
-    monkeypatch.setenv("TMDHIP_FUSED_STEP_F64", "1")  # (fp64 step blocks are opt-in: correct, but slower than the separate kernel)
     if case == "water_counter_wraps":
         monkeypatch.setenv("TMDHIP_DEBUG_FUSED_GEN0", str(2**32 - 20))
     nrep = 2 if case == "water_two_replicas" else 1
@@ -801,10 +736,7 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
     assert torch.equal(p1, p0) and torch.equal(v1, v0) and torch.equal(f1, f0)
     for a, b in zip(r1, r0):
         for x, y in zip(a, b):
-            if prec == "f64":  # (energies are folded with atomics: sums of fp64 terms depend on their order in the last bits)
-                assert np.allclose(np.asarray(x), np.asarray(y), rtol=1e-12, atol=0)
-            else:
-                assert np.array_equal(np.asarray(x), np.asarray(y))
+            assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
 @pytest.mark.gpu

@@ -14,7 +14,14 @@ from _golden import GoldenParameters, PREC, box_tensor, energies, load, pos_tens
 
 pytestmark = pytest.mark.gpu
 
-FTOL = {"f64": 1e-8, "f32": 2e-3}  # north-star bars: 1e-4 / 1e-2
+# North-star bars: 1e-4 (fp64) / 1e-2 (fp32), and "forces within 1e-4" in its target sentence for the 100k-atom box.
+# Asserted: fp64 1e-8; fp32 3e-4 — observed on MI355X (round 5, gpurun_out/r05_a/tests_rP.log): alanine dipeptide 6.7e-5,
+# 5 184-atom water 5.6e-5, the 98 304-atom box 7.1e-5 (6.1e-5 with unwrapped coordinates): partial forces of up to a few
+# hundred kcal/mol/A summed in list order in fp32, against the reference's pair order.
+FTOL = {"f64": 1e-8, "f32": 3e-4}
+# ... except on states with close contacts (an unrelaxed lattice start after tens of MD steps: |F| of several hundred,
+# observed 2.0e-4 at 98 304 atoms): 6e-4
+FTOL_HOT = {"f64": 1e-8, "f32": 6e-4}
 ERTOL = {"f64": 1e-10, "f32": 2e-5}
 EFAC = 3  # energies: relative tolerance ERTOL * EFAC (fp32: 6e-5; observed <= 2e-5)
 ALL_TERMS = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
@@ -257,7 +264,7 @@ def test_water_box_celllist_vs_oracle(prec):
     assert f.count_pairs(ps.to(dev), b) == ns
 
 
-@pytest.mark.parametrize("case", ["water12-f32", "water12-f64", "c3-f32"])
+@pytest.mark.parametrize("case", ["water12-f32", "water12-f64", "c3-f32", "c3-f64"])
 @pytest.mark.parametrize("reach", [1, 3])
 def test_image_offsets_vs_oracle(case, reach):
     """Unwrapped coordinates (the reference's System/Integrator never wrap: integrator.py:61-64): every atom is
@@ -383,10 +390,12 @@ def test_lj_box_vs_oracle(prec):
     assert f.count_pairs(p.to(dev), box_tensor(box, 1, dt, dev)) == npairs
 
 
-def test_c3_full_size_vs_oracle():
-    """Config C3 at full size (98 304 atoms, fp32), all four terms of the bench (lj, electrostatics, bonds,
-    angles): HIP cell-list path vs the oracle with a sparse candidate list; bar: max |dF| <= 2e-3 kcal/mol/A
-    (north star 1e-2), identical in-cutoff pair count, sum(F) ~ 0, energies within EFAC x 2e-5 relative.
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_c3_full_size_vs_oracle(prec):
+    """Config C3 at full size (98 304 atoms; fp32 = the bench's precision, fp64 = the lean fp64 kernel), all four terms
+    of the bench (lj, electrostatics, bonds, angles): HIP cell-list path vs the oracle with a sparse candidate list;
+    bar: max |dF| <= 3e-4 kcal/mol/A in fp32 (north star 1e-2; its target sentence 1e-4; observed 7e-5), <= 1e-8 in
+    fp64 (north star 1e-4), identical in-cutoff pair count, sum(F) ~ 0, energies within EFAC x 2e-5 (1e-10) relative.
     Second leg: the state the bench times — ~60 Langevin steps through Integrator with the default gates (per-atom
     and velocity-dependent skins, rebuild chains left out by the pacing host: asserted active) — then the AGED
     list's in-cutoff pair count and the run's forces against the oracle at the final positions."""
@@ -397,29 +406,29 @@ def test_c3_full_size_vs_oracle():
     from torchmd_amd.parameters import Parameters
     from torchmd_amd.systems import System
 
-    dev = _dev()
+    dev, dt = _dev(), PREC[prec]
     mol, pos, box = tip3p_box(32, seed=0)
     nb = ["lj", "electrostatics"]
     terms = nb + ["bonds", "angles"]
-    par = Parameters(water_forcefield(mol), mol, terms, precision=torch.float32)
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
     excl = orc.exclusion_pairs(par)
-    s = System(mol.numAtoms, 1, torch.float32, dev)
+    s = System(mol.numAtoms, 1, dt, dev)
     s.set_positions(pos[:, :, None])
     s.set_box(box)
     f = Forces(par, terms=terms, cutoff=9.0, rfa=True)
     pots = f.compute(s.pos, s.box, s.forces, returnDetails=True)
     n_gpu = f.count_pairs(s.pos, s.box)
     assert f.stats(s.pos)["algorithm"] == "celllist"
-    assert s.forces.sum(dim=1).abs().max().item() < 0.5  # Newton's third law (fp32 sum over 98k atoms)
+    assert s.forces.sum(dim=1).abs().max().item() < (0.5 if prec == "f32" else 1e-8)  # Newton's third law (sum over 98k atoms)
     p = s.pos.detach().cpu()
     pairs = orc.candidate_pairs(p[0].double().numpy(), box, 9.5, excl)
     po, Fo, npairs = orc.compute(par, p, s.box.cpu(), terms, pairs=pairs, cutoff=9.0, rfa=True)
     err = (s.forces.cpu() - Fo).abs().max().item()
-    print(f"C3 full size: P_cut = {npairs[0]}, max|dF| = {err:.3e}, " + ", ".join(f"E_{t} = {pots[0][t]:.2f}" for t in terms))
+    print(f"C3 full size {prec}: P_cut = {npairs[0]}, max|dF| = {err:.3e}, " + ", ".join(f"E_{t} = {pots[0][t]:.2f}" for t in terms))
     assert n_gpu == npairs
-    assert err < FTOL["f32"]
+    assert err < FTOL[prec]
     for t in terms:
-        assert abs(pots[0][t] - po[0][t]) <= ERTOL["f32"] * EFAC * max(1.0, abs(po[0][t])), (t, pots[0][t], po[0][t])
+        assert abs(pots[0][t] - po[0][t]) <= ERTOL[prec] * EFAC * max(1.0, abs(po[0][t])), (t, pots[0][t], po[0][t])
 
     # ---- the bench state: an MD run with every default gate, then the aged list against the oracle
     torch.manual_seed(1)
@@ -437,10 +446,10 @@ def test_c3_full_size_vs_oracle():
     pairs = orc.candidate_pairs(p[0].double().numpy(), box, 9.3, excl)
     _, Fo, npairs = orc.compute(par, p, s.box.cpu(), terms, pairs=pairs, cutoff=9.0, rfa=True)
     err = (s.forces.cpu() - Fo).abs().max().item()
-    print(f"C3 after 61 MD steps: P_cut = {npairs[0]}, GPU count {n_gpu[0]} (list aged: {aged}), max|dF| = {err:.3e}, "
+    print(f"C3 {prec} after 61 MD steps: P_cut = {npairs[0]}, GPU count {n_gpu[0]} (list aged: {aged}), max|dF| = {err:.3e}, "
           f"chains skipped {st['chains_skipped']}, rebuilds {st['n_rebuilds']}")
     assert n_gpu == npairs
-    assert err < FTOL["f32"]
+    assert err < FTOL_HOT[prec]  # (the lattice start after 61 steps: see FTOL_HOT)
 
 
 def test_lj_million_atoms_properties():
@@ -957,6 +966,8 @@ def test_thrombin_fp32_open_boundaries_lean_kernel():
     _, F_a, fa, _, _ = _run(par, g["pos"], zero, terms, prec="f32", algorithm="allpairs", **kw)
     Fn = torch.zeros_like(p)
     fc._evaluate(p, b, Fn, False, True)  # forces only -> lean fp32 kernel
+    print(f"thrombin fp32: cell list vs all pairs {np.abs(F_c - F_a).max():.3e}, lean kernel vs all pairs "
+          f"{np.abs(Fn.cpu().numpy() - F_a).max():.3e} (max|F| {np.abs(F_a).max():.1f})")
     assert np.abs(F_c - F_a).max() < 2e-3 and np.abs(Fn.cpu().numpy() - F_a).max() < 2e-3
     assert fc.count_pairs(p, b) == fa.count_pairs(p, b)
 

@@ -173,7 +173,6 @@ template <typename R>
 int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   using R4 = typename Vec<R>::T4;
   const int n = ctx->d.natoms;
-  TMD_TRY(drop_lookahead(ctx, rp, true));  // (the list geometry changes: a shadow list in flight is of the old one)
   TMD_TRY(rp.cell_of.ensure(sizeof(int) * n));
   TMD_TRY(rp.slot.ensure(sizeof(int) * n));
   TMD_TRY(rp.order_tmp.ensure(sizeof(int) * n));
@@ -222,7 +221,6 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
   int force = 0;
   if (!rp.have_list || box_changed) {
     // (re)plan the grid — host-synchronising path, taken on the first call and when the box changes
-    TMD_TRY(drop_lookahead(ctx, rp, true));  // a shadow list in flight belongs to the old plan
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     const bool periodic = !(box[0] == 0 && box[1] == 0 && box[2] == 0);
     double volume;
@@ -518,8 +516,6 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
   for (auto &rp : ctx->rep) {
     if (rp.flags.ensure(sizeof(int) * F_COUNT)) return cleanup(-1);
     (void)hipMemset(rp.flags.p, 0, sizeof(int) * F_COUNT);
-    const int one = 1;
-    (void)hipMemcpy(rp.flags.as<int>() + F_ALWAYS, &one, sizeof(int), hipMemcpyHostToDevice);
     if (rp.paircount.ensure(sizeof(unsigned long long))) return cleanup(-1);
     (void)hipMemset(rp.paircount.p, 0, sizeof(unsigned long long));
     if (rp.extent.ensure(sizeof(kExtentEmpty))) return cleanup(-1);
@@ -538,11 +534,6 @@ int tmdhip_create(tmdhip_ctx **out, const tmdhip_nonbonded_desc *desc) {
 
 void tmdhip_destroy(tmdhip_ctx *ctx) {
   if (!ctx) return;
-  if (ctx->la_stream) {
-    (void)hipStreamSynchronize(ctx->la_stream);
-    (void)hipStreamDestroy(ctx->la_stream);
-    ctx->la_stream = nullptr;
-  }
   for (auto &rp : ctx->rep) {
     if (rp.hostpub) (void)hipHostFree(rp.hostpub);
     rp.hostpub = nullptr;
@@ -718,8 +709,6 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   out->chains_skipped = rp.chains_skipped;
   out->steps_in_pair_launch = rp.steps_in_pair_launch;
   out->fused_step_timeouts = ctx->fused_step_timeouts;
-  out->lookahead_builds = rp.lookahead_builds;
-  out->lookahead_adopted = rp.lookahead_adopted;
   out->pairs_in_cutoff = (int64_t)pc;
   out->algorithm = ctx->algorithm;
   out->max_neighbours = rp.lg.maxn;

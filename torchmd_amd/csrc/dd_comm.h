@@ -95,6 +95,13 @@ struct tmdhip_local_hub {
     }
     return !broken;
   }
+  // a rank that leaves a hub-backed call early (an error return, a count mismatch) calls this instead of never arriving:
+  // the others wake up at once with "broken" rather than after the 30-s time-out
+  void abort() {
+    std::lock_guard<std::mutex> lk(m);
+    broken = true;
+    cv.notify_all();
+  }
 };
 
 // halo-exchange communicator of one rank + the state of the asynchronous migration trigger

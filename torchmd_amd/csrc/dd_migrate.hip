@@ -589,7 +589,12 @@ int tmdhip_dd_migrate(tmdhip_ctx *ctx, tmdhip_comm *comm, tmdhip_dd_brick *b, vo
     return fail("tmdhip_dd_migrate: null pointer");
   if (b->nown < 0 || b->nown > b->cap_own || b->cap_own > b->cap_rows) return fail("tmdhip_dd_migrate: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  return b->dtype == TMDHIP_F32 ? migrate<float>(ctx, comm, b, st) : migrate<double>(ctx, comm, b, st);
+  const int rc = b->dtype == TMDHIP_F32 ? migrate<float>(ctx, comm, b, st) : migrate<double>(ctx, comm, b, st);
+  // only a return of 2 (capacity too small: grow and call again) is resumable; after an error the next call starts from
+  // the beginning on every rank instead of resuming mid-way on stale scratch while the other ranks start at stage 0
+  if (rc < 0) comm->mig_stage = 0;
+  if (rc < 0 && comm->hub) comm->hub->abort();  // (in-process transport: the other ranks must not wait 30 s for this one)
+  return rc;
 }
 
 }  // extern "C"

@@ -726,10 +726,11 @@ int tmdhip_dd_reset(tmdhip_comm *c) {
   c->pending = false;
   c->at = 0;
   c->csr_index = nullptr;  // the send list changes with the migration
+  c->mig_stage = 0;        // (a native migration that stopped half-way does not resume after a reset)
   return 0;
 }
 
-int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int32_t *iters_done, void *stream) {
+static int dd_run_body(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int32_t *iters_done, void *stream) {
   if (!ctx || !c || !d || !iters_done) return fail("tmdhip_dd_run: null argument");
   if (d->struct_size != (int32_t)sizeof(tmdhip_dd_desc)) return fail("tmdhip_dd_run: struct_size mismatch");
   if (d->dtype != TMDHIP_F32 && d->dtype != TMDHIP_F64) return fail("tmdhip_dd_run: bad dtype");
@@ -864,6 +865,14 @@ int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int3
     TMD_TRY(kick_drift(1, last > 0 ? last - 1 : 0));
   }
   return 0;
+}
+
+int tmdhip_dd_run(tmdhip_ctx *ctx, tmdhip_comm *c, const tmdhip_dd_desc *d, int32_t *iters_done, void *stream) {
+  const int rc = dd_run_body(ctx, c, d, iters_done, stream);
+  // in-process transport: a rank that fails leaves the others waiting at the hub's next rendezvous — wake them up now
+  // (their calls fail with "broken hub") instead of after the barrier's 30-s time-out
+  if (rc < 0 && c && c->hub) c->hub->abort();
+  return rc;
 }
 
 int tmdhip_dd_step(int dtype, int64_t nown, void *pos, void *vel, const void *forces, const void *mass,

@@ -90,10 +90,10 @@ __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
 //                 ListCheck::skipped): the forces since then are invalid, the caller rewinds and repeats
 //   F_STEP_TIMEOUT  a step block of a fused pair launch gave up waiting for a force record (pair_fast_f32.hip): its
 //                 atoms were NOT integrated; the caller rewinds and repeats the batch with the separate integrator kernel
-//   F_ALWAYS      constant 1: the "flag" of a chain that is to run unconditionally (look-ahead builds)
+//   F_RESERVED    unused (was the always-on flag of the look-ahead builds removed in round 5)
 //   F_CELLCAP     a cell received more atoms than the member array of the two-launch binning holds (kCellCap): the list of
 //                 this build is incomplete; the caller switches the replica to the four-launch binning and repeats
-enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_STEP_TIMEOUT = 5, F_ALWAYS = 6, F_CELLCAP = 7,
+enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_STEP_TIMEOUT = 5, F_RESERVED = 6, F_CELLCAP = 7,
        F_COUNT = 8 };
 constexpr int kCellCap = 64;             // members per cell of the two-launch binning
 constexpr int kScanPlaceMaxCells = 12288;  // cells whose prefix a block of scan_place_kernel can hold in LDS (48 KB)
@@ -118,8 +118,6 @@ struct ListCheck {
   unsigned *near_host;  // null: no reporting
   unsigned seq;
   R near_frac2;
-  R near2_frac2;  // > 0: atoms beyond this (smaller) fraction of their limit store `seq` into near_host[4] — the signal
-                  // that starts a look-ahead list build (Replica::shadow); 0: no such report
   int skipped;
   int *ext;  // coordinate extent of everything ever stored into sorted_xyzq (see extent_note)
 };
@@ -178,7 +176,6 @@ __device__ __forceinline__ void list_check_point(const ListCheck<R> &k, const Pa
     if (k.near_host) k.near_host[2] = k.seq;  // "this step rebuilds": its successor needs no chain either
   }
   if (k.near_host && !(d2 <= h2 * k.near_frac2)) *k.near_host = k.seq;  // host-mapped: only the few fast atoms store
-  if (k.near_host && k.near2_frac2 > R(0) && !(d2 <= h2 * k.near2_frac2)) k.near_host[4] = k.seq;
 }
 // squared displacement atom i may reach before the list has to be rebuilt
 template <typename R>
@@ -424,18 +421,6 @@ struct DevBuf {
   }
 };
 
-// the buffers one list build writes: binning scratch, the cell order and its per-slot copies, reference positions and
-// skins of the displacement test, the list itself (the ACTIVE set of a replica lives in the Replica's members of the
-// same names; swapping two DevBufs swaps pointers)
-struct ListBufs {
-  DevBuf cell_of, slot, order_tmp, count, cell_start, order, inv, stype, ref, sorted_hs, hs2_dyn, nlist, nneigh, sorted, padgen, members;
-  void release() {
-    for (DevBuf *b : {&cell_of, &slot, &order_tmp, &count, &cell_start, &order, &inv, &stype, &ref, &sorted_hs, &hs2_dyn, &nlist,
-                      &nneigh, &sorted, &padgen, &members})
-      b->release();
-  }
-};
-
 struct Replica {
   int64_t step = 0;
   int64_t n_compute = 0;
@@ -482,24 +467,10 @@ struct Replica {
   DevBuf flags;  // int[F_COUNT], see the enum
   DevBuf extent;  // int[6]: keys of the coordinate extent of sorted_xyzq (extent_note)
   DevBuf paircount;  // unsigned long long
-  // Look-ahead list build (tmdhip_md_run, md_loop.hip): while the pair launches of the next steps still use the list
-  // above, its successor is built from a snapshot of the positions into this second set of buffers — binning on the
-  // compute stream, the expensive build kernel on a second stream, concurrently with the pair launches, which leave more
-  // than half of the VALU issue slots idle — and adopted `la_steps` steps later at a launch boundary (the buffers swap).
-  // The list's age at adoption is charged to its skin by the displacement test the adoption kernel makes.
-  ListBufs shadow;
-  int la_state = 0;            // 0 idle, 1 a shadow list is being built / waiting for its adoption step
-  int64_t la_start_step = 0;   // `step` when the snapshot was taken
-  hipEvent_t la_binned = nullptr, la_built = nullptr;
-  int64_t lookahead_builds = 0, lookahead_adopted = 0, lookahead_dropped = 0;
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
                       &nlist, &nneigh, &padgen, &members, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond})
       b->release();
-    shadow.release();
-    if (la_binned) (void)hipEventDestroy(la_binned);
-    if (la_built) (void)hipEventDestroy(la_built);
-    la_binned = la_built = nullptr;
   }
 };
 
@@ -528,7 +499,6 @@ struct tmdhip_ctx {
   // out twice stops fusing for good (`fused_disabled`): the hand-over's in-order-dispatch assumption does not hold here.
   bool no_fused_once = false, fused_off_call = false, fused_disabled = false;
   int64_t fused_step_timeouts = 0;
-  hipStream_t la_stream = nullptr;  // second stream of the look-ahead list builds (created on first use)
   // velocity-dependent skins inside tmdhip_md_run (place_sorted_kernel): s_i = min(floor * static_i + time * |v_i|, cap)
   double vskin_floor = 0.8, vskin_time = 0, vskin_cap = 1.2, vskin_cap_len = 0;
   double mean_list_scale = 1;  // mean list length / length of a list at the largest pair radius (per-atom skins)
@@ -610,7 +580,6 @@ ListCheck<R> make_check(const tmdhip_ctx *ctx, Replica &rp) {
   k.near_host = nullptr;
   k.seq = 0;
   k.near_frac2 = R(0);
-  k.near2_frac2 = R(0);
   k.skipped = 0;
   k.flags = rp.flags.as<int>();
   k.parity = (int)(rp.step & 1);
@@ -664,15 +633,6 @@ int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A
 template <typename R>
 int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force, hipStream_t st,
                         bool prechecked = false);
-// look-ahead build (Replica::shadow): snapshot + binning of `pos` on `st`, the build kernel on ctx->la_stream behind it
-template <typename R>
-int enqueue_lookahead_build(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, hipStream_t st);
-// adoption of the finished shadow list at a launch boundary: `st` waits for the build, the current positions are
-// written in the new cell order and tested against the new list's reference positions (F_VIOLATION), the buffers swap
-template <typename R>
-int adopt_lookahead_list(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, hipStream_t st);
-// forget a shadow list that is in flight (host-synchronising re-plans, end of a context); waits for its kernels
-int drop_lookahead(tmdhip_ctx *ctx, Replica &rp, bool wait);
 // pair_generic.hip
 template <typename R>
 int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *forces, double *energies, int flags,
@@ -688,7 +648,7 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
                          hipEvent_t e0, hipEvent_t e1, int lmode, const FusedLaunch *fl);
 template <bool ENERGY>
 int launch_pair_lean_f64(tmdhip_ctx *ctx, Replica &rp, const PairConsts<double> &c, double *f, int overwrite,
-                         hipStream_t st, hipEvent_t e0, hipEvent_t e1, int lmode, const FusedLaunchT<double> *fl);
+                         hipStream_t st, hipEvent_t e0, hipEvent_t e1, int lmode);
 // md_loop.hip
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st);

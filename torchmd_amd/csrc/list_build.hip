@@ -701,25 +701,18 @@ unsigned long long *debug_timeline_buffer(int blocks) {
   return g_dbg_timeline.as<unsigned long long>();
 }
 
-// where a rebuild chain reads and writes: the replica's active buffers or its shadow set (look-ahead build)
+// the buffers a rebuild chain reads and writes (the replica's own)
 struct ListTarget {
   DevBuf *cell_of, *slot, *order_tmp, *count, *cell_start, *order, *inv, *stype, *ref, *sorted_hs, *hs2_dyn, *nlist, *nneigh, *sorted, *members;
 };
-static ListTarget active_target(Replica &rp) {
-  return {&rp.cell_of, &rp.slot, &rp.order_tmp, &rp.count, &rp.cell_start, &rp.order, &rp.inv, &rp.stype, &rp.ref,
-          &rp.sorted_hs, &rp.hs2_dyn, &rp.nlist, &rp.nneigh, &rp.sorted, &rp.members};
-}
-static ListTarget shadow_target(Replica &rp) {
-  ListBufs &s = rp.shadow;
-  return {&s.cell_of, &s.slot, &s.order_tmp, &s.count, &s.cell_start, &s.order, &s.inv, &s.stype, &s.ref, &s.sorted_hs,
-          &s.hs2_dyn, &s.nlist, &s.nneigh, &s.sorted, &s.members};
-}
 
-// The rebuild chain into `T`: cell binning on `st` (one launch for small systems, four otherwise) and the list build on
-// `st_build` (the same stream, or a second one that waits for `binned`).  Every kernel returns at once unless *flag != 0.
+// The rebuild chain: cell binning (one launch for small systems, two or four otherwise) and the list build, all on `st`.
+// Every kernel returns at once unless *flag != 0.
 template <typename R>
-static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const ListTarget &T, const R *pos, const PairConsts<R> &c,
-                         const int *flag, hipStream_t st, hipStream_t st_build, hipEvent_t binned) {
+static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, const int *flag, hipStream_t st) {
+  const ListTarget T = {&rp.cell_of, &rp.slot, &rp.order_tmp, &rp.count, &rp.cell_start, &rp.order, &rp.inv, &rp.stype, &rp.ref,
+                        &rp.sorted_hs, &rp.hs2_dyn, &rp.nlist, &rp.nneigh, &rp.sorted, &rp.members};
+  const hipStream_t st_build = st;
   using R4 = typename Vec<R>::T4;
   const int n = ctx->d.natoms;
   int *flags = rp.flags.as<int>();
@@ -747,7 +740,7 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const ListTarget &T, cons
   P.dummy_a = P.dummy_b = nullptr;
   if (rp.pad_rows) {
     P.dummy_a = T.sorted->as<R4>() + n;
-    if (T.sorted == &rp.sorted && rp.sorted_alt.p) P.dummy_b = rp.sorted_alt.as<R4>() + n;
+    if (rp.sorted_alt.p) P.dummy_b = rp.sorted_alt.as<R4>() + n;
     for (int k = 0; k < 3; ++k) {  // (pad_dummy_positions' values)
       const bool open = !(c.box[k] > R(0));
       P.dummy_pos[0][k] = open ? R(1.0e6) : R(0.25) * c.box[k];
@@ -773,10 +766,6 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const ListTarget &T, cons
     hipLaunchKernelGGL(fill_cells_kernel, dim3(nb), dim3(256), 0, st, n, T.cell_of->as<int>(), T.slot->as<int>(),
                        T.cell_start->as<int>(), T.order_tmp->as<int>(), flag);
     hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, P, flag);
-  }
-  if (st_build != st) {
-    TMD_HIP(hipEventRecord(binned, st));
-    TMD_HIP(hipStreamWaitEvent(st_build, binned, 0));
   }
   const R rl = (R)ctx->rlist;
   constexpr int kMaxBuildBlocks = 16384;
@@ -818,134 +807,9 @@ int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairCo
   if (!prechecked)
     hipLaunchKernelGGL((check_displacement_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, pos, make_check<R>(ctx, rp), c,
                        force, rp.inv.as<int>(), ctx->qs.as<R>(), rp.sorted.as<R4>());
-  return enqueue_chain<R>(ctx, rp, active_target(rp), pos, c, flag, st, st, nullptr);
+  return enqueue_chain<R>(ctx, rp, pos, c, flag, st);
 }
 
-// ---- look-ahead build (Replica::shadow) ------------------------------------------------------------------------
-// The shadow set has the active set's sizes (same atoms, same grid, same list geometry).
-template <typename R>
-static int ensure_shadow(tmdhip_ctx *ctx, Replica &rp) {
-  ListBufs &s = rp.shadow;
-  TMD_TRY(s.cell_of.ensure(rp.cell_of.bytes));
-  TMD_TRY(s.slot.ensure(rp.slot.bytes));
-  TMD_TRY(s.order_tmp.ensure(rp.order_tmp.bytes));
-  TMD_TRY(s.order.ensure(rp.order.bytes));
-  TMD_TRY(s.inv.ensure(rp.inv.bytes));
-  TMD_TRY(s.stype.ensure(rp.stype.bytes));
-  TMD_TRY(s.ref.ensure(rp.ref.bytes));
-  if (rp.sorted_hs.bytes) TMD_TRY(s.sorted_hs.ensure(rp.sorted_hs.bytes));
-  if (rp.hs2_dyn.bytes) TMD_TRY(s.hs2_dyn.ensure(rp.hs2_dyn.bytes));
-  TMD_TRY(s.nlist.ensure(rp.nlist.bytes));
-  TMD_TRY(s.nneigh.ensure(rp.nneigh.bytes));
-  TMD_TRY(s.sorted.ensure(rp.sorted.bytes));
-  TMD_TRY(s.cell_start.ensure(rp.cell_start.bytes));
-  if (rp.members.bytes) TMD_TRY(s.members.ensure(rp.members.bytes));
-  if (s.padgen.bytes < rp.padgen.bytes) {
-    TMD_TRY(s.padgen.ensure(rp.padgen.bytes));
-    TMD_HIP(hipMemset(s.padgen.p, 0, s.padgen.bytes));  // (0: no rebuild count ever equals it)
-  }
-  if (s.count.bytes < rp.count.bytes) {
-    TMD_TRY(s.count.ensure(rp.count.bytes));
-    TMD_HIP(hipMemset(s.count.p, 0, s.count.bytes));  // (scan_cells_kernel leaves the counts zero for the next build)
-  }
-  TMD_HIP(hipStreamSynchronize(nullptr));  // (the streams these buffers are used on need not be ordered behind the null stream)
-  return 0;
-}
-
-template <typename R>
-int enqueue_lookahead_build(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, hipStream_t st) {
-  if (!ctx->la_stream) {
-    // (a lower priority than the compute stream's was measured)
-    int lo = 0, hi = 0;
-    TMD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    int prio = 0;
-    if (const char *e = std::getenv("TMDHIP_LOOKAHEAD_PRIO")) prio = !std::strcmp(e, "low") ? lo : (!std::strcmp(e, "high") ? hi : 0);
-    TMD_HIP(hipStreamCreateWithPriority(&ctx->la_stream, hipStreamNonBlocking, prio));
-  }
-  if (!rp.la_binned) {
-    TMD_HIP(hipEventCreateWithFlags(&rp.la_binned, hipEventDisableTiming));
-    TMD_HIP(hipEventCreateWithFlags(&rp.la_built, hipEventDisableTiming));
-  } else {
-    // the previous shadow build (adopted or dropped) may still be reading these buffers
-    TMD_HIP(hipStreamWaitEvent(st, rp.la_built, 0));
-  }
-  TMD_TRY(ensure_shadow<R>(ctx, rp));
-  TMD_TRY((enqueue_chain<R>(ctx, rp, shadow_target(rp), pos, c, rp.flags.as<int>() + F_ALWAYS, st, ctx->la_stream, rp.la_binned)));
-  TMD_HIP(hipEventRecord(rp.la_built, ctx->la_stream));
-  rp.la_state = 1;
-  rp.la_start_step = rp.step;
-  rp.lookahead_builds++;
-  return 0;
-}
-
-// The positions of this step in the NEW cell order + the displacement test against the NEW list's reference positions
-// (its age is charged to its skin here: every atom must still be inside its half skin, or the list may miss a pair:
-// F_VIOLATION, the caller rewinds).  The old list's pending rebuild request, if any, is history.
-template <typename R>
-__global__ void adopt_list_kernel(int n, const R *__restrict__ pos, const R *__restrict__ qs, const int *__restrict__ inv,
-                                  const R *__restrict__ ref, const R *__restrict__ hs2, R hard2, PairConsts<R> c,
-                                  typename Vec<R>::T4 *__restrict__ sorted, int *flags, int parity) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) flags[F_REBUILD0 + parity] = 0;
-  if (i >= n) return;
-  const R x = pos[3 * i + 0], y = pos[3 * i + 1], z = pos[3 * i + 2];
-  const R dx = min_image(x - ref[3 * i + 0], c.box[0], c.invbox[0]);
-  const R dy = min_image(y - ref[3 * i + 1], c.box[1], c.invbox[1]);
-  const R dz = min_image(z - ref[3 * i + 2], c.box[2], c.invbox[2]);
-  const R h2 = hs2 ? hs2[i] : hard2;
-  if (!(dx * dx + dy * dy + dz * dz <= h2)) flags[F_VIOLATION] = 1;
-  typename Vec<R>::T4 rec;
-  rec.x = x;
-  rec.y = y;
-  rec.z = z;
-  rec.w = qs[i];
-  sorted[inv[i]] = rec;
-}
-
-template <typename R>
-int adopt_lookahead_list(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, hipStream_t st) {
-  using R4 = typename Vec<R>::T4;
-  const int n = ctx->d.natoms;
-  ListBufs &s = rp.shadow;
-  TMD_HIP(hipStreamWaitEvent(st, rp.la_built, 0));
-  const R *hs2 = ctx->half_skin2.p ? (s.hs2_dyn.p ? s.hs2_dyn.as<R>() : ctx->half_skin2.as<R>()) : nullptr;
-  hipLaunchKernelGGL((adopt_list_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, pos, ctx->qs.as<R>(), s.inv.as<int>(),
-                     s.ref.as<R>(), hs2, (R)(0.25 * ctx->skin * ctx->skin), c, s.sorted.as<R4>(), rp.flags.as<int>(),
-                     (int)(rp.step & 1));
-  TMD_HIP(hipGetLastError());
-  std::swap(rp.cell_of, s.cell_of);
-  std::swap(rp.slot, s.slot);
-  std::swap(rp.order_tmp, s.order_tmp);
-  std::swap(rp.count, s.count);
-  std::swap(rp.cell_start, s.cell_start);
-  std::swap(rp.order, s.order);
-  std::swap(rp.inv, s.inv);
-  std::swap(rp.stype, s.stype);
-  std::swap(rp.ref, s.ref);
-  std::swap(rp.sorted_hs, s.sorted_hs);
-  std::swap(rp.hs2_dyn, s.hs2_dyn);
-  std::swap(rp.nlist, s.nlist);
-  std::swap(rp.nneigh, s.nneigh);
-  std::swap(rp.padgen, s.padgen);
-  std::swap(rp.sorted, s.sorted);
-  rp.la_state = 0;
-  rp.lookahead_adopted++;
-  return 0;
-}
-
-int drop_lookahead(tmdhip_ctx *ctx, Replica &rp, bool wait) {
-  if (rp.la_state) {
-    rp.la_state = 0;
-    rp.lookahead_dropped++;
-  }
-  if (wait && ctx->la_stream) TMD_HIP(hipStreamSynchronize(ctx->la_stream));
-  return 0;
-}
-
-template int enqueue_lookahead_build<float>(tmdhip_ctx *, Replica &, const float *, const PairConsts<float> &, hipStream_t);
-template int enqueue_lookahead_build<double>(tmdhip_ctx *, Replica &, const double *, const PairConsts<double> &, hipStream_t);
-template int adopt_lookahead_list<float>(tmdhip_ctx *, Replica &, const float *, const PairConsts<float> &, hipStream_t);
-template int adopt_lookahead_list<double>(tmdhip_ctx *, Replica &, const double *, const PairConsts<double> &, hipStream_t);
 template int enqueue_list_update<float>(tmdhip_ctx *, Replica &, const float *, const PairConsts<float> &, int, hipStream_t, bool);
 template int enqueue_list_update<double>(tmdhip_ctx *, Replica &, const double *, const PairConsts<double> &, int, hipStream_t, bool);
 

@@ -170,28 +170,6 @@ constexpr double kChainSkipNear = 0.75;  // "near": beyond this fraction of the 
                                          // skin 1.2: 2.2 x the largest per-step move seen in the water box, 9.5
                                          // standard deviations of a hydrogen's thermal velocity at 300 K)
 
-// ---- look-ahead list builds (Replica::shadow): OPT-IN, measured slower on MI355X ------------------------------------
-// A list build is 158 us at C3 and runs alone between two pair launches, every ~11 steps: 14.5 us per step, while the
-// pair launches leave more than half of the VALU issue slots idle.  The idea: start the NEXT list's build early — when
-// the displacement test reports the first atom beyond `frac` of its limit — from a snapshot of the current positions
-// into the replica's second buffer set: binning on the compute stream (4 short launches), the build kernel on a second
-// stream, concurrently with the pair launches of the next `steps` steps, which keep using the old list.  Then the new
-// list is adopted at a launch boundary (adopt_list_kernel: current positions in the new cell order + the displacement
-// test against the new reference positions, so the list's age is charged to its skin by the same test that guards
-// every list; the buffer sets swap).  The number of steps is fixed, not "when the build is done": which step adopts
-// must not depend on timing, or trajectories would not be reproducible; if the build is late the compute stream waits.
-// The old list's own rebuild chain stays in place (a device-side rebuild request before the adoption is served
-// synchronously, or flagged as a violation where the chain was left out).
-// MEASURED (round 4, C3): correct (exact pair counts, reproducible trajectories) and 40 % SLOWER — 62.3 ->
-// 89 us per step at "0.55,4".  The pair kernel's five waves per SIMD hold 480 of the 512 VGPRs, so a build wave only
-// becomes resident where a pair wave retires: the two kernels time-slice the SIMDs instead of sharing them (pair
-// launches 45 -> 64-69 us while a build is in flight; a cycle of 5.1 steps costs exactly one build more than the
-// same steps without one), and a list that is adopted at age `steps` is retired `steps` earlier: a build every 5.1
-// instead of every 10.9 steps.  Hence off unless TMDHIP_LOOKAHEAD = "frac,steps" asks for it (e.g. "0.55,4").
-constexpr int64_t kLookaheadMinEntries = 20'000'000;  // list slots from which the build would be worth hiding
-constexpr double kLookaheadFrac = 0.55;
-constexpr int kLookaheadSteps = 4;
-
 // spin until the device has published sequence number `target` (wrap-around safe); false after 0.2 s
 bool wait_published(volatile unsigned *hp, unsigned target) {
   if ((int)(hp[0] - target) >= 0) return true;
@@ -224,19 +202,12 @@ int upload_fused_static(Replica &rp, const FusedStaticT<R> &now, hipStream_t st)
 template int upload_fused_static<float>(Replica &, const FusedStaticT<float> &, hipStream_t);
 template int upload_fused_static<double>(Replica &, const FusedStaticT<double> &, hipStream_t);
 
-// can the pair launch of this replica integrate the next step itself?  (lean kernels — fp32, and since round 4 fp64 —
-// 4 .. 64 lanes per atom: a pair block's atoms fit one wave of a step block)
+// can the pair launch of this replica integrate the next step itself?  (lean fp32 kernel, 4 .. 64 lanes per atom: a pair
+// block's atoms fit one wave of a step block.  fp64: built in round 4, bit-identical and slower — 151 against 124.5 us
+// per step at C3, no partial last round of pair blocks for the step blocks to hide in — and removed in round 5.)
 template <typename R>
 bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairConsts<R> &c) {
-  // fp64: built and bit-identical in round 4, and measured SLOWER at C3 (pair + step launch 126 us against 82.5 + a 15-us
-  // integrator kernel; 151 against 124.5 us per step): the fp64 kernel's 3 072 pair blocks are exactly three rounds of
-  // the 1 024 that are resident at four waves per SIMD, so there is no partial last round whose idle slots the step
-  // blocks could use — they run behind the pair work, with the fp64 noise and bonded code spilling under the pair
-  // path's 128-register cap.  Opt-in: TMDHIP_FUSED_STEP_F64=1.
-  if (std::is_same<R, double>::value) {
-    const char *e64 = std::getenv("TMDHIP_FUSED_STEP_F64");
-    if (!(e64 && std::atoi(e64) != 0)) return false;
-  }
+  if (std::is_same<R, double>::value) return false;
   const char *e = std::getenv("TMDHIP_FUSED_STEP");  // (read per call: tests switch it within a process)
   if (e && std::atoi(e) == 0) return false;
   if (ctx->fused_off_call || ctx->fused_disabled) return false;  // repetition of a batch whose fused launch timed out
@@ -258,21 +229,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   ctx->no_chain_skip_once = false;
   ctx->fused_off_call = ctx->no_fused_once;
   ctx->no_fused_once = false;
-  double la_frac = kLookaheadFrac;
-  int la_steps = kLookaheadSteps;
-  bool la_on = false;
-  if (const char *e = std::getenv("TMDHIP_LOOKAHEAD")) {
-    double fr = 0;
-    int k = 0;
-    const int got = std::sscanf(e, "%lf,%d", &fr, &k);
-    la_on = got >= 1 && fr > 0 && fr < 1;
-    if (la_on) la_frac = fr;
-    if (got == 2 && k >= 1 && k <= 64) la_steps = k;
-  }
-  const char *e_lamin = std::getenv("TMDHIP_DEBUG_LOOKAHEAD_MIN_ENTRIES");
-  const int64_t la_min_entries = e_lamin ? std::atoll(e_lamin) : kLookaheadMinEntries;
-  if (!d->continuation)  // the caller may have moved atoms: a snapshot taken in the previous call is worthless
-    for (auto &rp : ctx->rep) TMD_TRY(drop_lookahead(ctx, rp, false));
   bool pace_timed_out = false;  // the device did not report within wait_published's limit: no more waiting in this call
   const int nrep = (int)ctx->rep.size();
   const bool langevin = d->vcoeff_dev != nullptr;
@@ -397,8 +353,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       // then the previous call's last), never in the repetition of a rewound batch.
       bool skip_chain = false;
       const bool pace = check && chain_skip_on && (int64_t)n * rp.lg.maxn >= chain_min_entries;
-      const bool la = la_on && pace && (int64_t)n * rp.lg.maxn >= la_min_entries;
-      bool near2_prev = false, rebuilt_prev = false;
       if (pace) {
         if (!rp.hostpub) {
           TMD_HIP(hipHostMalloc((void **)&rp.hostpub, 8 * sizeof(unsigned), hipHostMallocMapped));
@@ -415,8 +369,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
           // (with its chain in place: every displacement is one step old now)
           const bool near = hp[1 + (rp.seq & 1u)] == rp.seq, rebuilt = hp[3 + (rp.seq & 1u)] == rp.seq;
           skip_chain = !near || (rebuilt && !rp.prev_skipped);
-          near2_prev = hp[5 + (rp.seq & 1u)] == rp.seq;
-          rebuilt_prev = rebuilt;
         }
         rp.prev_skipped = skip_chain;
         rp.seq += 1;
@@ -424,7 +376,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         a.chk.near_host = rp.hostpub + 1 + (rp.seq & 1u);
         a.chk.seq = rp.seq;
         a.chk.near_frac2 = (R)(chain_near * chain_near);
-        a.chk.near2_frac2 = la ? (R)(la_frac * la_frac) : R(0);
         a.chk.skipped = skip_chain ? 1 : 0;
         rp.seq_valid = true;
         rp.pub_ptr = rp.hostpub;
@@ -475,20 +426,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       TMD_HIP(hipGetLastError());
       if (!first) continue;
       R *pos = cur[r];
-      if (la && list) {  // look-ahead list (see kLookaheadFrac): adopt the finished one, or start the next
-        if (rp.la_state && rp.step - rp.la_start_step >= la_steps) {
-          TMD_TRY(adopt_lookahead_list<R>(ctx, rp, pos, c, st));
-          const ListCheck<R> fresh = make_check<R>(ctx, rp);  // the list buffers have swapped
-          a.chk.ref = fresh.ref;
-          a.chk.hs2 = fresh.hs2;
-          a.sorted = rp.sorted.as<R4>();
-          a.inv = rp.inv.as<int>();
-          skip_chain = true;  // (the adoption kernel has cleared this step's rebuild request: the old list's business)
-          rp.prev_skipped = true;
-        } else if (!rp.la_state && near2_prev && !rebuilt_prev) {
-          TMD_TRY(enqueue_lookahead_build<R>(ctx, rp, pos, c, st));
-        }
-      }
       // forces of step `it` (forces.py:122-319): nonbonded stores (list path) or accumulates into zeros
       int flags_c = TMDHIP_WANT_FORCES;
       double *en = nullptr;
@@ -532,7 +469,6 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               now.s.chk.hs2 = a.chk.hs2;
               now.s.chk.flags = a.chk.flags;
               now.s.chk.near_frac2 = (R)(chain_near * chain_near);
-              now.s.chk.near2_frac2 = a.chk.near2_frac2;
               now.s.chk.ext = a.chk.ext;
               if (bm == 1) std::memcpy(&now.A, &A, sizeof(A));
               now.has_bonded = bm;

@@ -91,38 +91,20 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
 // ---- the MD step inside a pair launch: step blocks (FusedStepT / FusedStaticT in engine.h) -----------------------------
 constexpr int kStepPollSleep = 4;  // s_sleep argument between two polls of a force record (x 64 cycles)
 
-// The force record a pair wave leaves for the step block that integrates its atom: {fx, fy, fz, launch number}.
-// fp32: ONE 16-byte store written through to device scope (sc1) — the number in .w says the force beside it is this
-// launch's.  fp64: 32 bytes as two 16-byte stores, {fx, fy} first, then — after the first has been acknowledged
-// (s_waitcnt vmcnt(0): stores retire in order behind it) — {fz, number}; the reader polls the second half and fetches
-// the first once the number is there.
+// The force record a pair wave leaves for the step block that integrates its atom: {fx, fy, fz, launch number} as ONE
+// 16-byte store written through to device scope (sc1) — the number in .w says the force beside it is this launch's.
+// (fp32 only.  The fp64 form — 32 bytes as two ordered 16-byte stores — was measured slower than the separate integrator
+// kernel in round 4 and removed in round 5: docs/history/round4.md.)
 __device__ __forceinline__ void store_force_record(float4 *fsort, int n, int a, float sx, float sy, float sz, unsigned gen) {
   const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fsort, 0, n * 16, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128((v4u){__float_as_uint(sx), __float_as_uint(sy), __float_as_uint(sz), gen}, frsrc, a * 16, 0,
                                          kAuxDeviceScope);
-}
-__device__ __forceinline__ void store_force_record(double4 *fsort, int n, int a, double sx, double sy, double sz, unsigned gen) {
-  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fsort, 0, n * 32, 0x00020000);
-  const unsigned long long bx = (unsigned long long)__double_as_longlong(sx), by = (unsigned long long)__double_as_longlong(sy),
-                           bz = (unsigned long long)__double_as_longlong(sz);
-  __builtin_amdgcn_raw_buffer_store_b128((v4u){(unsigned)bx, (unsigned)(bx >> 32), (unsigned)by, (unsigned)(by >> 32)}, frsrc, a * 32, 0,
-                                         kAuxDeviceScope);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (expcnt / lgkmcnt left alone): the first half has been written through
-  __builtin_amdgcn_raw_buffer_store_b128((v4u){(unsigned)bz, (unsigned)(bz >> 32), gen, 0u}, frsrc, a * 32 + 16, 0, kAuxDeviceScope);
 }
 // one look at atom slot a's record: true (and the force in f) when it carries launch number `want`
 __device__ __forceinline__ bool load_force_record(const __amdgpu_buffer_rsrc_t &frsrc, float, int a, unsigned want, float (&f)[3]) {
   const v4u r = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 16, 0, kAuxDeviceScope | kAuxVolatile);
   if (r.w != want) return false;
   f[0] = __uint_as_float(r.x), f[1] = __uint_as_float(r.y), f[2] = __uint_as_float(r.z);
-  return true;
-}
-__device__ __forceinline__ bool load_force_record(const __amdgpu_buffer_rsrc_t &frsrc, double, int a, unsigned want, double (&f)[3]) {
-  const v4u hi = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 32 + 16, 0, kAuxDeviceScope | kAuxVolatile);
-  if (hi.z != want) return false;
-  const v4u lo = __builtin_amdgcn_raw_buffer_load_b128(frsrc, a * 32, 0, kAuxDeviceScope | kAuxVolatile);
-  f[0] = __hiloint2double((int)lo.y, (int)lo.x), f[1] = __hiloint2double((int)lo.w, (int)lo.z);
-  f[2] = __hiloint2double((int)hi.y, (int)hi.x);
   return true;
 }
 

@@ -40,13 +40,10 @@ namespace tmd {
 // (v_fma with clamp + v_mul) where no energy is wanted; the four v_rsq of a group issued back to back; list words
 // through a raw buffer with a SCALAR running offset, requested behind the gathers issued in the same breath; and the
 // unchecked groups software-pipelined over two register sets (gathers of group g+1 in flight while g is evaluated).
-// A/B switch (results identical; python -m torchmd_amd._build -DTMD_AB_LDS_GATHER=1 --out=..., tools/ab_pair.py): the gathers of
-// the pipelined loop land in LDS (`buffer_load_dwordx4 ... lds`, gfx950) instead of in VGPRs — two stages of 4 KB per wave.
-// The 32 KB per block this takes limit the CU to four blocks (four waves per SIMD); measured in round 4, DESIGN 6g.
-#ifndef TMD_AB_LDS_GATHER
-#define TMD_AB_LDS_GATHER 0
-#endif
-constexpr int kFastWaves = TMD_AB_LDS_GATHER ? 4 : 5;  // waves per SIMD of the pipelined loop (94 VGPRs); measured at 4 / 6 / 7 / 8: section 6c of DESIGN.md
+// (Measured and not kept, round 4: the gathers of the pipelined loop landing in LDS — `buffer_load_dwordx4 ... lds`, two
+// stages of 4 KB per wave, four waves per SIMD — 49.2-50.5 against 45.6-46.9 us, identical checksums; the code is in commit
+// daee5f8, the record in profiles/r04_lds_gather_ab.txt.)
+constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs); measured at 4 / 6 / 7 / 8: docs/history/round3.md
 // ---- the MD step inside the pair launch (FUSED variants; tmdhip_md_run, interior steps) -----------------------
 // Between two force evaluations an MD step is per-atom work on the force just computed: second half kick of step
 // `it` (+ thermostat), first half kick and drift of step it+1, the displacement test, the new record of the
@@ -288,14 +285,10 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   const bool stream_list = lmode & kLmStream;
   auto list_word = [&](int gg) {
     v4u w = (v4u){0u, 0u, 0u, 0u};
-#ifdef TMD_AB_NO_TAIL_GUARD  // A/B build switch (tools/ab_pair.py): request unconditionally, as before round 4
-    w = list_word_raw(gg);
-#else
     if (gg < gall) {
       if (stream_list) w = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, gg * 1024, 2 /* nt */);
       else w = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, gg * 1024, 0);
     }
-#endif
     return w;
   };
   // A list word is requested AFTER the gathers issued in the same breath (see the head comment); sched_barrier pins
@@ -330,64 +323,6 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
         __builtin_amdgcn_sched_barrier(0);
         group(fused_image{}, unchecked_t{}, tab, raw, g * UNROLL);
       }
-#if TMD_AB_LDS_GATHER
-    } else if (gfull > 0) {
-      // the same pipeline with the gathered records landing in LDS: stage s of wave w = s_stage[s][w][entry][lane]
-      // (two arrays, not one indexed by the stage: the compiler's wait-count pass must see that a read of one stage does
-      // not alias the loads in flight into the other, or every ds_read waits for all of them)
-      __shared__ v4u s_stage0[kFastThreads / 64][UNROLL][64];
-      __shared__ v4u s_stage1[kFastThreads / 64][UNROLL][64];
-      const int wv = (int)(threadIdx.x >> 6);
-      auto issue_lds = [&](const v4u &w, auto stage, unsigned (&tab)[UNROLL]) {
-        const unsigned entry[UNROLL] = {w.x, w.y, w.z, w.w};
-        auto &S = decltype(stage)::value ? s_stage1 : s_stage0;
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (__attribute__((address_space(3))) void *)&S[wv][u][0], 16,
-                                                   entry[u] & kEntryOffMask, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) tab[u] = trow | (entry[u] >> 24);
-      };
-      auto eval_lds = [&](auto stage, const unsigned (&tab)[UNROLL], int kk0) {
-        auto &S = decltype(stage)::value ? s_stage1 : s_stage0;
-        v4u r[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) r[u] = S[wv][u][lane];
-        group(fused_image{}, unchecked_t{}, tab, r, kk0);
-      };
-      using st0 = std::integral_constant<int, 0>;
-      using st1 = std::integral_constant<int, 1>;
-      unsigned ta[UNROLL], tb[UNROLL];
-      issue_lds(word, st0{}, ta);
-      __builtin_amdgcn_sched_barrier(0);
-      word = list_word(1);
-      __builtin_amdgcn_sched_barrier(0);
-      while (true) {
-        if (g + 1 >= gfull) {
-          eval_lds(st0{}, ta, g * UNROLL);
-          g += 1;
-          break;
-        }
-        issue_lds(word, st1{}, tb);
-        __builtin_amdgcn_sched_barrier(0);
-        word = list_word(g + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        eval_lds(st0{}, ta, g * UNROLL);
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 2 >= gfull) {
-          eval_lds(st1{}, tb, (g + 1) * UNROLL);
-          g += 2;
-          break;
-        }
-        issue_lds(word, st0{}, ta);
-        __builtin_amdgcn_sched_barrier(0);
-        word = list_word(g + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        eval_lds(st1{}, tb, (g + 1) * UNROLL);
-        __builtin_amdgcn_sched_barrier(0);
-        g += 2;
-      }
-#else
     } else if (gfull > 0) {
       v4u ra[UNROLL], rb[UNROLL];
       unsigned ta[UNROLL], tb[UNROLL];
@@ -420,7 +355,6 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
         __builtin_amdgcn_sched_barrier(0);
         g += 2;
       }
-#endif
     }
     checked_loop(fused_image{});  // tail
   }

@@ -344,8 +344,8 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
     }
   }
   if constexpr (std::is_same<R, double>::value) {
-    if (lean && (f || ENERGY || fl)) {  // lean fp64 kernel (same conditions as the fp32 one)
-      TMD_TRY(launch_pair_lean_f64<ENERGY>(ctx, rp, c, f, overwrite, st, e0, e1, lmode, fl));
+    if (lean && !fl && (f || ENERGY)) {  // lean fp64 kernel (same conditions as the fp32 one; never fused)
+      TMD_TRY(launch_pair_lean_f64<ENERGY>(ctx, rp, c, f, overwrite, st, e0, e1, lmode));
       if (ENERGY && fold) TMD_TRY(tmd::fold_energies(ctx, energies, st, 1));
       return 0;
     }

@@ -1,7 +1,6 @@
 // K3d: the lean list pair kernel for fp64 contexts (gfx950).  Reference semantics as pair_fast_f32.hip
 // (torchmd/forces.py:260-319, LJ and/or electrostatics).
 #include "engine.h"
-#include "md_step.h"
 
 namespace tmd {
 
@@ -9,37 +8,27 @@ namespace tmd {
 // 32-byte records (two 16-byte gathers per entry), 16-byte table entries, half-rate arithmetic; 1/r from v_rsq_f64
 // and two Newton steps.  Same entry format, list layout and decision arithmetic (min_image_magic's fp64 overload:
 // magic number 1.5 * 2^52; norm2's fp64 order).
-// FUSED (round 4): interior steps of tmdhip_md_run — step blocks behind the pair blocks make the MD step, exactly as in
-// the fp32 kernel (md_step.h: fused_step_blocks; the force record is 32 bytes here, see store_force_record).
-// (The step-block path — fp64 Philox + libm noise, inline bonded records — would take 214 VGPRs and halve the pair
-// waves' occupancy (122 VGPRs, four waves per SIMD): the fused variants are held to four waves, the step blocks spill.)
-template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
-__global__ __launch_bounds__(256, FUSED ? 4 : 2) void list_pair_lean_f64_kernel(
+// (Step blocks behind the pair blocks — the MD step inside the launch, as in the fp32 kernel — were built for fp64 in
+// round 4, bit-identical and SLOWER at C3: 151 against 124.5 us per step; the code is in commit daee5f8, the record in
+// docs/history/round4.md.  fp64 contexts keep the separate integrator kernel.)
+template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH>
+__global__ __launch_bounds__(256, 2) void list_pair_lean_f64_kernel(
     int n, const double4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const double2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<double> c, double *__restrict__ forces, int overwrite,
-    double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext, int *lflags, int lmode,
-    const FusedStaticT<double> *__restrict__ fst, FusedStepT<double> fstep) {
+    double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext, int *lflags, int lmode) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
-  static_assert(!(FUSED && ENERGY), "the fused step is for interior steps");
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // tells the host (host-mapped word) that everything enqueued before this launch has completed
     if (publish) __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (lflags) {  // list duties of the launch's first thread (as in the fp32 kernel)
       const int parity = (lmode & kLmParity) ? 1 : 0;
       if ((lmode & kLmViolation) && lflags[F_REBUILD0 + parity] != 0) lflags[F_VIOLATION] = 1;
-      if (FUSED) lflags[F_REBUILD0 + parity] = 0;
     }
   }
   __shared__ __align__(16) double2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
-  // pair blocks of the launch (FUSED: step blocks follow them)
-  const unsigned npair = FUSED ? gridDim.x - (unsigned)fstep.nstep_blocks : gridDim.x;
-  if (FUSED && blockIdx.x >= npair) {
-    fused_step_blocks<double, FUSED == 2, 256 / LPA>(fst, fstep, c, n, sorted, order, (int)(blockIdx.x - npair), (int)npair,
-                                                     reinterpret_cast<double *>(stab));
-    return;
-  }
+  const unsigned npair = gridDim.x;
   for (int t = threadIdx.x; t < ntypes * kEntryTypes; t += blockDim.x) {  // rows of existing classes only
     const int ti = t >> 5, tj = t & 31;
     double2 ab = make_double2(0.0, 0.0);
@@ -194,10 +183,6 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 2) void list_pair_lean_f64_kernel(
     sy += __shfl_xor(sy, o, 64);
     sz += __shfl_xor(sz, o, 64);
   }
-  if constexpr (FUSED != 0) {
-    if (active && sub == 0) store_force_record(fstep.fsort, n, a, sx, sy, sz, fstep.gen);
-    return;
-  }
   if (active && sub == 0 && forces) {
     const int oi = order[a];
     if (overwrite) {
@@ -222,84 +207,41 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 2) void list_pair_lean_f64_kernel(
   }
 }
 
-// host side: one launch of the lean fp64 kernel over the replica's list (fl: with step blocks behind the pair blocks)
+// host side: one launch of the lean fp64 kernel over the replica's list
 template <bool ENERGY>
 int launch_pair_lean_f64(tmdhip_ctx *ctx, Replica &rp, const PairConsts<double> &c, double *f, int overwrite,
-                         hipStream_t st, hipEvent_t e0, hipEvent_t e1, int lmode, const FusedLaunchT<double> *fl) {
+                         hipStream_t st, hipEvent_t e0, hipEvent_t e1, int lmode) {
   const int n = ctx->d.natoms;
   const int apw = rp.lg.apw;
   const int waves = (n + apw - 1) / apw;
   const int blocks = (waves + 3) / 4;
   const int npair8 = (blocks + 7) / 8 * 8;
   const bool lj = c.terms & TMDHIP_TERM_LJ, el = c.terms & TMDHIP_TERM_ELECTROSTATICS;
-  FusedStepT<double> fstep{};
-#define TMD_LAUNCH_FAST_T(L, A, B, F)       \
-  if (c.switch_on && A) {                  \
-    TMD_LAUNCH_FAST_S(L, A, B, true, F);   \
-  } else {                                 \
-    TMD_LAUNCH_FAST_S(L, A, B, false, F);  \
+#define TMD_LAUNCH_FAST_T(L, A, B)       \
+  if (c.switch_on && A) {               \
+    TMD_LAUNCH_FAST_S(L, A, B, true);   \
+  } else {                              \
+    TMD_LAUNCH_FAST_S(L, A, B, false);  \
   }
-#define TMD_LAUNCH_FAST_S(L, A, B, S, F)                                                                                          \
-  launch_with_events(list_pair_lean_f64_kernel<L, A, B, ENERGY, S, F>, dim3(npair8 + (F ? fstep.nstep_blocks : 0)), dim3(256), 0u, \
-                     st, e0, e1, n, rp.sorted.as<double4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,                 \
-                     ctx->tab.as<double2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite,            \
-                     ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>(), rp.flags.as<int>(), lmode,           \
-                     F ? fl->fst : nullptr, fstep)
-#define TMD_LAUNCH_FAST(L, F)               \
-  if (lj && el) {                           \
-    TMD_LAUNCH_FAST_T(L, true, true, F);    \
-  } else if (lj) {                          \
-    TMD_LAUNCH_FAST_T(L, true, false, F);   \
-  } else {                                  \
-    TMD_LAUNCH_FAST_T(L, false, true, F);   \
+#define TMD_LAUNCH_FAST_S(L, A, B, S)                                                                                       \
+  launch_with_events(list_pair_lean_f64_kernel<L, A, B, ENERGY, S>, dim3(npair8), dim3(256), 0u, st, e0, e1, n,              \
+                     rp.sorted.as<double4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes, ctx->tab.as<double2>(), \
+                     rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f, overwrite, ctx->escratch.as<double>(),  \
+                     rp.pub_ptr, rp.pub_val, rp.extent.as<int>(), rp.flags.as<int>(), lmode)
+#define TMD_LAUNCH_FAST(L)               \
+  if (lj && el) {                        \
+    TMD_LAUNCH_FAST_T(L, true, true);    \
+  } else if (lj) {                       \
+    TMD_LAUNCH_FAST_T(L, true, false);   \
+  } else {                               \
+    TMD_LAUNCH_FAST_T(L, false, true);   \
   }
-  if (fl) {
-    // step blocks behind the pair blocks (interior steps of tmdhip_md_run): as launch_pair_fast_f32
-    fstep = fl->step;
-    const int k = rp.lg.lpa * 64 / 256, g8 = npair8 / 8;
-    const int units = (g8 + k - 1) / k;  // 64-atom units per XCD's eighth: a block with bonded records, a wave without
-    fstep.nstep_blocks = 8 * (fstep.bonded == 1 ? units : (units + 3) / 4);
-    if (rp.fsort.bytes < sizeof(double4) * (size_t)n) {
-      TMD_TRY(rp.fsort.ensure(sizeof(double4) * (size_t)n));
-      TMD_HIP(hipMemsetAsync(rp.fsort.p, 0, rp.fsort.bytes, st));  // launch number 0 = never written
-      rp.fused_gen = 0;
-    }
-    if (rp.fused_gen == 0)  // test knob: start the launch counter just below its wrap-around
-      if (const char *e = std::getenv("TMDHIP_DEBUG_FUSED_GEN0")) rp.fused_gen = (unsigned)std::strtoul(e, nullptr, 0);
-    if (++rp.fused_gen == 0) rp.fused_gen = 1;  // (0 = "never written" in the records)
-    fstep.gen = fstep.watch_gen = rp.fused_gen;
-    fstep.poll_limit = 1u << 22;
-    rp.fused_launches++;
-    if (const char *e = std::getenv("TMDHIP_DEBUG_STEP_TIMEOUT"))
-      if (rp.fused_launches == std::atoll(e)) fstep.watch_gen ^= 0x80000000u, fstep.poll_limit = 1u << 8;
-    fstep.fsort = rp.fsort.as<double4>();
-    if constexpr (!ENERGY) {
-#define TMD_LAUNCH_FUSED(L)    \
-  if (fl->langevin) {          \
-    TMD_LAUNCH_FAST(L, 2);     \
-  } else {                     \
-    TMD_LAUNCH_FAST(L, 1);     \
-  }
-      switch (rp.lg.lpa) {
-        case 4: TMD_LAUNCH_FUSED(4); break;
-        case 8: TMD_LAUNCH_FUSED(8); break;
-        case 16: TMD_LAUNCH_FUSED(16); break;
-        case 32: TMD_LAUNCH_FUSED(32); break;
-        case 64: TMD_LAUNCH_FUSED(64); break;
-        default: return fail("fused MD step: unsupported lanes-per-atom");
-      }
-#undef TMD_LAUNCH_FUSED
-    } else {
-      return fail("fused MD step with energies");
-    }
-  } else {
-    switch (rp.lg.lpa) {  // (pick_lpa never returns less than 4)
-      case 4: TMD_LAUNCH_FAST(4, 0); break;
-      case 8: TMD_LAUNCH_FAST(8, 0); break;
-      case 16: TMD_LAUNCH_FAST(16, 0); break;
-      case 32: TMD_LAUNCH_FAST(32, 0); break;
-      default: TMD_LAUNCH_FAST(64, 0); break;
-    }
+  switch (rp.lg.lpa) {  // (pick_lpa never returns less than 4)
+    case 4: TMD_LAUNCH_FAST(4); break;
+    case 8: TMD_LAUNCH_FAST(8); break;
+    case 16: TMD_LAUNCH_FAST(16); break;
+    case 32: TMD_LAUNCH_FAST(32); break;
+    default: TMD_LAUNCH_FAST(64); break;
   }
 #undef TMD_LAUNCH_FAST
 #undef TMD_LAUNCH_FAST_T
@@ -309,8 +251,8 @@ int launch_pair_lean_f64(tmdhip_ctx *ctx, Replica &rp, const PairConsts<double> 
 }
 
 template int launch_pair_lean_f64<true>(tmdhip_ctx *, Replica &, const PairConsts<double> &, double *, int, hipStream_t,
-                                        hipEvent_t, hipEvent_t, int, const FusedLaunchT<double> *);
+                                        hipEvent_t, hipEvent_t, int);
 template int launch_pair_lean_f64<false>(tmdhip_ctx *, Replica &, const PairConsts<double> &, double *, int, hipStream_t,
-                                         hipEvent_t, hipEvent_t, int, const FusedLaunchT<double> *);
+                                         hipEvent_t, hipEvent_t, int);
 
 }  // namespace tmd

@@ -570,6 +570,11 @@ class DomainSet:
         self.max_recoveries = 6  # per `step` call
         self.recoveries = 0  # (total, for reports)
         self._saved = None
+        # a halo overrun halves `check_every`; `regrow_after` clean migrations in a row give one step of it back, up to
+        # the value it had before the first overrun (one hot transient must not cost an all-reduce per step for ever)
+        self.regrow_after = 16
+        self._check_every_ceiling = None
+        self._clean_migrations = 0
 
     # -- setup: every rank holds the same global arrays and keeps its brick ---------------------
     def scatter(self, pos, vel, charges, types, masses):
@@ -713,6 +718,8 @@ class DomainSet:
             th.join()
         torch.cuda.synchronize(self.device)
         if errors:
+            if self.local:
+                self.transport.close()  # (a broken hub is not reused: the next call creates a new one)
             raise RuntimeError(f"tmdhip_dd_migrate failed on ranks {sorted(errors)}: {next(iter(errors.values()))}")
         return True
 
@@ -758,6 +765,15 @@ class DomainSet:
         """Re-assign atoms to bricks, rebuild halo plans and engines."""
         if verify and self.recover:
             self.verify_halo()
+            # the lists of the steps since the last checkpoint, BEFORE the migration resets them (a new atom set forces a
+            # rebuild and would absorb an overflow / outlived-skin report): a state saved after this migration is then one
+            # whose forces were computed from complete lists (round 4's advisor; migrate() synchronises with the host anyway)
+            self._lists_valid()
+            self._clean_migrations += 1
+            if self._check_every_ceiling and self._clean_migrations >= self.regrow_after and \
+                    self.check_every < self._check_every_ceiling:
+                self.check_every += 1
+                self._clean_migrations = 0
         if self._native_migration():
             self.migrations += 1
             self._since_migration = 0
@@ -865,7 +881,10 @@ class DomainSet:
                 recovered += 1
                 self.recoveries += 1
                 if halo:
+                    if self._check_every_ceiling is None:
+                        self._check_every_ceiling = self.check_every
                     self.check_every = max(1, self.check_every // 2)
+                    self._clean_migrations = 0
                 remaining, first = self._restore_state()
 
     def _dd_desc(self, d, recv_counts, remaining, first, dt, gamma, vnoise, seed):
@@ -903,6 +922,8 @@ class DomainSet:
 
         bad = False
         for d in self.domains.values():
+            if getattr(d, "forces_engine", None) is None:
+                continue
             bad = bad or not d.forces_engine._verify(d.forces_engine._engine(d.local_pos), d.local_pos)
         if not self.local:  # (every rank must take the same way: the verdict is the OR over the ranks)
             bad = self.transport.any_true(torch.tensor([1.0 if bad else 0.0], device=self.device))
@@ -948,6 +969,7 @@ class DomainSet:
             torch.cuda.synchronize(self.device)
             bad = {r: v for r, v in results.items() if v[0] < 0}
             if bad:
+                self.transport.close()  # (the hub is broken for good: the next use creates a new one with new communicators)
                 raise RuntimeError(f"tmdhip_dd_run failed on ranks {sorted(bad)}: {next(iter(bad.values()))[2]}")
             rcs, dones = {v[0] for v in results.values()}, {v[1] for v in results.values()}
             if len(rcs) != 1 or len(dones) != 1:

@@ -726,8 +726,6 @@ class Forces:
             "chains_skipped": int(st.chains_skipped),
             "steps_in_pair_launch": int(st.steps_in_pair_launch),
             "fused_step_timeouts": int(st.fused_step_timeouts),
-            "lookahead_builds": int(st.lookahead_builds),
-            "lookahead_adopted": int(st.lookahead_adopted),
         }
 
     def enable_timing(self, pos, on=True, every=1, limit=0, skip=0):

@@ -90,6 +90,9 @@ def _second_VV(vel, force, mass, dt):
 
 _REPLAY_FAILED = ("Integrator.step(): the batch of steps was rewound and repeated once and failed again; the trajectory "
                   "since the previous step() call is invalid (restart from the last saved state).  The library says: ")
+# (the step-by-step loop over a duck-typed / external force has no saved entry state: nothing was rewound)
+_LIST_INVALID = ("Integrator.step(): a neighbour list overflowed or outlived its skin during this call; the trajectory since "
+                 "the previous step() call is invalid (restart from the last saved state; the list capacity has been grown)")
 
 
 class Integrator:
@@ -244,9 +247,10 @@ class Integrator:
                 host = torch.cat([ke.flatten(), tot]).cpu().numpy()
                 Ekin, pot = host[: ke.numel()], [float(v) for v in host[ke.numel():]]
             if not self.forces._verify(eng, s.pos):
+                why = L.last_error()  # (tmdhip_check's verdict, set by judge_flags a moment ago)
                 if fused and not replay:  # (batch mode of the fused loop: same rewind as above)
                     return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
-                raise RuntimeError(_REPLAY_FAILED + L.last_error())
+                raise RuntimeError((_REPLAY_FAILED + why) if (fused and replay) else (_LIST_INVALID + ": " + why))
         else:
             Ekin = ke.flatten().cpu().numpy()
         Ekin = Ekin.astype(np.dtype("float32") if s.pos.dtype == torch.float32 else np.float64)
