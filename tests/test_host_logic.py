@@ -3,6 +3,7 @@ readers / Parameters against the reference (when /root/reference is present), re
 gloo with world_size 2."""
 
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -413,6 +414,23 @@ def test_halo_exchange_gloo(tmp_path, world):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_c5_dry_gloo(world):
+    """`bench.py --config c5 --gpus N --dry --backend gloo`: the N-brick bench path end to end without a GPU — DomainSet
+    planning, DistTransport count / row exchanges, the migration trigger and migrations over gloo, the force engine
+    stubbed (DryDomain).  The run checks itself (halo == brute-force image set before and after, every atom id exactly
+    once, positions == x0 + v t although atoms changed bricks) and exits non-zero otherwise."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c5", "--gpus", str(world), "--backend", "gloo",
+                          "--dry", "--nside", "24", "--steps", "40", "--warmup", "3"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["dry"] is True and out["n_gpus"] == world and out["backend"] == "gloo"
+    assert out["halo_equals_brute_force"] == [True, True] and out["atoms_accounted_for"] is True
+    assert out["domains"]["migrations_in_timed_region"] >= 2 and out["max_abs_dx_vs_ballistic"] < 1e-9
+    assert sorted(out["domains"]["grid"]) == ([1, 1, 2] if world == 2 else [1, 2, 2])
 
 
 def test_merge_lj_types_preserves_every_pair_parameter():

@@ -542,11 +542,68 @@ class Domain:
         return e
 
 
+class _DryEngine:
+    """Stand-in for `Forces` in a dry run (no device, no forces): what DomainSet asks of an engine."""
+
+    def _engine(self, pos):
+        return None
+
+    def _verify(self, eng, pos):
+        return True
+
+    def close(self):
+        pass
+
+
+class DryDomain(Domain):
+    """A brick without a force engine, on CPU tensors: `bench.py --config c5 --gpus N --dry --backend gloo` drives the
+    planning (ownership, halo plans), the count / row exchanges, the migration trigger and the migrations of a
+    `DomainSet` over gloo with it — the N > 1 bench path executed end to end where no GPU is.  Forces are zero (atoms
+    move ballistically, which is what makes them cross brick faces); the halo rows of every exchange can be checked
+    against the brute-force set of periodic images (`halo_matches_brute_force`)."""
+
+    def _build_engine(self, nhalo):
+        n = self.nown + nhalo
+        self.forces_engine = _DryEngine()
+        self.local_forces = torch.zeros(1, n, 3, dtype=self.dtype, device=self.device)
+        self.zero_box = torch.zeros(1, 3, 3, dtype=self.dtype, device=self.device)
+
+    def pack_halo(self):
+        if len(self.send_index32):
+            torch.add(self.pos[self.send_index32.long()], self.send_shift, out=self.send_buf)
+        return self.send_buf
+
+    def compute(self, want_energy=False):
+        self.forces = self.local_forces[0, : self.nown]
+        return None
+
+    def halo_matches_brute_force(self, all_wrapped):
+        """`all_wrapped`: the wrapped positions of EVERY atom of the box (gathered by the caller): the rows this brick
+        holds behind its own atoms must be exactly the periodic images that lie within `halo` of the brick."""
+        import itertools
+
+        lo, hi = self.grid.bounds(self.rank)
+        box = torch.as_tensor(self.grid.box, dtype=all_wrapped.dtype)
+        exp = []
+        for sft in itertools.product((-1, 0, 1), repeat=3):
+            img = all_wrapped + torch.tensor(sft, dtype=all_wrapped.dtype) * box
+            ext = ((img >= lo - self.halo) & (img < hi + self.halo)).all(dim=1)
+            own = ((img >= lo) & (img < hi)).all(dim=1)
+            exp.append(img[ext & ~own])
+        exp = torch.cat(exp)
+        got = self.halo_rows.to(all_wrapped.dtype)
+        if got.shape != exp.shape:
+            return False
+        key = lambda t: t[np.lexsort((t[:, 2].numpy(), t[:, 1].numpy(), t[:, 0].numpy()))]  # noqa: E731
+        return bool(torch.allclose(key(got), key(exp), atol=1e-9))
+
+
 class DomainSet:
     """Drives the domains of this process: one (`DistTransport`) or all of them (`LocalTransport`)."""
 
     def __init__(self, box, world, device, dtype, terms, cutoff, A=None, B=None, skin=1.5, grid=None, transport=None,
-                 **engine_kwargs):
+                 dry=False, **engine_kwargs):
+        self.dry = bool(dry)  # CPU tensors, no force engine (DryDomain): the plumbing of an N-rank run without a GPU
         self.grid = BrickGrid(box, world, grid)
         self.device, self.dtype = torch.device(device), dtype
         self.transport = transport if transport is not None else LocalTransport(world)
@@ -554,7 +611,8 @@ class DomainSet:
         ranks = range(world) if self.local else [self.transport.rank]
         if not self.local:
             self.transport.bind(self.device)
-        mk = lambda r: Domain(self.grid, r, self.device, dtype, terms, cutoff, skin, A, B, engine_kwargs)  # noqa: E731
+        kind = DryDomain if self.dry else Domain
+        mk = lambda r: kind(self.grid, r, self.device, dtype, terms, cutoff, skin, A, B, engine_kwargs)  # noqa: E731
         self.domains = {r: mk(r) for r in ranks}
         self.migrations = 0
         self._recv_counts = {}
@@ -668,12 +726,16 @@ class DomainSet:
             else:  # reduced in place: the flag becomes the maximum over all ranks, which is what it is used for
                 t = self.transport.max_(next(iter(self.domains.values())).disp2)
             if self._host_ring is None:  # two pinned slots and events, reused alternately
-                self._host_ring = [(torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event())
-                                   for _ in range(2)]
+                if self.device.type == "cuda":
+                    self._host_ring = [(torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event())
+                                       for _ in range(2)]
+                else:  # (dry run on CPU tensors: nothing is asynchronous)
+                    done = SimpleNamespace(synchronize=lambda: None, record=lambda *a: None)
+                    self._host_ring = [(torch.empty(1, dtype=torch.float32), done) for _ in range(2)]
             self._ring_pos ^= 1
             host, ev = self._host_ring[self._ring_pos]
             host.copy_(t, non_blocking=True)
-            ev.record(torch.cuda.current_stream(self.device))
+            ev.record(torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None)
             self._pending = (ev, host, self._since_migration)
             if first_check:
                 # one synchronous look, so that a migration can be requested now already instead of two periods
@@ -819,11 +881,17 @@ class DomainSet:
         dt = timestep_fs / TIMEFACTOR
         code = L.dtype_code(self.dtype)
         gamma = gamma_ps / PICOSEC2TIMEU if gamma_ps is not None else 0.0
-        stream = lambda: torch.cuda.current_stream(self.device).cuda_stream  # noqa: E731
+        stream = lambda: torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None  # noqa: E731
         vnoise = float(np.sqrt(2.0 * gamma * BOLTZMAN * T * dt)) if T else 0.0
 
         def dd_step(d, phases):
             """phases 1: second half kick of the step that just got its forces; 2: first half of the next; 3: both."""
+            if self.dry:  # forces are zero: no kick; the drift and the running displacement maximum in torch
+                if phases & 2:
+                    d.pos.add_(d.vel, alpha=dt)
+                    if d.nown:
+                        d.disp2[0] = max(float(d.disp2[0]), float(((d.pos - d.ref) ** 2).sum(dim=1).max()))
+                return
             vc = 0
             if T and (phases & 1):
                 if getattr(d, "_vc_key", None) != (vnoise, d.nown):
@@ -834,7 +902,7 @@ class DomainSet:
                                        d.masses.data_ptr(), vc, dt, gamma, seed + 7919 * d.rank, max(self._nstep - 1, 0),
                                        phases, d.ref.data_ptr(), d.disp2.data_ptr(), stream()))
 
-        comm = None if self.local else self.transport.native()
+        comm = None if (self.local or self.dry) else self.transport.native()
 
         def run(remaining, first):
             if comm is not None:
