@@ -465,7 +465,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   __shared__ int s_eb[64], s_more[64];
   __shared__ unsigned s_bm[64];
   __shared__ __align__(16) int s_cnt[64];
-  __shared__ __align__(16) unsigned s_rowoff[64];  // byte offset of the atom's list row (= s_rec1[].w: the quad-read path below)
   const int apw_shift = 6 - lg.lpa_shift;
   const unsigned kmask = (unsigned)lg.lpa - 1u;
   // entry k of a row sits at byte ((k / (4 LPA)) << 10) + ((k % LPA) << 4) + (((k / LPA) % 4) << 2)  (list_slot); the
@@ -503,7 +502,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       ex.z = 1 < ne ? excl_idx[eb + 1] : -1;
       ex.w = (int)(rowoff * 4u);  // byte offset of the atom's list row
       s_rec1[lane] = ex;
-      s_rowoff[lane] = rowoff * 4u;
       long_rows = ne > EXS - 1;
     } else {
       // dummy atoms that pad the last batch of four: parked out of reach (never a hit, never a store)
@@ -512,7 +510,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       p.y = p.z = p.w = R(0);
       s_rec0[lane] = p;
       s_rec1[lane] = make_int4(-1, -1, -1, 0);
-      s_rowoff[lane] = 0u;
     }
     const bool any_long = __ballot(long_rows) != 0ull;
     s_bm[lane] = 0u;
@@ -619,78 +616,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
         // candidates that somebody in this block excludes (see s_bm); lanes past the end never hit anyway
         const unsigned bmw = s_bm[(oj & 2047u) >> 5];
         const unsigned long long special = __builtin_amdgcn_uicmp((bmw >> (oj & 31u)) & 1u, 0u, 33 /* ne */);
-        if constexpr (sizeof(R) == 4) {
-          // Round 5: the LDS pipe was this kernel's busiest unit (~70 %: 8.5e6 LDS instructions per build at C3, almost all of
-          // them 16-byte reads that hand the SAME record to all 64 lanes — 1 KB of LDS bandwidth per 16 useful bytes; ten of
-          // them per batch: four i records, four index / row records, the counters in and out).  Now lane l reads the record,
-          // the row offset and the counter of atom t + (l & 3) — ONE 16-byte and two 4-byte reads per batch, issued together
-          // (one LDS round trip) — and the value of atom u reaches every lane as a DPP operand (quad_perm [u, u, u, u], folded
-          // into the consuming VALU instruction).  The index records are only read for batches that meet a flagged candidate.
-          // Same arithmetic on the same values in the same order: the lists are identical bit for bit.
-          const unsigned q16 = ((unsigned)lane & 3u) << 4, q4 = ((unsigned)lane & 3u) << 2;
-          for (; t < ni; t += 4, recoff += 64u) {
-            const R4 P = *reinterpret_cast<const R4 *>(reinterpret_cast<const char *>(s_rec0) + recoff + q16);
-            const unsigned RO = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(s_rowoff) + (recoff >> 2) + q4);
-            const int CN = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_cnt) + (recoff >> 2) + q4);
-            // in_range() of atom t + U with the atom's record as DPP operands of the four instructions that consume it
-            // (the compiler's DPP combiner does not fold a builtin's v_mov_b32_dpp into them: 24 moves per batch)
-            auto in_range_q = [&](auto uc) -> unsigned long long {
-              constexpr int U = decltype(uc)::value;
-              float dx, dy, dz;
-              asm("v_sub_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "=v"(dx) : "v"(P.x), "v"(pj.x), "n"(U));
-              asm("v_sub_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "=v"(dy) : "v"(P.y), "v"(pj.y), "n"(U));
-              asm("v_sub_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "=v"(dz) : "v"(P.z), "v"(pj.z), "n"(U));
-              if constexpr (WSKIN) {
-                float reach;  // cutoff + s_i + s_j
-                asm("v_add_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "=v"(reach) : "v"(P.w), "v"(sj), "n"(U));
-                return wave_mask_le(dx * dx + dy * dy + dz * dz, reach * reach);
-              }
-              return wave_mask_le(dx * dx + dy * dy + dz * dz, rlist2);
-            };
-            using U0 = std::integral_constant<int, 0>;
-            using U1 = std::integral_constant<int, 1>;
-            using U2 = std::integral_constant<int, 2>;
-            using U3 = std::integral_constant<int, 3>;
-            unsigned long long m[4] = {in_range_q(U0{}), in_range_q(U1{}), in_range_q(U2{}), in_range_q(U3{})};
-            const unsigned long long any = m[0] | m[1] | m[2] | m[3];
-            if (!any) continue;
-            if (any & special) {  // rare: a flagged candidate is in range of one of the four
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff + 16u * u);
-                m[u] &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) | __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
-                          __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32));
-              }
-            }
-            int cnt[4];
-            auto emit = [&](auto uc) {
-              constexpr int u = decltype(uc)::value;
-              const unsigned base = (unsigned)__builtin_amdgcn_mov_dpp(CN, 0x55 * u, 0xF, 0xF, true);
-              // slot of this lane's hit (the counter is the start value of the prefix count), clamped to the row's last
-              // one: a row that overflows is reported through F_MAXN and its list thrown away (the caller grows the
-              // capacity and rebuilds), so what lands there is never used
-              const unsigned k = min(__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[u], base)),
-                                     vmaxn1);
-              // byte offset of entry k in the row: iteration kk = k / LPA, lane part k % LPA (list_slot's layout); the row's
-              // own offset joins last, as the DPP operand of the final add
-              unsigned rel = (k & vmask_hi) << sh_hi;
-              rel += (k & vmask_lo) << 4;
-              rel += __builtin_amdgcn_ubfe(k, (unsigned)lg.lpa_shift, 2u) << 2;
-              unsigned posb;
-              asm("v_add_u32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "=v"(posb) : "v"(RO), "v"(rel), "n"(u));
-              // only the lanes with a hit store: exec = the hit mask for the one instruction (every lane of the block is
-              // active here); a v_cndmask on an out-of-range offset would cost a half-rate VALU slot instead
-              asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_dword %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
-                           :: "v"(entry), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
-              cnt[u] = (int)base + (int)__popcll(m[u]);
-            };
-            emit(U0{});
-            emit(U1{});
-            emit(U2{});
-            emit(U3{});
-            *reinterpret_cast<int4 *>(&s_cnt[t]) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);  // every lane writes the same values
-          }
-        } else {
         for (; t < ni; t += 4, recoff += 64u) {
           const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
           unsigned long long m[4] = {in_range(p0), in_range(p1), in_range(p2), in_range(p3)};
@@ -711,18 +636,22 @@ __global__ __launch_bounds__(64) void build_list_kernel(
           int cnt[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
+            // slot of this lane's hit, clamped to the row's last one: a row that overflows is reported through F_MAXN
+            // and its list thrown away (the caller grows the capacity and rebuilds), so what lands there is never used
             const unsigned k = min((unsigned)base[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
                                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u)),
                                    vmaxn1);
+            // byte offset of entry k in the row: iteration kk = k / LPA, lane part k % LPA (list_slot's layout)
             unsigned posb = (unsigned)ex[u].w + ((k & vmask_hi) << sh_hi);
             posb += (k & vmask_lo) << 4;
             posb += __builtin_amdgcn_ubfe(k, (unsigned)lg.lpa_shift, 2u) << 2;
+            // only the lanes with a hit store: exec = the hit mask for the one instruction (every lane of the block is
+            // active here); a v_cndmask on an out-of-range offset would cost a half-rate VALU slot instead
             asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_dword %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
                          :: "v"(entry), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
             cnt[u] = base[u] + (int)__popcll(m[u]);
           }
           *reinterpret_cast<int4 *>(&s_cnt[t]) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);  // every lane writes the same values
-        }
         }
       }
       for (; t + 4 <= ni; t += 4, recoff += 64u) {  // (cells with long exclusion rows: the branching path)
