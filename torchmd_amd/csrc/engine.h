@@ -149,6 +149,32 @@ __device__ __forceinline__ void extent_note(int *ext, R x, R y, R z) {
     if (k[d] > ext[3 + d]) atomicMax(&ext[3 + d], k[d]);
   }
 }
+// The same for a whole wave at once (the placement kernels of a list build): after a re-plan the extent is empty and
+// EVERY atom widens it — 98 304 x 6 atomicMin/Max on the same six words took 127-167 us of scan_place_kernel at C3 (round
+// 5, profiles/r05_build_experiments.txt) against 13.7 us for the kernel on the rebuilds of an MD run.  Every lane of the wave
+// must call (`has`: the lane holds an atom); nothing but six compares and a ballot while no lane is outside the bounds.
+template <typename R>
+__device__ __forceinline__ void extent_note_wave(int *ext, bool has, R x, R y, R z) {
+  if (!ext) return;
+  const int k[3] = {extent_key((float)x), extent_key((float)y), extent_key((float)z)};
+  bool outside = false;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) outside = outside || (has && (k[d] < ext[d] || k[d] > ext[3 + d]));
+  if (__ballot(outside) == 0ull) return;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int lo = has ? k[d] : 0x7FFFFFFF, hi = has ? k[d] : (int)0x80000000;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o, 64));
+      hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (lo < ext[d]) atomicMin(&ext[d], lo);
+      if (hi > ext[3 + d]) atomicMax(&ext[3 + d], hi);
+    }
+  }
+}
 // true when some coordinate difference may reach 2.5 box edges (wave-uniform: scalar loads)
 template <typename R>
 __device__ __forceinline__ bool extent_needs_exact_image(const int *__restrict__ ext, const R *box) {
@@ -208,6 +234,13 @@ struct PlaceArgs {
   R vs_floor, vs_time, vs_cap;
   R *hs2_dyn;
   int *ext;
+  // the list build's own view of the atoms (round 5), written here so that the build kernel neither wraps positions nor
+  // loads four arrays per candidate: bsorted[slot] = {position folded into [0, box), the atom's half skin of this list
+  // (0 without per-atom skins)}, binfo[slot] = original index | LJ class << 27 (class 0 where the entries carry none)
+  typename Vec<R>::T4 *bsorted;
+  int *binfo;
+  R box[3], invbox[3];
+  int type_in_entry;
   // padded rows (fp32): the two dummy records behind the last atom, rewritten with every build (null: none)
   typename Vec<R>::T4 *dummy_a, *dummy_b;  // sorted + n of the target copy, and of the replica's second copy (or null)
   R dummy_pos[2][3];
@@ -219,6 +252,7 @@ struct PlaceArgs {
 constexpr unsigned kEntryOffMask = 0x07FFFFF0u;  // byte offset of atom j's float4 record
 constexpr int kEntryTypes = 32;                  // LJ classes that fit the entry's type field
 constexpr int kEntryTypeShift = 27;
+constexpr int kInfoIndexMask = 0x07FFFFFF;  // Replica::binfo: original index (< 2^23) below the LJ class field
 constexpr float kR2Floor = 1.0e-2f;  // (0.1 A)^2: keeps 1/r^14 finite for the self entries that pad a column
 
 // Padded list rows (Replica::pad_rows): the entry that fills the padding slots of atom `a`'s row — one of the two dummy
@@ -437,6 +471,7 @@ struct Replica {
   DevBuf members;  // two-launch binning: int32[ncell x kCellCap], the atoms of every cell in arrival order
   bool cell_cap_fallback = false;  // a cell overflowed `members` once: this replica bins with the four launches
   DevBuf sorted_hs;  // per-atom half skins in cell-sorted order (contexts with skin weights)
+  DevBuf bsorted, binfo;  // the build kernel's records (PlaceArgs): wrapped position + half skin, original index | LJ class
   DevBuf hs2_dyn;    // (half skin)^2 of the CURRENT list per atom, original order: what the displacement test uses
   const void *skin_vel = nullptr;  // velocities of this replica while tmdhip_md_run is enqueuing (velocity-dependent skins)
   // chain skipping (see ListCheck): host-mapped words {progress, near[2], rebuilds[2]}, sequence number of the last
@@ -469,7 +504,8 @@ struct Replica {
   DevBuf paircount;  // unsigned long long
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
-                      &nlist, &nneigh, &padgen, &members, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond})
+                      &nlist, &nneigh, &padgen, &members, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond,
+                      &bsorted, &binfo})
       b->release();
   }
 };

@@ -126,21 +126,22 @@ __global__ void fill_cells_kernel(int n, const int *__restrict__ cell_of, const 
 // atom at position `a` of the unsorted cell order -> its final slot (rank by original index inside the cell) and every
 // per-slot copy the pair kernels read
 template <typename R>
-__device__ __forceinline__ void place_atom_at(const PlaceArgs<R> &P, int me, int dst);
+__device__ __forceinline__ typename Vec<R>::T4 place_atom_at(const PlaceArgs<R> &P, int me, int dst);
 
+// (the caller notes the coordinate extent for its whole wave: extent_note_wave)
 template <typename R>
-__device__ __forceinline__ void place_atom(const PlaceArgs<R> &P, int a) {
+__device__ __forceinline__ typename Vec<R>::T4 place_atom(const PlaceArgs<R> &P, int a) {
   const int me = P.order_tmp[a];
   const int cidx = P.cell_of[me];
   const int s = P.cell_start[cidx], e = P.cell_start[cidx + 1];
   int rank = 0;
   for (int k = s; k < e; ++k) rank += P.order_tmp[k] < me;
-  place_atom_at<R>(P, me, s + rank);
+  return place_atom_at<R>(P, me, s + rank);
 }
 
 // atom `me` at its final slot `dst`: every per-slot copy the pair kernels read
 template <typename R>
-__device__ __forceinline__ void place_atom_at(const PlaceArgs<R> &P, int me, int dst) {
+__device__ __forceinline__ typename Vec<R>::T4 place_atom_at(const PlaceArgs<R> &P, int me, int dst) {
   P.order[dst] = me;
   P.inv[me] = dst;
   typename Vec<R>::T4 v;
@@ -149,8 +150,10 @@ __device__ __forceinline__ void place_atom_at(const PlaceArgs<R> &P, int me, int
   v.z = P.pos[3 * me + 2];
   v.w = P.qs[me];
   P.sorted[dst] = v;
-  extent_note<R>(P.ext, v.x, v.y, v.z);
-  P.stype[dst] = P.types[me];
+  const int ty = P.types[me];
+  P.stype[dst] = ty;
+  P.binfo[dst] = me | (P.type_in_entry ? ty << kEntryTypeShift : 0);
+  R hrec = R(0);
   if (P.half_skin) {
     // this list's half skin of the atom: its static share, or — inside an MD run, where the velocity is known —
     // a reduced floor plus the distance it covers in `vs_time` at its present speed, capped at vs_cap times the
@@ -164,10 +167,18 @@ __device__ __forceinline__ void place_atom_at(const PlaceArgs<R> &P, int me, int
     }
     P.sorted_hs[dst] = h;
     if (P.hs2_dyn) P.hs2_dyn[me] = h * h;
+    hrec = h;
   }
+  typename Vec<R>::T4 b;
+  b.x = wrap_into_box(v.x, P.box[0], P.invbox[0]);
+  b.y = wrap_into_box(v.y, P.box[1], P.invbox[1]);
+  b.z = wrap_into_box(v.z, P.box[2], P.invbox[2]);
+  b.w = hrec;
+  P.bsorted[dst] = b;
   P.ref[3 * me + 0] = v.x;
   P.ref[3 * me + 1] = v.y;
   P.ref[3 * me + 2] = v.z;
+  return v;
 }
 
 // dummy record `which` behind the last atom of the cell-sorted copies (padded rows, engine.h: pad_entry_for)
@@ -241,18 +252,25 @@ __global__ __launch_bounds__(256) void scan_place_kernel(int n, int ncell, const
     for (int k = t; k <= ncell; k += 256) cell_start_out[k] = s_start[k];
   if (blockIdx.x == 0 && t < 2) place_dummy<R>(P, t);
   const int me = blockIdx.x * blockDim.x + t;
-  if (me >= n) return;
-  const int cidx = P.cell_of[me];
-  const int cnt = min(count[cidx], kCellCap);
-  const int *m = members + (size_t)cidx * kCellCap;
-  int rank = 0, seen = 0;
-  for (int k = 0; k < cnt; ++k) {
-    const int o = m[k];
-    rank += o < me;
-    seen |= o == me;
+  typename Vec<R>::T4 v{};
+  bool placed = false;
+  if (me < n) {
+    const int cidx = P.cell_of[me];
+    const int cnt = min(count[cidx], kCellCap);
+    const int *m = members + (size_t)cidx * kCellCap;
+    int rank = 0, seen = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const int o = m[k];
+      rank += o < me;
+      seen |= o == me;
+    }
+    // (an atom that did not fit its cell's member array is not placed: F_CELLCAP is set, the build is thrown away)
+    if (seen) {
+      v = place_atom_at<R>(P, me, s_start[cidx] + rank);
+      placed = true;
+    }
   }
-  if (!seen) return;  // (this atom did not fit its cell's member array: F_CELLCAP is set, the build is thrown away)
-  place_atom_at<R>(P, me, s_start[cidx] + rank);
+  extent_note_wave<R>(P.ext, placed, v.x, v.y, v.z);
 }
 
 template <typename R>
@@ -260,8 +278,9 @@ __global__ void place_sorted_kernel(int n, PlaceArgs<R> P, const int *flag) {
   if (*flag == 0) return;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a < 2) place_dummy<R>(P, a);
-  if (a >= n) return;
-  place_atom<R>(P, a);
+  typename Vec<R>::T4 v{};
+  if (a < n) v = place_atom<R>(P, a);
+  extent_note_wave<R>(P.ext, a < n, v.x, v.y, v.z);
 }
 
 // Binning of a small system in ONE launch of one block: count (LDS atomics), scan, fill and place — the work of
@@ -327,7 +346,12 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__rest
   for (int i = t; i < n; i += 1024) order_tmp[s_start[cell_of[i]] + slot[i]] = i;
   __threadfence_block();
   __syncthreads();  // order_tmp and cell_start are complete for the whole block
-  for (int a = t; a < n; a += 1024) place_atom<R>(P, a);
+  for (int a0 = 0; a0 < n; a0 += 1024) {  // (all lanes stay in the loop: the extent is noted wave by wave)
+    const int a = a0 + t;
+    typename Vec<R>::T4 v{};
+    if (a < n) v = place_atom<R>(P, a);
+    extent_note_wave<R>(P.ext, a < n, v.x, v.y, v.z);
+  }
   if (t < 2) place_dummy<R>(P, t);
 }
 
@@ -339,11 +363,14 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__rest
 // compaction.  Entry order per atom is fixed by the stencil order -> lists are bit-reproducible.
 // WSKIN: per-atom skins — pair (i, j) is listed when |d| <= cutoff + s_i + s_j (s = the atom's half skin: the
 // displacement it may reach before a rebuild, see ListCheck), instead of cutoff + skin for every pair.
-template <typename R, bool LOOP, bool WSKIN>
-__global__ __launch_bounds__(64) void build_list_kernel(
-    int n, const typename Vec<R>::T4 *__restrict__ sorted, const R *__restrict__ sorted_hs,
-    const int *__restrict__ stype,
-    const int *__restrict__ order, const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
+// LPAS: log2 of the lanes per atom of the list layout as a compile-time constant (3 = the C3 / water layout: the masks and
+// shifts of a hit's byte offset become literals — full-rate VALU, no registers), or -1: read from ListGeom.
+template <typename R, bool LOOP, bool WSKIN, int LPAS>
+// (fp32: held to seven waves per SIMD — 72 VGPRs; the allocator is one register over without the hint and spills 16 bytes
+// in the prologue with it — because all 6 859 cell blocks of C3 are then resident at once: 7 168 slots)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 7 : 1, 8))) void build_list_kernel(
+    int n, const typename Vec<R>::T4 *__restrict__ bsorted, const int *__restrict__ binfo,
+    const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
     int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split, int *__restrict__ count_zero) {
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       nlist, 0, (int)((((size_t)n + lg.apw - 1) / lg.apw) * (size_t)lg.maxn * lg.apw * 4u), 0x00020000);
   __shared__ int seg_start[128];
   __shared__ int seg_prefix[129];
-  __shared__ int seg_code[128];  // periodic image of the stencil cell: 2 bits per axis, 0:-L 1:0 2:+L
+  // (the periodic image of a segment's cells — 2 bits per axis, 0:-L 1:0 2:+L — rides in bits 24..29 of seg_start: start < 2^23)
   const int lane = threadIdx.x;
   int wmax = 0;
   unsigned long long dbg_work = 0;  // candidates x atoms over the block's cells (debug timeline only)
@@ -442,10 +469,8 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   }
   const int tot0 = __shfl(inc0, 63, 64);
   const int ncand = tot0 + __shfl(inc1, 63, 64);
-  seg_start[lane] = st2[0];
-  seg_start[lane + 64] = st2[1];
-  seg_code[lane] = code2[0];
-  seg_code[lane + 64] = code2[1];
+  seg_start[lane] = st2[0] | (code2[0] << 24);
+  seg_start[lane + 64] = st2[1] | (code2[1] << 24);
   seg_prefix[lane] = inc0 - cnt2[0];
   seg_prefix[lane + 64] = tot0 + inc1 - cnt2[1];
   if (lane == 0) seg_prefix[128] = ncand;
@@ -465,16 +490,21 @@ __global__ __launch_bounds__(64) void build_list_kernel(
   __shared__ int s_eb[64], s_more[64];
   __shared__ unsigned s_bm[64];
   __shared__ __align__(16) int s_cnt[64];
-  const int apw_shift = 6 - lg.lpa_shift;
-  const unsigned kmask = (unsigned)lg.lpa - 1u;
+  __shared__ __align__(16) unsigned s_rowoff[64];  // byte offset of the atom's list row (= s_rec1[].w; four of them are one 16-byte read)
+  const unsigned lpas = LPAS >= 0 ? (unsigned)LPAS : (unsigned)lg.lpa_shift;
+  const int apw_shift = 6 - (int)lpas;
+  const unsigned kmask = (1u << lpas) - 1u;
   // entry k of a row sits at byte ((k / (4 LPA)) << 10) + ((k % LPA) << 4) + (((k / LPA) % 4) << 2)  (list_slot); the
   // masks live in VGPRs (an SGPR operand halves the VALU rate)
-  unsigned vmask_hi, vmask_lo;
-  asm("v_mov_b32 %0, %1" : "=v"(vmask_hi) : "s"(~((4u << lg.lpa_shift) - 1u)));
-  asm("v_mov_b32 %0, %1" : "=v"(vmask_lo) : "s"(kmask));
-  unsigned vmaxn1;
-  asm("v_mov_b32 %0, %1" : "=v"(vmaxn1) : "s"((unsigned)lg.maxn - 1u));
-  const unsigned sh_hi = 8u - (unsigned)lg.lpa_shift;  // (k / (4 LPA)) << 10 == (k & ~(4 LPA - 1)) << (10 - 2 - lpa_shift)
+  unsigned vmask_hi = ~((4u << lpas) - 1u), vmask_lo = kmask;
+  if constexpr (LPAS < 0) {  // run-time layout: the masks live in VGPRs (an SGPR operand halves the VALU rate)
+    asm("v_mov_b32 %0, %1" : "=v"(vmask_hi) : "s"(~((4u << lpas) - 1u)));
+    asm("v_mov_b32 %0, %1" : "=v"(vmask_lo) : "s"(kmask));
+  }
+  unsigned vmaxn1 = (unsigned)lg.maxn - 1u;  // (LPAS >= 0: an SGPR operand of one v_min per hit row — the register it would
+                                             // take as a VGPR is the one that decides between six and seven waves per SIMD)
+  if constexpr (LPAS < 0) asm("v_mov_b32 %0, %1" : "=v"(vmaxn1) : "s"((unsigned)lg.maxn - 1u));
+  const unsigned sh_hi = 8u - lpas;  // (k / (4 LPA)) << 10 == (k & ~(4 LPA - 1)) << (10 - 2 - lpa_shift)
   for (int ib = cs; ib < ce; ib += 64) {  // blocks of up to 64 atoms i of this cell (usually one)
     const int iend = min(ib + 64, ce);
     const int ni = iend - ib;
@@ -482,14 +512,11 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     int long_rows = 0;
     if (lane < ni) {
       const int a = ib + lane;
-      R4 p = sorted[a];
-      p.x = wrap_into_box(p.x, c.box[0], c.invbox[0]);
-      p.y = wrap_into_box(p.y, c.box[1], c.invbox[1]);
-      p.z = wrap_into_box(p.z, c.box[2], c.invbox[2]);
+      R4 p = bsorted[a];  // (already folded into the box; .w = the atom's half skin)
       const unsigned rowoff = (((unsigned)(a >> apw_shift) * (unsigned)lg.maxn) << apw_shift) +
-                              ((unsigned)(a & (lg.apw - 1)) << (lg.lpa_shift + 2));
-      p.w = WSKIN ? rcut + sorted_hs[a] : R(0);
-      const int oi = order[a];
+                              ((unsigned)(a & ((1 << apw_shift) - 1)) << (lpas + 2));
+      p.w = WSKIN ? rcut + p.w : R(0);
+      const int oi = binfo[a] & kInfoIndexMask;
       // passive atoms (original index >= nactive: halo images of a domain) get no list: parked out of reach
       if (oi >= nactive) p.x = (R)-1e18;
       const int eb = excl_off[oi], ne = excl_off[oi + 1] - eb;
@@ -502,6 +529,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       ex.z = 1 < ne ? excl_idx[eb + 1] : -1;
       ex.w = (int)(rowoff * 4u);  // byte offset of the atom's list row
       s_rec1[lane] = ex;
+      s_rowoff[lane] = rowoff * 4u;
       long_rows = ne > EXS - 1;
     } else {
       // dummy atoms that pad the last batch of four: parked out of reach (never a hit, never a store)
@@ -510,6 +538,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       p.y = p.z = p.w = R(0);
       s_rec0[lane] = p;
       s_rec1[lane] = make_int4(-1, -1, -1, 0);
+      s_rowoff[lane] = 0u;
     }
     const bool any_long = __ballot(long_rows) != 0ull;
     s_bm[lane] = 0u;
@@ -531,41 +560,169 @@ __global__ __launch_bounds__(64) void build_list_kernel(
     // candidate stream, software-pipelined: the three global loads of chunk q0 + 64 are issued before
     // chunk q0 is processed, so their latency overlaps the i loop instead of stalling the wave at the
     // top of every chunk (the build is latency-bound: PMC showed VALU busy 57 %)
-    R4 nx_p;
-    R nx_hs = 0;
-    int nx_j = cs, nx_code = 0, nx_order = 0, nx_type = 0;
+    R4 nx_p;  // {wrapped position, half skin}
+    int nx_j = cs, nx_code = 0, nx_info = 0;
     bool nx_valid = false;
+    // (Round 5 also tried the prefetch straight into LDS — `buffer_load ... lds`, no prefetch registers, no copies at the end
+    // of an iteration: 163 us per build against 149 with the registers; profiles/r05_build_experiments.txt.)
     auto fetch = [&](int q0) {
       const int q = q0 + lane;
       nx_valid = q < ncand;
       nx_j = cs;
-      if (nx_valid) {  // last s with seg_prefix[s] <= q
-        while (seg_prefix[seg + 1] <= q) ++seg;
-        nx_j = seg_start[seg] + (q - seg_prefix[seg]);
-      }
-      nx_code = seg_code[seg];
-      nx_p = sorted[nx_j];
-      nx_order = order[nx_j];
-      nx_type = stype[nx_j];
-      if constexpr (WSKIN) nx_hs = sorted_hs[nx_j];
+      if (nx_valid) while (seg_prefix[seg + 1] <= q) ++seg;  // last s with seg_prefix[s] <= q
+      const int packed = seg_start[seg];
+      nx_code = packed >> 24;
+      if (nx_valid) nx_j = (packed & 0x00FFFFFF) + (q - seg_prefix[seg]);
+      nx_p = bsorted[nx_j];
+      nx_info = binfo[nx_j];
     };
+    // ---- candidate prefilter (round 5) ------------------------------------------------------------------------------
+    // Only a quarter of the (atom, candidate) tests of a (2m+1)^3 stencil hit, and the build is instruction bound (debug
+    // builds, profiles/r05_build_experiments.txt): every 64-candidate chunk costs each batch of four atoms ~130 instructions
+    // whether anything is in range or not.  A candidate that lies further from the BOUNDING BOX of this block's atoms than
+    // the block's largest reach (+ its own half skin) can hit none of them: 44 % of the stream at C3.  The survivors are
+    // compacted ACROSS chunks, in stream order — so every list is the same list, entry for entry — and the batch loop runs
+    // on dense chunks: 16 instead of 28 per cell.  The compaction needs no LDS memory: ds_permute_b32 (a forward lane
+    // permutation through the LDS crossbar) pushes the kept lanes of a chunk behind the `pending` survivors of the
+    // previous ones; what wraps around the 64 lanes starts the next dense chunk.
+    R blo[3], bhi[3], breach;
+    {
+      const R4 p = s_rec0[lane];
+      const bool real = lane < ni && p.x > (R)-1e17;  // (passive atoms — halo rows of a brick — are parked out of reach: they list nothing)
+      const R big = (R)1e18;
+      R v[7] = {real ? p.x : big,  real ? p.y : big,  real ? p.z : big,
+                real ? p.x : -big, real ? p.y : -big, real ? p.z : -big, real ? p.w : R(0)};
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = min(v[k], __shfl_xor(v[k], o, 64));
+#pragma unroll
+        for (int k = 3; k < 7; ++k) v[k] = max(v[k], __shfl_xor(v[k], o, 64));
+      }
+      // (wave-uniform after the butterfly: into scalar registers — the build runs at seven waves per SIMD on 72 VGPRs)
+      auto uniform = [](R x) {
+        if constexpr (sizeof(R) == 4) {
+          return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+        } else {
+          const long long b = __double_as_longlong(x);
+          const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b >> 32));
+          return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        blo[k] = uniform(v[k]);
+        bhi[k] = uniform(v[3 + k]);
+      }
+      breach = uniform(v[6]);
+    }
+    // one value of any 4- or 8-byte type to lane `dest4 / 4` (every lane sends, the destinations are a permutation)
+    auto push = [&](auto val, int dest4) {
+      using T = decltype(val);
+      if constexpr (sizeof(T) == 4) {
+        int w;
+        __builtin_memcpy(&w, &val, 4);
+        w = __builtin_amdgcn_ds_permute(dest4, w);
+        T out;
+        __builtin_memcpy(&out, &w, 4);
+        return out;
+      } else {
+        int w[2];
+        __builtin_memcpy(w, &val, 8);
+        w[0] = __builtin_amdgcn_ds_permute(dest4, w[0]);
+        w[1] = __builtin_amdgcn_ds_permute(dest4, w[1]);
+        T out;
+        __builtin_memcpy(&out, w, 8);
+        return out;
+      }
+    };
+    // survivors waiting for a full chunk: lanes [0, pending)
+    R a_x = R(0), a_y = R(0), a_z = R(0);
+    R a_s = R(0);
+    unsigned a_entry = 0u;
+    int pending = 0;  // wave-uniform
     fetch(0);
-    for (int q0 = 0; q0 < ncand; q0 += 64) {
-      R4 pj = nx_p;
-      const R sj = nx_hs;
-      const int j = nx_j, code = nx_code;
-      const bool valid = nx_valid;
-      const unsigned oj = (unsigned)nx_order;
-      const unsigned entry = ((unsigned)j << 4) | (type_in_entry ? (unsigned)nx_type << kEntryTypeShift : 0u);
-      if (q0 + 64 < ncand) fetch(q0 + 64);
-      // candidate position as the periodic image that lies next to this cell: the i loop then needs
-      // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
-      // the reference's rounding; the pair kernel's cutoff test does).  Lanes past the end of the
-      // candidate list are parked far away so that they can never hit.
-      pj.x = wrap_into_box(pj.x, c.box[0], c.invbox[0]) + (R)((code & 3) - 1) * c.box[0];
-      pj.y = wrap_into_box(pj.y, c.box[1], c.invbox[1]) + (R)(((code >> 2) & 3) - 1) * c.box[1];
-      pj.z = wrap_into_box(pj.z, c.box[2], c.invbox[2]) + (R)(((code >> 4) & 3) - 1) * c.box[2];
-      if (!valid) pj.x = (R)1e18;
+    for (int q0 = 0; q0 < ncand || pending > 0; q0 += 64) {
+      const bool have = q0 < ncand;  // (one more round behind the last chunk flushes what is pending)
+      R w_x = R(0), w_y = R(0), w_z = R(0), w_s = R(0);  // this round's push: what wraps around the 64 lanes starts the next chunk
+      unsigned w_entry = 0u;
+      int total = pending;
+      if (have) {
+        const R4 rec = nx_p;
+        const int info = nx_info;
+        const R isj = rec.w;
+        R ipx = rec.x, ipy = rec.y, ipz = rec.z;
+        const int j = nx_j, code = nx_code;
+        const bool valid = nx_valid;
+        const unsigned ioj = (unsigned)info & (unsigned)kInfoIndexMask;
+        // (bit 0 of an entry is free — the pair kernels mask it: here it carries "somebody in this block excludes this
+        // candidate" (s_bm) through the compaction, and is cleared before the entry is stored)
+        const unsigned iflag = any_long ? 1u : (s_bm[(ioj & 2047u) >> 5] >> (ioj & 31u)) & 1u;
+        const unsigned ientry = ((unsigned)j << 4) | ((unsigned)info & ~(unsigned)kInfoIndexMask) | iflag;
+        if (q0 + 64 < ncand) fetch(q0 + 64);
+        // candidate position as the periodic image that lies next to this cell: the i loop then needs
+        // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
+        // the reference's rounding; the pair kernel's cutoff test does).
+        ipx += (R)((code & 3) - 1) * c.box[0];
+        ipy += (R)(((code >> 2) & 3) - 1) * c.box[1];
+        ipz += (R)(((code >> 4) & 3) - 1) * c.box[2];
+        // distance to the block's bounding box against the block's largest reach (a hair of slack for the rounding of the
+        // two different expressions: a candidate this filter drops must fail every atom's own test)
+        const R ex = max(max(blo[0] - ipx, ipx - bhi[0]), R(0)), ey = max(max(blo[1] - ipy, ipy - bhi[1]), R(0)),
+                ez = max(max(blo[2] - ipz, ipz - bhi[2]), R(0));
+        R lim;
+        if constexpr (WSKIN) {
+          const R rr = breach + isj;
+          lim = rr * rr * (R)1.00001;
+        } else {
+          lim = rlist2 * (R)1.00001;
+        }
+        const unsigned long long keep = wave_mask_le(ex * ex + ey * ey + ez * ez, valid ? lim : (R)-1);
+        const int cnew = (int)__popcll(keep);
+        // forward permutation: the kept lanes to [pending, pending + cnew), the others behind them (mod 64)
+        const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, 0u));
+        const bool kept = __builtin_amdgcn_inverse_ballot_w64(keep);
+        const int dest4 = (int)((((unsigned)pending + (kept ? pre : (unsigned)cnew + ((unsigned)lane - pre))) & 63u) << 2);
+        w_x = push(ipx, dest4);
+        w_y = push(ipy, dest4);
+        w_z = push(ipz, dest4);
+        if constexpr (WSKIN) w_s = push(isj, dest4);
+        w_entry = push(ientry, dest4);
+        // the new survivors join the buffer behind the pending ones
+        const bool from_buffer = lane < pending;
+        a_x = from_buffer ? a_x : w_x;
+        a_y = from_buffer ? a_y : w_y;
+        a_z = from_buffer ? a_z : w_z;
+        if constexpr (WSKIN) a_s = from_buffer ? a_s : w_s;
+        a_entry = from_buffer ? a_entry : w_entry;
+        total = __builtin_amdgcn_readfirstlane(pending + cnew);  // (wave-uniform: keeps the loop control on the scalar unit)
+        if (total < 64) {  // not a full chunk yet
+          pending = total;
+          continue;
+        }
+      }
+      // a dense chunk in the buffer's lanes [0, min(total, 64)) (the last one of a block may be partial: its lanes past
+      // the end are parked far away so that they can never hit)
+      R4 pj;
+      pj.x = a_x;
+      pj.y = a_y;
+      pj.z = a_z;
+      pj.w = R(0);
+      const R sj = a_s;
+      const bool parked = lane >= min(total, 64);
+      if (parked) pj.x = (R)1e18;
+      const unsigned entry = a_entry & ~1u;
+      // the original index of a flagged candidate (exclusion compares): gathered only by the chunks that hold one
+      const unsigned long long special = __builtin_amdgcn_uicmp(parked ? 0u : (a_entry & 1u), 0u, 33 /* ne */);  // (a wave-wide mask)
+      unsigned oj = 0xFFFFFFFFu;
+      if (special) oj = (unsigned)binfo[(a_entry >> 4) & 0x7FFFFFu] & (unsigned)kInfoIndexMask;
+      // what wrapped around the 64 lanes is the start of the next chunk (w_* stay live through the batch loop)
+      struct Carry {
+        R x, y, z, s;
+        unsigned entry;
+        int pending;
+      } carry{w_x, w_y, w_z, w_s, w_entry, total >= 64 ? total - 64 : 0};
       // exclusions, compaction and store of the hits of atom t (mask = lanes whose candidate is in range)
       auto handle = [&](int t, unsigned roff, const R4 &pi, unsigned long long mask) {
         const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + roff);
@@ -583,7 +740,7 @@ __global__ __launch_bounds__(64) void build_list_kernel(
                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
           const unsigned rowoff = (unsigned)ex.w >> 2;
-          const unsigned kk = k >> lg.lpa_shift;
+          const unsigned kk = k >> lpas;
           nlist[rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u)] = entry;
         }
         s_cnt[t] = base + (int)__popcll(mask);  // every lane writes the same value
@@ -613,9 +770,6 @@ __global__ __launch_bounds__(64) void build_list_kernel(
       // exec.  Atoms with long exclusion rows (proteins) keep the branching path.
       // The last batch is padded with parked dummy atoms (staged above), so there is no scalar remainder loop.
       if (!any_long) {
-        // candidates that somebody in this block excludes (see s_bm); lanes past the end never hit anyway
-        const unsigned bmw = s_bm[(oj & 2047u) >> 5];
-        const unsigned long long special = __builtin_amdgcn_uicmp((bmw >> (oj & 31u)) & 1u, 0u, 33 /* ne */);
         for (; t < ni; t += 4, recoff += 64u) {
           const R4 p0 = rec0(recoff), p1 = rec0(recoff + 16u), p2 = rec0(recoff + 32u), p3 = rec0(recoff + 48u);
           unsigned long long m[4] = {in_range(p0), in_range(p1), in_range(p2), in_range(p3)};
@@ -623,28 +777,28 @@ __global__ __launch_bounds__(64) void build_list_kernel(
           if (!any) continue;
           const int4 base4 = *reinterpret_cast<const int4 *>(&s_cnt[t]);
           const int base[4] = {base4.x, base4.y, base4.z, base4.w};
-          int4 ex[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            ex[u] = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff + 16u * u);
+          const uint4 ro4 = *reinterpret_cast<const uint4 *>(&s_rowoff[t]);
+          const unsigned ro[4] = {ro4.x, ro4.y, ro4.z, ro4.w};
           if (any & special) {  // rare: a flagged candidate is in range of one of the four
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-              m[u] &= ~(__builtin_amdgcn_uicmp((unsigned)ex[u].x, oj, 32 /* eq */) | __builtin_amdgcn_uicmp((unsigned)ex[u].y, oj, 32) |
-                        __builtin_amdgcn_uicmp((unsigned)ex[u].z, oj, 32));
+            for (int u = 0; u < 4; ++u) {
+              const int4 ex = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(s_rec1) + recoff + 16u * u);
+              m[u] &= ~(__builtin_amdgcn_uicmp((unsigned)ex.x, oj, 32 /* eq */) | __builtin_amdgcn_uicmp((unsigned)ex.y, oj, 32) |
+                        __builtin_amdgcn_uicmp((unsigned)ex.z, oj, 32));
+            }
           }
           int cnt[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             // slot of this lane's hit, clamped to the row's last one: a row that overflows is reported through F_MAXN
             // and its list thrown away (the caller grows the capacity and rebuilds), so what lands there is never used
-            const unsigned k = min((unsigned)base[u] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u)),
+            // (the counter is the start value of the prefix count: one add less)
+            const unsigned k = min(__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[u], (unsigned)base[u])),
                                    vmaxn1);
             // byte offset of entry k in the row: iteration kk = k / LPA, lane part k % LPA (list_slot's layout)
-            unsigned posb = (unsigned)ex[u].w + ((k & vmask_hi) << sh_hi);
+            unsigned posb = ro[u] + ((k & vmask_hi) << sh_hi);
             posb += (k & vmask_lo) << 4;
-            posb += __builtin_amdgcn_ubfe(k, (unsigned)lg.lpa_shift, 2u) << 2;
+            posb += __builtin_amdgcn_ubfe(k, lpas, 2u) << 2;
             // only the lanes with a hit store: exec = the hit mask for the one instruction (every lane of the block is
             // active here); a v_cndmask on an out-of-range offset would cost a half-rate VALU slot instead
             asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_dword %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
@@ -667,6 +821,12 @@ __global__ __launch_bounds__(64) void build_list_kernel(
         const unsigned long long m0 = in_range(p0);
         if (m0) handle(t, recoff, p0, m0);
       }
+      a_x = carry.x;
+      a_y = carry.y;
+      a_z = carry.z;
+      a_s = carry.s;
+      a_entry = carry.entry;
+      pending = __builtin_amdgcn_readfirstlane(carry.pending);
     }
     __syncthreads();
     const int mycnt = s_cnt[lane];
@@ -737,6 +897,13 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
   P.vs_cap = (R)ctx->vskin_cap_len;
   P.hs2_dyn = T.hs2_dyn->as<R>();
   P.ext = rp.extent.as<int>();
+  P.bsorted = rp.bsorted.as<R4>();
+  P.binfo = rp.binfo.as<int>();
+  for (int k = 0; k < 3; ++k) {
+    P.box[k] = c.box[k];
+    P.invbox[k] = c.invbox[k];
+  }
+  P.type_in_entry = ctx->d.ntypes <= kEntryTypes;
   P.dummy_a = P.dummy_b = nullptr;
   if (rp.pad_rows) {
     P.dummy_a = T.sorted->as<R4>() + n;
@@ -777,20 +944,27 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
                                          // MD step at split 1, 2, 4): 29.7 27.7 (28-37) / 37.8 35.5 35.0 / 43.0 44.6 48.3
   if (rp.ncell > kMaxBuildBlocks) split = 1;
   auto launch_build = [&](auto kernel, int blocks) {
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st_build, n, T.sorted->as<R4>(), T.sorted_hs->as<R>(),
-                       T.stype->as<int>(), T.order->as<int>(), T.cell_start->as<int>(), rp.grid, c, rl * rl,
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st_build, n, rp.bsorted.as<R4>(), rp.binfo.as<int>(),
+                       T.cell_start->as<int>(), rp.grid, c, rl * rl,
                        (R)ctx->d.cutoff, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, T.nlist->as<unsigned>(),
                        T.nneigh->as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes,
                        debug_timeline_buffer(blocks), split,
                        (bin2 && !(prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells)) ? T.count->as<int>() : nullptr);
   };
-  if (rp.ncell <= kMaxBuildBlocks) {
-    if (wskin) launch_build(build_list_kernel<R, false, true>, rp.ncell * split);
-    else launch_build(build_list_kernel<R, false, false>, rp.ncell * split);
-  } else {
-    if (wskin) launch_build(build_list_kernel<R, true, true>, kMaxBuildBlocks);
-    else launch_build(build_list_kernel<R, true, false>, kMaxBuildBlocks);
+#define TMD_BUILD(LOOPED, BLOCKS)                                                                   \
+  if (rp.lg.lpa_shift == 3) {                                                                      \
+    if (wskin) launch_build(build_list_kernel<R, LOOPED, true, 3>, BLOCKS);                        \
+    else launch_build(build_list_kernel<R, LOOPED, false, 3>, BLOCKS);                             \
+  } else {                                                                                         \
+    if (wskin) launch_build(build_list_kernel<R, LOOPED, true, -1>, BLOCKS);                       \
+    else launch_build(build_list_kernel<R, LOOPED, false, -1>, BLOCKS);                            \
   }
+  if (rp.ncell <= kMaxBuildBlocks) {
+    TMD_BUILD(false, rp.ncell * split)
+  } else {
+    TMD_BUILD(true, kMaxBuildBlocks)
+  }
+#undef TMD_BUILD
   TMD_HIP(hipGetLastError());
   return 0;
 }
