@@ -656,9 +656,11 @@ def test_fused_launch_timeout_falls_back_to_the_integrator_kernel(monkeypatch):
     assert st0["fused_step_timeouts"] == 0 and st0["steps_in_pair_launch"] == 0
     assert torch.isfinite(p1).all()
     assert torch.equal(p1, p0) and torch.equal(v1, v0) and torch.equal(f1, f0)
+    # (observables: the fused run's last launch sums the bonded and kinetic energies in its step blocks, the unfused one in
+    # the bonded / kinetic-energy kernels — the same terms in another order)
     for a, b in zip(r1, r0):
         for x, y in zip(a, b):
-            assert np.array_equal(np.asarray(x), np.asarray(y)), (a, b)
+            assert np.allclose(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), rtol=1e-6, atol=0), (a, b)
 
 
 @pytest.mark.gpu
@@ -734,9 +736,90 @@ def test_step_blocks_of_the_pair_launch_are_bit_identical(case, monkeypatch):
         assert st["n_rebuilds"] == su["n_rebuilds"] and st["chains_skipped"] == su["chains_skipped"]
     assert torch.isfinite(p1).all()
     assert torch.equal(p1, p0) and torch.equal(v1, v0) and torch.equal(f1, f0)
+    # (observables: the fused run's last launch sums the bonded and kinetic energies in its FINAL step blocks, the unfused
+    # one in the bonded / kinetic-energy kernels — the same fp64 terms in another order; Ekin and T are returned in fp32)
     for a, b in zip(r1, r0):
         for x, y in zip(a, b):
-            assert np.array_equal(np.asarray(x), np.asarray(y))
+            assert np.allclose(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), rtol=1e-6, atol=0), (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["water_langevin", "water_nve", "lj_langevin", "thrombin"])
+def test_final_step_of_a_call_in_the_pair_launch(case, monkeypatch):
+    """The LAST step of a step() call (reference integrator.py:116-125: forces, second half kick, then the energies and
+    the kinetic energy the call returns) is made by the last pair launch itself: FINAL step blocks (csrc/md_step.h) apply
+    the kick, leave pair + bonded force in `forces`, and sum the bonded and kinetic energies — instead of a bonded
+    kernel, a kick kernel and a kinetic-energy kernel behind the launch (TMDHIP_FUSED_FINAL=0 keeps those).  Same device
+    functions in the same order: positions, velocities and forces equal bit for bit after calls of 1, 2, 19 and 7 steps;
+    energies are the same fp64 terms summed in another order (1e-12), Ekin / T come back in fp32."""
+    from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = _dev(), torch.float32
+    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    if case == "thrombin":
+        g = load("thrombin")
+        par = GoldenParameters(g, dt)
+        pos, box = np.asarray(g["pos"], dtype=np.float64), np.zeros(3)
+        terms = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+        kw = dict(cutoff=9.0)
+    elif case.startswith("water"):
+        mol, pos, box = tip3p_box(14, seed=4)  # 8 232 atoms
+        terms = ["lj", "electrostatics", "bonds", "angles"]
+        par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+        kw = dict(cutoff=9.0, rfa=True)
+    else:
+        mol, pos, box = lj_box(22, seed=4)  # 10 648 atoms
+        terms = ["lj"]
+        par = Parameters(argon_forcefield(mol), mol, terms, precision=dt)
+        kw = dict(cutoff=9.0)
+    gamma = None if case == "water_nve" else 1.0
+    monkeypatch.setenv("TMDHIP_LPA", "64" if case == "thrombin" else ("8" if case.startswith("water") else "4"))
+    torch.manual_seed(3)
+    vel0 = maxwell_boltzmann(par.masses, 300.0, 1)
+
+    def run(final):
+        monkeypatch.setenv("TMDHIP_FUSED_FINAL", "1" if final else "0")
+        s = System(pos.shape[0], 1, dt, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        s.set_velocities(vel0)
+        f = Forces(par, terms=terms, algorithm="celllist", **kw)
+        f.compute(s.pos, s.box, s.forces)
+        torch.manual_seed(9)
+        integ = Integrator(s, f, 1.0, dev, gamma=gamma, T=300.0 if gamma else None)
+        res, snaps = [], []
+        for k in (1, 2, 19, 7):
+            res.append(integ.step(k))
+            snaps.append((s.pos.cpu().clone(), s.vel.cpu().clone(), s.forces.cpu().clone()))
+        st = f.stats(s.pos)
+        f.close()
+        return res, snaps, st
+
+    r1, s1, st1 = run(True)
+    r0, s0, st0 = run(False)
+    assert st1["overflow"] == 0 and st1["fused_step_timeouts"] == 0 and st1["steps_in_pair_launch"] == st0["steps_in_pair_launch"] == 25
+    for (p1, v1, f1), (p0, v0, f0) in zip(s1, s0):
+        assert torch.isfinite(p1).all()
+        assert torch.equal(p1, p0) and torch.equal(v1, v0) and torch.equal(f1, f0)
+    for a, b in zip(r1, r0):
+        ek1, pot1, T1 = a
+        ek0, pot0, T0 = b
+        assert np.allclose(pot1, pot0, rtol=1e-12, atol=1e-9), (pot1, pot0)
+        assert np.allclose(ek1, ek0, rtol=2e-7) and np.allclose(T1, T0, rtol=2e-7), (ek1, ek0)
+    # the energies the fused call returns are those of a fresh evaluation at the final positions
+    s = System(pos.shape[0], 1, dt, dev)
+    s.pos.copy_(s1[-1][0].to(dev))
+    s.set_box(box)
+    f = Forces(par, terms=terms, algorithm="celllist", **kw)
+    F = torch.zeros_like(s.pos)
+    e = f.compute(s.pos, s.box, F)
+    assert abs(e[0] - r1[-1][1][0]) <= 3e-5 * max(1.0, abs(e[0])), (e, r1[-1][1])
+    assert (F.cpu() - s1[-1][2]).abs().max().item() < 6e-4
+    f.close()
 
 
 @pytest.mark.gpu

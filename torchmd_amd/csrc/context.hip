@@ -345,8 +345,9 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     fl = *fused;
     fl.step.parity = (int)(rp.step & 1);
   }
-  if (flags & TMDHIP_WANT_ENERGY)
-    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1, lmode, nullptr, !(flags & kDeferFold))));
+  if (flags & TMDHIP_WANT_ENERGY)  // (fused: the final step of an MD call — md_run folds the scratch rows, with the kinetic energy)
+    TMD_TRY((launch_list_pair<R, true>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1, lmode, fused ? &fl : nullptr,
+                                       !(flags & kDeferFold) && !fused)));
   else
     TMD_TRY((launch_list_pair<R, false>(ctx, rp, c, f, overwrite, energies, pc, st, e0, e1, lmode, fused ? &fl : nullptr)));
   if (pc) TMD_TRY(halve_pair_count(pc, st));

@@ -535,6 +535,10 @@ struct tmdhip_ctx {
   // out twice stops fusing for good (`fused_disabled`): the hand-over's in-order-dispatch assumption does not hold here.
   bool no_fused_once = false, fused_off_call = false, fused_disabled = false;
   int64_t fused_step_timeouts = 0;
+  // the last step of the last tmdhip_md_run was made by FINAL step blocks (md_step.h): the kinetic energy of the velocities
+  // `ke_from_run` points at is in obs_ke already (tmdhip_md_observe then launches no kinetic-energy kernel)
+  const void *ke_from_run = nullptr;
+  int64_t final_steps_in_pair_launch = 0;
   // velocity-dependent skins inside tmdhip_md_run (place_sorted_kernel): s_i = min(floor * static_i + time * |v_i|, cap)
   double vskin_floor = 0.8, vskin_time = 0, vskin_cap = 1.2, vskin_cap_len = 0;
   double mean_list_scale = 1;  // mean list length / length of a list at the largest pair radius (per-atom skins)

@@ -248,6 +248,10 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   std::vector<R *> cur(nrep);
   std::vector<char> owed(nrep, 0);
   std::vector<char> stepped(nrep, 0);  // the previous pair launch of the replica has made this iteration's step (FusedStep)
+  std::vector<char> finalized(nrep, 0);  // the last pair launch made the call's final kick, bonded force and energies itself (FINAL step blocks)
+  ctx->ke_from_run = nullptr;
+  const char *e_final = std::getenv("TMDHIP_FUSED_FINAL");  // (A/B, tests: 0 = the separate kernels behind the last pair launch)
+  const bool final_on = !(e_final && std::atoi(e_final) == 0);
   for (int r = 0; r < nrep; ++r) cur[r] = (R *)d->pos_dev + r * stride;
   // the same for the replica-batched all-pairs mode (all replicas move together)
   R *const home_all = (R *)d->pos_dev;
@@ -394,7 +398,9 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       std::memset(&A, 0, sizeof(A));
       const bool was_stepped = stepped[r] != 0;
       stepped[r] = 0;
-      if (was_stepped) {
+      if (finalized[r]) {
+        // (it == niter: the final kick was made by the step blocks of the last pair launch)
+      } else if (was_stepped) {
         // kicks, drift, displacement test and cell-sorted records of this iteration: done by the previous pair
         // launch's epilogue (cur[r] and rp.sorted already point at its output)
       } else if (owed[r]) {
@@ -440,16 +446,21 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
           FusedLaunchT<R> fl{};
           bool fuse = false;
           {
-            const int bm = (check && it + 1 < d->niter && !en && fused_step_possible<R>(ctx, rp, c))
+            // interior steps: the launch makes the next step; the last step of a call that wants energies (one replica):
+            // the launch makes the final kick, the bonded force + energies and the kinetic energy (FINAL step blocks)
+            const bool interior = it + 1 < d->niter && !en;
+            const bool final_step = it + 1 == d->niter && en && nrep == 1 && final_on && std::is_same<R, float>::value;
+            const int bm = (check && (interior || final_step) && fused_step_possible<R>(ctx, rp, c))
                                ? tmd::bonded_inline_args(ctx, box, A) : -1;
             if (bm >= 0) {
               if (bm == 2) {
                 // heavy topology: the bonded force depends on the positions only — it is evaluated in front of the
                 // pair launch into a buffer of its own and the step blocks add it (same values, same order as the
                 // separate kernels: pair force stored, bonded force added, divided by the mass)
+                // (the final step: with its energies, which the bonded kernel folds into the call's buffer itself)
                 TMD_TRY(rp.fbond.ensure(sizeof(R) * stride));
-                TMD_TRY(tmdhip_compute_bonded(ctx, r, pos, box, rp.fbond.p, nullptr,
-                                              TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES, st));
+                TMD_TRY(tmdhip_compute_bonded(ctx, r, pos, box, rp.fbond.p, en,
+                                              TMDHIP_WANT_FORCES | TMDHIP_OVERWRITE_FORCES | (en ? TMDHIP_WANT_ENERGY : 0), st));
               }
               FusedStaticT<R> now;
               std::memset(&now, 0, sizeof(now));
@@ -499,12 +510,24 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
                                              (en && !fuse && rp.have_list && tmd::bonded_inline_args(ctx, box, A) != 0 ? kDeferFold : 0),
                                          st, fuse ? &fl : nullptr);
           rp.pub_ptr = nullptr;
+          if (fuse && rc == 0 && en) {
+            // the call's last step: forces (pair + bonded) are in `forces`, velocities kicked, the energy rows (pair,
+            // bonded, kinetic) folded here — into the call's energy buffer and the context's kinetic-energy word
+            TMD_TRY(ctx->obs_ke.ensure(sizeof(double) * ctx->rep.size()));
+            hipLaunchKernelGGL(final_fold_kernel, dim3(1), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), en,
+                               ctx->obs_ke.as<double>());
+            TMD_HIP(hipGetLastError());
+            finalized[r] = 1;
+            ctx->ke_from_run = d->vel_dev;
+            ctx->final_steps_in_pair_launch++;
+            continue;
+          }
           if (fuse && rc == 0) {
             cur[r] = fl.step.pos_out;
             std::swap(rp.sorted, rp.sorted_alt);
             stepped[r] = 1;
             rp.steps_in_pair_launch++;
-            continue;  // forces of this step never reach `forces`: the last step of the call is never fused
+            continue;  // forces of this step never reach `forces`
           }
           if (rc == kFallbackAllPairs) {
             ctx->algorithm = TMDHIP_ALGO_ALLPAIRS;
@@ -610,7 +633,12 @@ int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev
   double *he = (double *)ctx->obs_host, *hk = he + TMDHIP_NENERGY * nrep;
   int *hf = (int *)((char *)ctx->obs_host + ebytes + kbytes);
   volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->obs_host + ebytes + kbytes + fbytes + 32);
-  TMD_TRY(tmdhip_kinetic_energy(ctx->d.dtype, (int64_t)nrep, ctx->d.natoms, vel_dev, mass_dev, ctx->obs_ke.as<double>(), stream));
+  if (ctx->ke_from_run == vel_dev && nrep == 1) {
+    // (the FINAL step blocks of the run that just ended have summed the kinetic energy of these velocities)
+  } else {
+    TMD_TRY(tmdhip_kinetic_energy(ctx->d.dtype, (int64_t)nrep, ctx->d.natoms, vel_dev, mass_dev, ctx->obs_ke.as<double>(), stream));
+  }
+  ctx->ke_from_run = nullptr;
   const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
   if (nrep <= 16) {
     TMD_TRY(publish_observables(ctx, energies_dev, ctx->obs_ke.as<double>(), lists, he, hk, hf, hseq, st));

@@ -31,7 +31,8 @@ __device__ __forceinline__ AtomIn<R> md_load_atom(const MdStepArgs<R> &s, int i,
 template <typename R, bool SECOND, bool LANGEVIN, bool FIRST, bool CHECK>
 __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairConsts<R> &c, int i, size_t off,
                                              uint64_t row0, const AtomIn<R> &x, const R (&fb)[3], bool add_fb,
-                                             const R *noise = nullptr) {  // noise: normal3 of this atom, drawn earlier
+                                             const R *noise = nullptr,  // noise: normal3 of this atom, drawn earlier
+                                             R *vout = nullptr) {       // the updated velocity (final step blocks: kinetic energy)
 #pragma clang fp contract(off)
   R *pos_out = s.pos_out + off, *vel = s.vel + off;
   const R m = x.m;
@@ -86,6 +87,10 @@ __device__ __forceinline__ void md_step_atom(const MdStepArgs<R> &s, const PairC
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) vel[3 * i + k] = v[k];
+  if (vout) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vout[k] = v[k];
+  }
 }
 
 // ---- the MD step inside a pair launch: step blocks (FusedStepT / FusedStaticT in engine.h) -----------------------------
@@ -113,10 +118,19 @@ __device__ __forceinline__ bool load_force_record(const __amdgpu_buffer_rsrc_t &
 // evaluates bonded record slots w, w + 4, ... of all 64 atoms (lane = atom), the partial forces meet in LDS as
 // (p0 + p1) + (p2 + p3), and the first wave updates — after it has waited for the pair waves of its atoms.
 // s_lds: room for kQuad x 3 x 64 values of R (the pair role's LJ table space).
-template <typename R, bool LANGEVIN, int APB>
+// FINAL (round 5): the step blocks of the LAST pair launch of a tmdhip_md_run call, which also wants the energies: no
+// drift follows, so the update is the second half kick (+ thermostat) only; the blocks also leave the complete force
+// (pair + bonded) in the caller's force array, the bonded energies of their atoms' records and the kinetic energy after
+// the kick in the energy scratch rows (slot kKineticSlot) — the work of the bonded kernel, the final-kick kernel and
+// the kinetic-energy kernel that used to follow the last pair launch of every call.  Same device functions in the
+// same order: velocities and forces are bit-identical to the separate kernels; the energies are sums of the same
+// terms in another order (fp64 atomics).
+constexpr int kKineticSlot = TMDHIP_NENERGY;  // (rows of kEnergyStride = 16 doubles: 8 per-term energies, then this)
+template <typename R, bool LANGEVIN, int APB, bool FINAL = false>
 __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restrict__ fst, const FusedStepT<R> &fs,
                                                   const PairConsts<R> &c, int n, const typename Vec<R>::T4 *__restrict__ sorted,
-                                                  const int *__restrict__ order, int j, int npair, R *s_lds) {
+                                                  const int *__restrict__ order, int j, int npair, R *s_lds,
+                                                  R *__restrict__ forces_out = nullptr, double *__restrict__ escratch = nullptr) {
   using R4 = typename Vec<R>::T4;
   constexpr int K = 64 / APB;  // pair blocks per 64 atoms
   R(*s_part)[3][64] = reinterpret_cast<R(*)[3][64]>(s_lds);  // [kQuad][3][64]
@@ -145,29 +159,31 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
   if (integrates) {  // every load of the update but the force, in flight during the bonded part
     x.m = s.mass[o];
     x.vc = LANGEVIN ? s.vcoeff[o] : R(0);
-    const R4 p = sorted[a];  // x, y, z, scaled charge: exactly what the position buffer holds
-    x.p[0] = p.x, x.p[1] = p.y, x.p[2] = p.z;
-    x.q = p.w;
+    if (!FINAL) {
+      const R4 p = sorted[a];  // x, y, z, scaled charge: exactly what the position buffer holds
+      x.p[0] = p.x, x.p[1] = p.y, x.p[2] = p.z;
+      x.q = p.w;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       x.v[k] = s.vel[3 * o + k];
-      x.r[k] = s.chk.ref[3 * o + k];
+      if (!FINAL) x.r[k] = s.chk.ref[3 * o + k];
     }
-    x.h2 = list_check_limit(s.chk, o);
+    if (!FINAL) x.h2 = list_check_limit(s.chk, o);
     x.slot = a;
   }
   R fb[3] = {0, 0, 0};
   R g[3] = {0, 0, 0};
   if (bonded) {
     R fx = 0, fy = 0, fz = 0;
+    double ef[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // (dead on interior steps: only FINAL reads them)
     if (exists) {
       const BondedArgs<R> A = fst->A;
-      double e[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // energies are not wanted on interior steps (dead)
       const AtomRec<R> *rec = A.arec + (size_t)o * A.arec_stride;
       for (int k = w; k < A.arec_stride; k += kQuad) {
         const AtomRec<R> r = rec[k];
         if (r.ent == kNoRec) break;  // records are packed from the front
-        eval_rec<R>(A, s.pos_in, o, r, fx, fy, fz, e);
+        eval_rec<R>(A, s.pos_in, o, r, fx, fy, fz, ef);
       }
     }
     s_part[w][0][lane] = fx;
@@ -175,6 +191,15 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
     s_part[w][2][lane] = fz;
     if (LANGEVIN && integrates) normal3<R>(s.seed, s.noise_step, s.row0 + (uint64_t)o, g[0], g[1], g[2]);
     __syncthreads();
+    if (FINAL && escratch) {  // the bonded energies of this wave's records (all four waves evaluate records; every lane takes part)
+      double *row = energy_row(escratch);
+      wave_energy(exists ? ef[TMDHIP_E_BONDS] : 0.0, row + TMDHIP_E_BONDS);
+      wave_energy(exists ? ef[TMDHIP_E_ANGLES] : 0.0, row + TMDHIP_E_ANGLES);
+      wave_energy(exists ? ef[TMDHIP_E_DIHEDRALS] : 0.0, row + TMDHIP_E_DIHEDRALS);
+      wave_energy(exists ? ef[TMDHIP_E_IMPROPERS] : 0.0, row + TMDHIP_E_IMPROPERS);
+      wave_energy(exists ? ef[TMDHIP_E_LJ] : 0.0, row + TMDHIP_E_LJ);
+      wave_energy(exists ? ef[TMDHIP_E_ELECTROSTATICS] : 0.0, row + TMDHIP_E_ELECTROSTATICS);
+    }
     if (w != 0) return;
 #pragma unroll
     for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
@@ -191,16 +216,39 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
   // waits for nothing.  Should that ever not hold, the wait is bounded: the lane gives up, reports F_STEP_TIMEOUT and
   // does NOT integrate its atom; the caller rewinds the batch and repeats it with the separate integrator kernel
   // (judge_flags).  The poll is a volatile device-scope load: nothing may hoist it out of the loop.
-  if (!integrates) return;
+  if (!FINAL && !integrates) return;
   const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(fs.fsort, 0, n * (int)sizeof(R4), 0x00020000);
+  bool ok = integrates;
   unsigned spins = 0;
-  while (!load_force_record(frsrc, R(0), a, fs.watch_gen, x.f)) {
+  while (ok && !load_force_record(frsrc, R(0), a, fs.watch_gen, x.f)) {
     __builtin_amdgcn_s_sleep(kStepPollSleep);
     if (++spins > fs.poll_limit) {
       s.chk.flags[F_STEP_TIMEOUT] = 1;
-      return;  // no update from a stale record
+      ok = false;  // no update from a stale record
     }
   }
+  if constexpr (FINAL) {
+    // second half kick (+ thermostat) of the call's last step; the complete force goes to the caller's array (the same
+    // sum the kick divides by the mass); kinetic energy of the new velocity, reduced over the wave (every lane is here)
+    double ke = 0.0;
+    if (ok) {
+      R vnew[3];
+      md_step_atom<R, true, LANGEVIN, false, false>(s, c, o, 0, s.row0, x, fb, fs.bonded != 0, LANGEVIN ? g : nullptr, vnew);
+      if (forces_out) {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          R fk = x.f[k];
+          if (fs.bonded != 0) fk += fb[k];
+          forces_out[3 * o + k] = fk;
+        }
+      }
+      ke = 0.5 * (double)x.m * ((double)vnew[0] * vnew[0] + (double)vnew[1] * vnew[1] + (double)vnew[2] * vnew[2]);  // (kinetic_kernel's expression)
+    }
+    if (escratch) wave_energy(ke, energy_row(escratch) + kKineticSlot);
+    return;
+  }
+  if (!ok) return;
   md_step_atom<R, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, fs.bonded != 0, LANGEVIN ? g : nullptr);
   if (fst->dd_out) {
     // brick of a domain decomposition (dd_own_kernel's extras, same expressions): the running maximum of the squared

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep, int *__restrict__ padgen) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
-  static_assert(!(FUSED && ENERGY), "the fused step is for interior steps");
+  // FUSED 1 / 2: interior steps (NVE / Langevin step blocks); 3 / 4: the LAST step of a call that wants energies (FINAL
+  // step blocks, md_step.h: second half kick + bonded energies + kinetic energy + the complete force)
+  static_assert(FUSED == 0 || (FUSED <= 2 && !ENERGY) || (FUSED >= 3 && ENERGY), "interior steps carry no energies, the final step does");
   static_assert(kFastThreads == 256, "step blocks are four waves");
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // tells the host (host-mapped word) that everything enqueued before this launch has completed
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
       const int parity = (lmode & kLmParity) ? 1 : 0;
       if ((lmode & kLmViolation) && lflags[F_REBUILD0 + parity] != 0) lflags[F_VIOLATION] = 1;
       // the epilogue's test (parity ^ 1) is the next step's: this step's request is history (list_check_clear)
-      if (FUSED) lflags[F_REBUILD0 + parity] = 0;
+      if (FUSED == 1 || FUSED == 2) lflags[F_REBUILD0 + parity] = 0;
     }
   }
   __shared__ __align__(16) float2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   // pair blocks of the launch (FUSED: step blocks follow them)
   const unsigned npair = FUSED ? gridDim.x - (unsigned)fstep.nstep_blocks : gridDim.x;
   if (FUSED && blockIdx.x >= npair) {
-    fused_step_blocks<float, FUSED == 2, kFastThreads / LPA>(fst, fstep, c, n, sorted, order, (int)(blockIdx.x - npair),
-                                                                 (int)npair, reinterpret_cast<float *>(stab));
+    fused_step_blocks<float, FUSED == 2 || FUSED == 4, kFastThreads / LPA, (FUSED >= 3)>(
+        fst, fstep, c, n, sorted, order, (int)(blockIdx.x - npair), (int)npair, reinterpret_cast<float *>(stab), forces, energies);
     return;
   }
   // XCD-aware block order: consecutive block ids go to the 8 XCDs round-robin, so block b works on
@@ -371,9 +373,9 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     // (A flag per wave behind the stores cost a memory round trip more at the end of the launch; an agent-scope
     // release does it with buffer_wbl2, a write-back of the whole L2 per wave: 365 us per launch.)
     if (active && sub == 0) store_force_record(fstep.fsort, n, a, sx, sy, sz, fstep.gen);
-    return;
+    if constexpr (!ENERGY) return;  // (the final launch of a call also leaves its pair energies, below; its step blocks the force)
   }
-  if (active && sub == 0 && forces) {
+  if (FUSED == 0 && active && sub == 0 && forces) {
     if (overwrite) {
       forces[3 * oi + 0] = sx;
       forces[3 * oi + 1] = sy;
@@ -449,12 +451,13 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
     if (const char *e = std::getenv("TMDHIP_DEBUG_STEP_TIMEOUT"))
       if (rp.fused_launches == std::atoll(e)) fstep.watch_gen ^= 0x80000000u, fstep.poll_limit = 1u << 8;
     fstep.fsort = rp.fsort.as<float4>();
-    if constexpr (!ENERGY) {
-#define TMD_LAUNCH_FUSED(L)    \
-  if (fl->langevin) {          \
-    TMD_LAUNCH_FAST(L, 2);     \
-  } else {                     \
-    TMD_LAUNCH_FAST(L, 1);     \
+    {
+      constexpr int kNve = ENERGY ? 3 : 1, kLangevin = ENERGY ? 4 : 2;  // (with energies: the final step of a call)
+#define TMD_LAUNCH_FUSED(L)            \
+  if (fl->langevin) {                  \
+    TMD_LAUNCH_FAST(L, kLangevin);     \
+  } else {                             \
+    TMD_LAUNCH_FAST(L, kNve);          \
   }
       switch (rp.lg.lpa) {
         case 4: TMD_LAUNCH_FUSED(4); break;
@@ -465,8 +468,6 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
         default: return fail("fused MD step: unsupported lanes-per-atom");
       }
 #undef TMD_LAUNCH_FUSED
-    } else {
-      return fail("fused MD step with energies");
     }
   } else {
     switch (rp.lg.lpa) {  // (pick_lpa never returns less than 4)

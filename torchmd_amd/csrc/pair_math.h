@@ -153,4 +153,30 @@ static __global__ __launch_bounds__(kEnergySlots) void energy_fold_kernel(double
   }
 }
 
+// the same for the final step of an MD call made by FINAL step blocks (md_step.h): slot TMDHIP_NENERGY of the rows holds
+// the kinetic energy; one block of kEnergySlots threads (one replica)
+static __global__ __launch_bounds__(kEnergySlots) void final_fold_kernel(double *__restrict__ scratch, double *__restrict__ out,
+                                                                  double *__restrict__ ke) {
+  __shared__ double part[kEnergySlots / 64][TMDHIP_NENERGY + 1];
+  double *row = scratch + (size_t)threadIdx.x * kEnergyStride;
+#pragma unroll
+  for (int k = 0; k <= TMDHIP_NENERGY; ++k) {
+    const double v = row[k];
+    if (v != 0.0) row[k] = 0.0;
+    const double s = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x <= TMDHIP_NENERGY) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kEnergySlots / 64; ++w) s += part[w][threadIdx.x];
+    if (threadIdx.x < TMDHIP_NENERGY) {
+      if (s != 0.0) out[threadIdx.x] += s;
+    } else {
+      ke[0] = s;
+    }
+  }
+}
+
 }  // namespace tmd
