@@ -30,7 +30,7 @@ TIMESTEP_FS = 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-PMC_TRAFFIC_FILES = ("r04_c_pmc_traffic.json", "r04_b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
+PMC_TRAFFIC_FILES = ("r05_a_pmc_traffic.json", "r04_c_pmc_traffic.json", "r04_b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 FLOP_PER_PAIR = 50.0             # ~50 FLOP + 1 rsqrt per in-cutoff pair
 SIMDS, NOMINAL_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues over 2 cycles per SIMD
@@ -183,7 +183,7 @@ def dry_run_c5(args, rank, world):
         raise SystemExit("dry run of the domain decomposition FAILED: " + json.dumps(out))
 
 
-C5_TRAFFIC_FILES = ("r04_c_c5_pmc_traffic.json", "r04_b_c5_pmc_traffic.json", "r04_c5_pmc_traffic.json", "r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json")  # newest committed PMC pass first
+C5_TRAFFIC_FILES = ("r05_a_c5_pmc_traffic.json", "r04_c_c5_pmc_traffic.json", "r04_b_c5_pmc_traffic.json", "r04_c5_pmc_traffic.json", "r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json")  # newest committed PMC pass first
 
 
 def c5_single_gpu(args, device, cpu_budget_s=15.0, steps=None, warmup=None):
