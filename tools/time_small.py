@@ -18,7 +18,7 @@ from torchmd_amd.integrator import Integrator, maxwell_boltzmann  # noqa: E402
 from torchmd_amd.systems import System  # noqa: E402
 
 
-def run(name, terms, R, steps=4000, tutorial_loop=False, **kw):
+def run(name, terms, R, steps=4000, tutorial_loop=False, per_call=10, **kw):
     g = load(name)
     dev = torch.device("cuda:0")
     par = GoldenParameters(g, torch.float32)
@@ -44,8 +44,8 @@ def run(name, terms, R, steps=4000, tutorial_loop=False, **kw):
         traj = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps // 10):
-        ek, ep, T = integ.step(10)  # energies read back every 10 steps like the tutorial's output period
+    for i in range(steps // per_call):
+        ek, ep, T = integ.step(per_call)  # energies read back every `per_call` steps (10 = the tutorial's output period)
         if tutorial_loop:
             wrapper.wrap(s.pos, s.box)
             traj.append(s.pos.detach().cpu().numpy().copy())
@@ -54,13 +54,14 @@ def run(name, terms, R, steps=4000, tutorial_loop=False, **kw):
     el = time.perf_counter() - t0
     if tutorial_loop:
         name += " (tutorial loop: wrap + host copy + CSV row every 10 steps)"
-    print(f"{name}: {n} atoms x {R} replicas, {el / steps * 1e6:.1f} us/step = {steps / el * 1e-6 * 86400:.0f} ns/day per replica, "
+    print(f"{name} [step({per_call}) calls]: {n} atoms x {R} replicas, {el / steps * 1e6:.1f} us/step = {steps / el * 1e-6 * 86400:.0f} ns/day per replica, "
           f"T={T[0]:.0f} K, Epot={ep[0]:.1f}, algorithm={f.stats(s.pos)['algorithm']}")
 
 
 if __name__ == "__main__":
     all7 = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
     run("ala2", all7, 1, cutoff=9.0, switch_dist=7.5, rfa=True)
+    run("ala2", all7, 1, per_call=100, cutoff=9.0, switch_dist=7.5, rfa=True)  # (a call's fixed cost — ~50 us — spread over 100 steps)
     run("ala2", all7, 1, tutorial_loop=True, cutoff=9.0, switch_dist=7.5, rfa=True)
     for R in (2, 16, 64):  # replicas share every launch (batched all-pairs / bonded / integrator kernels)
         run("water291", ["lj", "bonds", "angles", "electrostatics"], R, steps=2000, cutoff=7.3)

@@ -16,6 +16,7 @@ namespace tmd {
 // streamed through LDS in tiles of 64 (broadcast reads).  Every (i,j) with i != j is evaluated from
 // i's side only, so forces need no cross-lane reduction; blocks with different j ranges combine
 // through one atomic add per atom.
+constexpr int kAllpairsLdsTypes = 16;  // LJ classes whose table the all-pairs kernel stages in LDS (2 / 4 KB)
 template <typename R, bool ENERGY>
 __global__ __launch_bounds__(64) void allpairs_kernel(
     int n, const R *__restrict__ pos, const R *__restrict__ qs, const int *__restrict__ types, int ntypes,
@@ -69,19 +70,46 @@ __global__ __launch_bounds__(64) void allpairs_kernel(
   const int jbeg = blockIdx.y * jchunk;
   const int jend = min(n, jbeg + jchunk);
 
+  // Round 5: small systems run ~1 000 of these waves for a few hundred atoms — 64 x 16 pairs each — so a wave's life is
+  // its chain of memory round trips, not its arithmetic (688-atom alanine dipeptide: 12 us per launch).  The chain was:
+  // own atom + exclusion offsets -> the exclusion row scanned entry by entry up to the wave's j range (one dependent load
+  // each: ~20 for a solute atom) -> barrier -> the j tile -> per hit a load of the LJ table from global memory.  Now:
+  // ONE batch holds the own atom, the exclusion offsets and the first j tile; a second one the first eight entries of
+  // the exclusion row (tested against every tile from registers; longer rows read the rest per tile); the LJ table is
+  // staged in LDS (up to kAllpairsLdsTypes classes).  Same arithmetic on the same values: results are unchanged.
+  constexpr int kExReg = 8;
+  __shared__ typename Vec<R>::T2 s_tab[kAllpairsLdsTypes * kAllpairsLdsTypes];
+  const bool tab_in_lds = ntypes <= kAllpairsLdsTypes;
   R xi = 0, yi = 0, zi = 0, qi = 0;
   int trow = 0;
-  int e = 0, eend = 0;
+  int ebeg = 0, eend = 0;
+  R4 v0;  // this lane's record of the first tile
+  v0.x = v0.y = v0.z = v0.w = R(0);
+  int t0 = 0;
+  {
+    const int jl = jbeg + lane;
+    if (jl < jend) {
+      v0.x = pos[3 * jl + 0];
+      v0.y = pos[3 * jl + 1];
+      v0.z = pos[3 * jl + 2];
+      v0.w = qs[jl];
+      t0 = types[jl];
+    }
+  }
   if (active) {
     xi = pos[3 * i + 0];
     yi = pos[3 * i + 1];
     zi = pos[3 * i + 2];
     qi = qs[i];
     trow = types[i] * ntypes;
-    e = excl_off[i];
+    ebeg = excl_off[i];
     eend = excl_off[i + 1];
-    while (e < eend && excl_idx[e] < jbeg) ++e;
   }
+  if (tab_in_lds)
+    for (int t = lane; t < ntypes * ntypes; t += 64) s_tab[t] = tab[t];
+  int ex[kExReg];
+#pragma unroll
+  for (int k = 0; k < kExReg; ++k) ex[k] = (ebeg + k < eend) ? excl_idx[ebeg + k] : -1;
   R fx = 0, fy = 0, fz = 0;
   R en[4] = {0, 0, 0, 0};
   unsigned long long cnt = 0;
@@ -89,7 +117,10 @@ __global__ __launch_bounds__(64) void allpairs_kernel(
   for (int j0 = jbeg; j0 < jend; j0 += 64) {
     __syncthreads();
     const int jl = j0 + lane;
-    if (jl < jend) {
+    if (j0 == jbeg) {
+      sj[lane] = v0;
+      st[lane] = t0;
+    } else if (jl < jend) {
       R4 v;
       v.x = pos[3 * jl + 0];
       v.y = pos[3 * jl + 1];
@@ -99,11 +130,17 @@ __global__ __launch_bounds__(64) void allpairs_kernel(
       st[lane] = types[jl];
     }
     __syncthreads();
-    // exclusion mask of this tile for atom i (rows of the CSR are sorted)
+    // exclusion mask of this tile for atom i: the row's first entries from registers, the rest (long rows: proteins) read here
     unsigned long long skip = 0;
-    while (e < eend && excl_idx[e] < j0 + 64) {
-      skip |= 1ull << (excl_idx[e] - j0);
-      ++e;
+#pragma unroll
+    for (int k = 0; k < kExReg; ++k) {
+      const unsigned d = (unsigned)(ex[k] - j0);
+      if (d < 64u) skip |= 1ull << d;
+    }
+    for (int e = ebeg + kExReg; e < eend; ++e) {
+      const int x = excl_idx[e];
+      if (x >= j0 + 64) break;  // (rows are sorted)
+      if (x >= j0) skip |= 1ull << (x - j0);
     }
     if (i >= j0 && i < j0 + 64) skip |= 1ull << (i - j0);
     const int tile = min(64, jend - j0);
@@ -115,7 +152,7 @@ __global__ __launch_bounds__(64) void allpairs_kernel(
       const R r2 = norm2(dx, dy, dz);
       const bool hit = active && !((skip >> k) & 1ull) && (r2 <= c.r2max);
       if (hit) {
-        const typename Vec<R>::T2 ab = tab[trow + st[k]];
+        const typename Vec<R>::T2 ab = tab_in_lds ? s_tab[trow + st[k]] : tab[trow + st[k]];
         const R fs = pair_terms<R, ENERGY>(c, r2, qi * pj.w, ab.x, ab.y, en);
         fx -= dx * fs;
         fy -= dy * fs;
@@ -298,7 +335,14 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
   const int nb = (n + 63) / 64;
   // split the j range so that ~1024 waves are in flight even for a few hundred atoms (each block then
   // walks a short j range; the partial forces are combined with one atomic per atom and split)
-  int nsplit = std::max(1, std::min((n + 15) / 16, 1024 / std::max(nb * nrep, 1)));
+  // (round 5: the wave target grows with the work — n^2 x replicas pairs / 512, 1 024 .. 4 096 waves: a batch of 16
+  // alanine-dipeptide replicas ran 880 waves of 144 iterations each, one per SIMD, nothing to hide a wave's latency
+  // behind.  Measured, us per MD step at 1 024 / 2 048 / 4 096 / 8 192 waves (profiles/r05_allpairs_waves.txt): ala2 x 16
+  // 71.1 / 43.3 / 37.8 / 44.2, tests/water x 64 46.0 / 29.5 / 23.0 / 25.7, x 16 18.5 / 15.3 / 15.2 / 15.6.  TMDHIP_ALLPAIRS_WAVES overrides.)
+  static const int waves_env = [] { const char *e = std::getenv("TMDHIP_ALLPAIRS_WAVES"); return e ? std::atoi(e) : 0; }();
+  const double pairs = (double)n * (double)n * (double)nrep;
+  const int want_waves = waves_env > 0 ? waves_env : (int)std::min(4096.0, std::max(1024.0, pairs / 512.0));
+  int nsplit = std::max(1, std::min((n + 15) / 16, want_waves / std::max(nb * nrep, 1)));
   int jchunk = ((n + nsplit - 1) / nsplit + 15) / 16 * 16;
   nsplit = (n + jchunk - 1) / jchunk;
   // `bonded` (heavy topologies, MD loop): n more one-wave blocks evaluate the bonded terms in the same launch
