@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace -d /tmp/p -- python bench.py --steps 400 --warmup 100 --no-cpu-baseline --no-secondary
     python tools/launch_timeline.py /tmp/p/<host>/<pid>_results.db
 
-The first pair launch after a list build writes the row padding and runs its tail checked (padded rows); this
+The first pair launch after a list build writes the row padding and runs its tail checked (docs/history/round4.md, padded rows); this
 prints what that launch costs against the ones that follow, and the gaps on the device between consecutive launches."""
 import sqlite3
 import sys

@@ -2,7 +2,7 @@
 """What a fork/join between two HIP streams costs on this box (needs a GPU): a ~20-us kernel A and a ~8-us kernel B per
 iteration, (i) both on one stream, (ii) A and B on two streams with an event each way, B overlapping A, (iii) the same
 without any dependency (upper bound of the overlap).  Decides whether the halo exchange of a brick step could hide
-behind interior pair work."""
+behind interior pair work (docs/history/round4.md, "what comes next" 1)."""
 import time
 
 import torch

@@ -61,7 +61,7 @@ constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs
 // order as md_step_bonded_kernel / md_step_kernel: trajectories are bit-identical to the separate kernels.
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
 // (LJ-only systems — liquid argon, short lists of ~90 entries — run the plain loop at one wave more per SIMD: 10^6 atoms
-// 175.5 -> 168.5 us/step; with charges the pipelined loop at 5 waves wins, section 6c)
+// 175.5 -> 168.5 us/step; with charges the pipelined loop at 5 waves wins, docs/history/round3.md)
 __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
