@@ -184,7 +184,10 @@ int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream);
  * Between steps the second half kick of step s-1, the first half step of step s and the neighbour-list
  * displacement test are ONE fused kernel.  Forces of the previous evaluation must be in forces_dev on
  * entry (as the reference requires: run.py:261 primes system.forces); on return forces_dev holds the
- * forces of the last step and velocities have received both half kicks. */
+ * forces of the last step and velocities have received both half kicks.  (Round 5: where the lean fp32 kernel serves
+ * one replica, the last step — with its energies — is made by the last pair launch itself; energies_dev is complete in
+ * stream order when the call returns either way, and tmdhip_md_observe of the same vel_dev then finds the kinetic energy
+ * already summed.) */
 typedef struct tmdhip_md_desc {
   int32_t struct_size;
   int32_t niter;
