@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TMDHIP_ABI_VERSION 8
+#define TMDHIP_ABI_VERSION 7
 
 /* dtype */
 #define TMDHIP_F32 0
@@ -137,8 +137,6 @@ typedef struct tmdhip_stats {
   int64_t chains_skipped;   /* MD steps whose rebuild chain the host left out (tmdhip_md_run)  */
   int64_t steps_in_pair_launch; /* MD steps made by step blocks of the pair launch instead of an integrator launch (ABI 4) */
   int64_t fused_step_timeouts;  /* batches rewound because a step block of a fused launch gave up waiting (ABI 5; whole context) */
-  int32_t list_entry_bits;      /* 32, or 16: the list streams from HBM as {stencil segment, offset, LJ class} entries (ABI 8) */
-  int32_t reserved0;
 } tmdhip_stats;
 
 int tmdhip_abi_version(void);

@@ -816,92 +816,6 @@ def test_streamed_list_reads_are_bit_identical(monkeypatch):
         assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
-@pytest.mark.parametrize("case", ["water-lpa8", "argon-lpa4"])
-def test_sixteen_bit_list_is_bit_identical(monkeypatch, case):
-    """Lists that stream from HBM are stored as 16-bit entries {stencil segment, offset, LJ class} (engine.h: list16_code;
-    by size, or TMDHIP_LIST16=0 / 1) and expanded by the pair waves from the segment tables of their atoms' cells.  The
-    expanded entries ARE the 32-bit entries: forces, energies, the pair count (which reads an expanded copy) and a short
-    fused trajectory with rebuilds equal those of the 32-bit list bit for bit, in both layouts the format exists for."""
-    from torchmd_amd.builders import argon_forcefield, lj_box, tip3p_box, water_forcefield
-    from torchmd_amd.forces import Forces
-    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
-    from torchmd_amd.parameters import Parameters
-    from torchmd_amd.systems import System
-
-    dev, dt = _dev(), torch.float32
-    if case == "water-lpa8":
-        mol, pos, box = tip3p_box(14, seed=2)
-        terms, kw, T, lpa = ["lj", "electrostatics", "bonds", "angles"], dict(cutoff=9.0, rfa=True), 300.0, "8"
-        par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
-    else:
-        mol, pos, box = lj_box(22, seed=3)
-        terms, kw, T, lpa = ["lj"], dict(cutoff=9.0), 3000.0, "4"  # (hot: a rebuild every few dozen steps)
-        par = Parameters(argon_forcefield(mol), mol, terms, precision=dt)
-    monkeypatch.setenv("TMDHIP_LPA", lpa)
-    torch.manual_seed(1)
-    vel0 = maxwell_boltzmann(par.masses, T, 1)
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("TMDHIP_LIST16", mode)
-        s = System(mol.numAtoms, 1, dt, dev)
-        s.set_positions(pos[:, :, None])
-        s.set_box(box)
-        s.set_velocities(vel0)
-        f = Forces(par, terms=terms, algorithm="celllist", **kw)
-        e0 = f.compute(s.pos, s.box, s.forces, returnDetails=True)
-        F0 = s.forces.clone().cpu()
-        npairs = f.count_pairs(s.pos, s.box)
-        st = f.stats(s.pos)
-        assert st["list_entry_bits"] == (16 if mode == "1" else 32), st
-        torch.manual_seed(9)
-        res = Integrator(s, f, 1.0, dev, gamma=1.0, T=T).step(60 if case == "water-lpa8" else 150)
-        st = f.stats(s.pos)
-        assert st["list_entry_bits"] == (16 if mode == "1" else 32) and st["n_rebuilds"] >= 4, st
-        out[mode] = (e0[0], F0, s.pos.cpu(), s.forces.cpu(), res, npairs)
-        f.close()
-    a, b = out["1"], out["0"]
-    assert a[5] == b[5] and a[5][0] > 0
-    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
-    for x, y in zip(a[4], b[4]):
-        assert np.array_equal(np.asarray(x), np.asarray(y))
-
-
-def test_sixteen_bit_list_falls_back_on_a_long_segment(monkeypatch):
-    """An offset field of 8 bits addresses 256 atoms of a stencil segment.  A droplet of 400 atoms in one cell overflows it:
-    the build raises F_LIST16, the replica rebuilds with 32-bit entries, and the results are those of a context that never
-    tried (forces against the oracle's are another test's business: here the two must agree bit for bit)."""
-    from torchmd_amd.builders import Topology
-    from torchmd_amd.forcefields.ff_yaml import YamlForceField
-    from torchmd_amd.forces import Forces
-    from torchmd_amd.parameters import Parameters
-
-    dev, dt = _dev(), torch.float32
-    rng = np.random.default_rng(11)
-    n, L = 6000, 60.0
-    p = rng.uniform(0, L, size=(n, 3))
-    v = rng.normal(size=(400, 3))
-    p[:400] = 30.0 + 1.5 * rng.uniform(0, 1, size=(400, 1)) ** (1 / 3) * v / np.linalg.norm(v, axis=1, keepdims=True)
-    ff = {"atomtypes": ["X"], "lj": {"X": {"sigma": 3.0, "epsilon": 0.1}}, "electrostatics": {"X": {"charge": 0.0}}, "masses": {"X": 10.0}}
-    q = rng.choice([-0.01, 0.01], size=n).astype(np.float32)
-    m2 = Topology(atomtype=np.full(n, "X", dtype=object), charge=q, masses=np.full(n, 10.0, dtype=np.float32))
-    par2 = Parameters(YamlForceField(m2, ff), m2, ["electrostatics"], precision=dt)
-    b3 = np.array([L, L, L])
-    pd2, bd2 = pos_tensor(p, 1, dt).to(dev), box_tensor(b3, 1, dt, dev)
-    monkeypatch.setenv("TMDHIP_BIN2", "0")  # (the droplet also overflows the two-launch binning's cells: not this test's subject)
-    out = {}
-    for mode, lpa in (("1", "8"), ("0", "8")):
-        monkeypatch.setenv("TMDHIP_LIST16", mode)
-        monkeypatch.setenv("TMDHIP_LPA", lpa)
-        f = Forces(par2, terms=["electrostatics"], cutoff=9.0, rfa=True, algorithm="celllist")
-        F = torch.zeros_like(pd2)
-        e = f.compute(pd2, bd2, F, returnDetails=True)
-        st = f.stats(pd2)
-        assert st["list_entry_bits"] == 32, st
-        out[mode] = (e[0], F.cpu(), f.count_pairs(pd2, bd2))
-        f.close()
-    assert out["1"][0] == out["0"][0] and torch.equal(out["1"][1], out["0"][1]) and out["1"][2] == out["0"][2]
-
-
 def test_side_stream_equals_the_default_stream():
     """Everything is enqueued on the caller's stream (`torch.cuda.current_stream`).  A side stream of PyTorch is created
     non-blocking: it is NOT ordered behind the null stream, through which the library's set-up uploads go (parameters,

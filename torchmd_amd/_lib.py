@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # TMDHIP_LIB: developer knob for A/B runs of differently built libraries (kernel experiments)
 LIBPATH = os.environ.get("TMDHIP_LIB") or os.path.join(PKG, "lib", "libtmdhip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 7
 F32, F64 = 0, 1
 TERM_LJ, TERM_ELECTROSTATICS, TERM_REPULSION, TERM_REPULSIONCG = 1, 2, 4, 8
 E_LJ, E_ELECTROSTATICS, E_REPULSION, E_REPULSIONCG, E_BONDS, E_ANGLES, E_DIHEDRALS, E_IMPROPERS = range(8)
@@ -199,8 +199,6 @@ class Stats(C.Structure):
         ("chains_skipped", C.c_int64),
         ("steps_in_pair_launch", C.c_int64),
         ("fused_step_timeouts", C.c_int64),
-        ("list_entry_bits", C.c_int32),
-        ("reserved0", C.c_int32),
     ]
 
 

@@ -169,21 +169,6 @@ bool list_streams(const tmdhip_ctx *ctx, const Replica &rp) {
   return (size_t)ctx->d.natoms * (size_t)rp.lg.maxn * 4u > ((size_t)384 << 20);
 }
 
-// 16-bit list entries (engine.h: list16_code) for the lists that stream from HBM: fp32, the lean fp32 pair kernel's layouts of
-// 4 or 8 lanes per atom, at most four LJ classes, a stencil of half-width <= 2, and no segment of more than 256 atoms so far
-// (F_LIST16).  TMDHIP_LIST16=0 / 1 overrides the size criterion (A/B, tests).  Every call site is followed by a forced rebuild.
-int plan_list16(tmdhip_ctx *ctx, Replica &rp) {
-  bool want = list_streams(ctx, rp);
-  if (const char *e = std::getenv("TMDHIP_LIST16")) want = std::atoi(e) != 0;
-  rp.list16_nseg = 2 * (2 * rp.grid.m + 1) * (2 * rp.grid.m + 1);
-  rp.list16 = want && !rp.list16_fallback && ctx->d.dtype == TMDHIP_F32 && (rp.lg.lpa == 4 || rp.lg.lpa == 8) &&
-              ctx->d.ntypes <= kList16MaxTypes && rp.list16_nseg <= kList16MaxSegs && rp.ncell > 0;
-  if (!rp.list16) return 0;
-  TMD_TRY(rp.acell.ensure(sizeof(int) * (size_t)ctx->d.natoms));
-  TMD_TRY(rp.cellseg.ensure(sizeof(int) * (size_t)rp.ncell * rp.list16_nseg));
-  return 0;
-}
-
 template <typename R>
 int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   using R4 = typename Vec<R>::T4;
@@ -286,7 +271,6 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     }
     for (int k = 0; k < 3; ++k) rp.box[k] = box[k];
     rp.pad_rows = plan_pad_rows(ctx, box);
-    TMD_TRY(plan_list16(ctx, rp));
     force = 1;
   }
   for (int attempt = 0; attempt < 8; ++attempt) {
@@ -309,12 +293,6 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
       rp.cell_cap_fallback = true;
       continue;
     }
-    if (h[F_LIST16]) {  // a stencil segment longer than a 16-bit entry's offset field: build again with 32-bit entries
-      TMD_HIP(hipMemsetAsync(rp.flags.as<int>() + F_LIST16, 0, sizeof(int), st));
-      rp.list16_fallback = true;
-      TMD_TRY(plan_list16(ctx, rp));
-      continue;
-    }
     int want = (int)(h[F_MAXN] * 1.2) + 8;
     if (const char *e = std::getenv("TMDHIP_DEBUG_LIST_SLACK")) {
       // test knob: size the list for the observed maximum + N entries only, so that a later device-side
@@ -323,7 +301,6 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
       const int tight = (want + 4 * rp.lg.lpa - 1) / (4 * rp.lg.lpa) * (4 * rp.lg.lpa);
       if (!rp.have_list && h[F_MAXN] <= rp.lg.maxn && rp.lg.maxn > tight) {
         TMD_TRY(alloc_replica<R>(ctx, rp, tight));
-        TMD_TRY(plan_list16(ctx, rp));
         continue;  // rebuild in the tighter geometry
       }
     }
@@ -333,7 +310,6 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     }
     rp.have_list = true;
     TMD_TRY(alloc_replica<R>(ctx, rp, std::max(want, rp.lg.maxn)));
-    TMD_TRY(plan_list16(ctx, rp));
   }
   R *f = (flags & TMDHIP_WANT_FORCES) ? (R *)forces : nullptr;
   unsigned long long *pc = nullptr;
@@ -427,18 +403,6 @@ int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
     rp.box[0] = -1;  // re-plan + rebuild
     last_error() = "a cell holds more atoms than the two-launch binning's member array (the replica switches to the "
                    "four-launch binning; results since the last check are invalid)";
-    return 1;
-  }
-  if (h[F_LIST16]) {
-    // a device-side rebuild met a stencil segment of more than 256 atoms: its 16-bit list is unusable.  The replica goes
-    // back to 32-bit entries; the work is repeated.
-    (void)hipMemsetAsync(rp.flags.as<int>() + F_LIST16, 0, sizeof(int), st);
-    rp.list16_fallback = true;
-    ctx->no_chain_skip_once = true;
-    rp.seq_valid = false;
-    rp.box[0] = -1;  // re-plan + rebuild
-    last_error() = "a stencil segment holds more atoms than a 16-bit list entry can address (the replica switches to 32-bit "
-                   "entries; results since the last check are invalid)";
     return 1;
   }
   if (h[F_VIOLATION]) {
@@ -751,8 +715,6 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   out->pairs_in_cutoff = (int64_t)pc;
   out->algorithm = ctx->algorithm;
   out->max_neighbours = rp.lg.maxn;
-  out->list_entry_bits = rp.list16 ? 16 : 32;
-  out->reserved0 = 0;
   out->overflow = (rp.have_list && h[F_MAXN] > rp.lg.maxn) ? h[F_MAXN] : 0;
   for (int k = 0; k < 3; ++k) out->ncell[k] = rp.grid.nc[k];
   if (rp.have_list) {

@@ -90,11 +90,10 @@ __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
 //                 ListCheck::skipped): the forces since then are invalid, the caller rewinds and repeats
 //   F_STEP_TIMEOUT  a step block of a fused pair launch gave up waiting for a force record (pair_fast_f32.hip): its
 //                 atoms were NOT integrated; the caller rewinds and repeats the batch with the separate integrator kernel
-//   F_LIST16      a 16-bit list (Replica::list16) met a stencil segment of more than 256 atoms: the list of this build is
-//                 unusable; the caller switches the replica back to 32-bit entries and repeats
+//   F_RESERVED    unused (was the always-on flag of the look-ahead builds removed in round 5)
 //   F_CELLCAP     a cell received more atoms than the member array of the two-launch binning holds (kCellCap): the list of
 //                 this build is incomplete; the caller switches the replica to the four-launch binning and repeats
-enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_STEP_TIMEOUT = 5, F_LIST16 = 6, F_CELLCAP = 7,
+enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_STEP_TIMEOUT = 5, F_RESERVED = 6, F_CELLCAP = 7,
        F_COUNT = 8 };
 constexpr int kCellCap = 64;             // members per cell of the two-launch binning
 constexpr int kScanPlaceMaxCells = 12288;  // cells whose prefix a block of scan_place_kernel can hold in LDS (48 KB)
@@ -254,19 +253,6 @@ constexpr unsigned kEntryOffMask = 0x07FFFFF0u;  // byte offset of atom j's floa
 constexpr int kEntryTypes = 32;                  // LJ classes that fit the entry's type field
 constexpr int kEntryTypeShift = 27;
 constexpr int kInfoIndexMask = 0x07FFFFFF;  // Replica::binfo: original index (< 2^23) below the LJ class field
-// 16-bit list entries (Replica::list16; lists that stream from HBM on every launch — 10^6 LJ atoms: 348 MB of the 544 MB a
-// launch moves — in half the bytes).  The neighbours of an atom come from the <= 50 stencil segments of its cell (runs of
-// consecutive cell-sorted slots: the z-run of one (x, y) stencil row, split where it wraps), so
-//   entry16 = offset in the segment (8 bits) | segment (6 bits) << 8 | LJ class (2 bits) << 14,
-// the build leaves the first slot of every segment of every cell in `cellseg` and every atom's cell in `acell`, and a pair
-// wave stages the segment table of its atoms' cells in LDS (64 words per atom) and expands entry by entry:
-//   32-bit entry = (table[segment] + offset) << 4 | class << 27.
-// Segment kList16PadSeg holds n: offsets 0 / 1 are the two dummy records of padded rows (pad_entry_for).
-constexpr int kList16PadSeg = 63;
-constexpr int kList16MaxSegs = 50;     // 2 (2m+1)^2 for a stencil half-width m <= 2
-constexpr int kList16MaxTypes = 4;     // LJ classes the entry's 2-bit field holds
-constexpr int kList16SegStride = 64;   // words per atom of the LDS table
-__device__ __host__ __forceinline__ unsigned list16_code(unsigned seg, unsigned off, unsigned cls) { return off | (seg << 8) | (cls << 14); }
 constexpr float kR2Floor = 1.0e-2f;  // (0.1 A)^2: keeps 1/r^14 finite for the self entries that pad a column
 
 // Padded list rows (Replica::pad_rows): the entry that fills the padding slots of atom `a`'s row — one of the two dummy
@@ -309,7 +295,6 @@ __device__ __forceinline__ size_t list_slot(const ListGeom &lg, int a, int k) {
 }
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 // k = round-half-even(d / box) by the magic-number trick: fma(d, 1/box, 1.5*2^23) - 1.5*2^23 is exact
 // round-to-nearest-even for |d/box| < 2^22 (v_rndne_f32 would be a fourth instruction).  It differs from
@@ -487,12 +472,6 @@ struct Replica {
   bool cell_cap_fallback = false;  // a cell overflowed `members` once: this replica bins with the four launches
   DevBuf sorted_hs;  // per-atom half skins in cell-sorted order (contexts with skin weights)
   DevBuf bsorted, binfo;  // the build kernel's records (PlaceArgs): wrapped position + half skin, original index | LJ class
-  // 16-bit list entries (list16_code): decided with the grid (a forced rebuild follows); `acell` = the cell of every
-  // cell-sorted slot, `cellseg` = int[ncell x list16_nseg] first slots of the cells' stencil segments, `nlist32` = the
-  // list expanded to 32-bit entries for the kernels that only read those (pair counting, repulsion terms)
-  bool list16 = false, list16_fallback = false;
-  int list16_nseg = 0;
-  DevBuf acell, cellseg, nlist32;
   DevBuf hs2_dyn;    // (half skin)^2 of the CURRENT list per atom, original order: what the displacement test uses
   const void *skin_vel = nullptr;  // velocities of this replica while tmdhip_md_run is enqueuing (velocity-dependent skins)
   // chain skipping (see ListCheck): host-mapped words {progress, near[2], rebuilds[2]}, sequence number of the last
@@ -526,7 +505,7 @@ struct Replica {
   void release() {
     for (DevBuf *b : {&cell_of, &slot, &order_tmp, &order, &inv, &count, &cell_start, &sorted, &stype, &ref, &sorted_hs, &hs2_dyn,
                       &nlist, &nneigh, &padgen, &members, &flags, &extent, &paircount, &pos_alt, &sorted_alt, &fused_dev, &fsort, &fbond,
-                      &bsorted, &binfo, &acell, &cellseg, &nlist32})
+                      &bsorted, &binfo})
       b->release();
   }
 };

@@ -365,9 +365,7 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__rest
 // displacement it may reach before a rebuild, see ListCheck), instead of cutoff + skin for every pair.
 // LPAS: log2 of the lanes per atom of the list layout as a compile-time constant (3 = the C3 / water layout: the masks and
 // shifts of a hit's byte offset become literals — full-rate VALU, no registers), or -1: read from ListGeom.
-// L16: 16-bit entries (engine.h: list16_code) — the candidate's stencil segment and its offset in it instead of its slot; the
-// block also leaves the cell's segment table in `cellseg` and its atoms' cell in `acell` for the pair waves.
-template <typename R, bool LOOP, bool WSKIN, int LPAS, bool L16 = false>
+template <typename R, bool LOOP, bool WSKIN, int LPAS>
 // (fp32: held to seven waves per SIMD — 72 VGPRs; the allocator is one register over without the hint and spills 16 bytes
 // in the prologue with it — because all 6 859 cell blocks of C3 are then resident at once: 7 168 slots)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 7 : 1, 8))) void build_list_kernel(
@@ -375,11 +373,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
     const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
     const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
-    int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split, int *__restrict__ count_zero,
-    int *__restrict__ acell, int *__restrict__ cellseg, int nseg) {
+    int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split, int *__restrict__ count_zero) {
   if (*flag == 0) return;
-  constexpr unsigned EB = L16 ? 1u : 2u;  // log2(bytes per list entry)
-  bool seg_overflow = false;
   const unsigned long long dbg_t0 = dbg ? __builtin_readcyclecounter() : 0ull;  // TMDHIP_DEBUG_TIMELINE (tools/build_timeline.py)
   using R4 = typename Vec<R>::T4;
   // the whole list as a bounds-checked buffer (< 2^30 entries): an out-of-range store is dropped
@@ -479,9 +474,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
   seg_prefix[lane] = inc0 - cnt2[0];
   seg_prefix[lane + 64] = tot0 + inc1 - cnt2[1];
   if (lane == 0) seg_prefix[128] = ncand;
-  if constexpr (L16) {
-    if (part == 0 && lane < nseg) cellseg[(size_t)cell * nseg + lane] = st2[0];
-  }
   if (dbg) dbg_work += (unsigned long long)ncand * (unsigned long long)(ce - cs);
   __syncthreads();
 
@@ -537,8 +529,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
       ex.z = 1 < ne ? excl_idx[eb + 1] : -1;
       ex.w = (int)(rowoff * 4u);  // byte offset of the atom's list row
       s_rec1[lane] = ex;
-      s_rowoff[lane] = rowoff << EB;
-      if constexpr (L16) acell[a] = cell;
+      s_rowoff[lane] = rowoff * 4u;
       long_rows = ne > EXS - 1;
     } else {
       // dummy atoms that pad the last batch of four: parked out of reach (never a hit, never a store)
@@ -581,14 +572,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
       if (nx_valid) while (seg_prefix[seg + 1] <= q) ++seg;  // last s with seg_prefix[s] <= q
       const int packed = seg_start[seg];
       nx_code = packed >> 24;
-      const int off = q - seg_prefix[seg];
-      if (nx_valid) nx_j = (packed & 0x00FFFFFF) + off;
+      if (nx_valid) nx_j = (packed & 0x00FFFFFF) + (q - seg_prefix[seg]);
       nx_p = bsorted[nx_j];
       nx_info = binfo[nx_j];
-      if constexpr (L16) {  // (the slot is not needed any more: the entry names the segment and the offset)
-        seg_overflow = seg_overflow || (nx_valid && off > 255);
-        nx_j = (seg << 8) | (off & 255);
-      }
     };
     // ---- candidate prefilter (round 5) ------------------------------------------------------------------------------
     // Only a quarter of the (atom, candidate) tests of a (2m+1)^3 stencil hit, and the build is instruction bound (debug
@@ -673,8 +659,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         // (bit 0 of an entry is free — the pair kernels mask it: here it carries "somebody in this block excludes this
         // candidate" (s_bm) through the compaction, and is cleared before the entry is stored)
         const unsigned iflag = any_long ? 1u : (s_bm[(ioj & 2047u) >> 5] >> (ioj & 31u)) & 1u;
-        const unsigned ientry = L16 ? (((unsigned)j | (((unsigned)info >> kEntryTypeShift) & 3u) << 14) << 16) | iflag
-                                    : ((unsigned)j << 4) | ((unsigned)info & ~(unsigned)kInfoIndexMask) | iflag;
+        const unsigned ientry = ((unsigned)j << 4) | ((unsigned)info & ~(unsigned)kInfoIndexMask) | iflag;
         if (q0 + 64 < ncand) fetch(q0 + 64);
         // candidate position as the periodic image that lies next to this cell: the i loop then needs
         // no minimum-image arithmetic (the list criterion has the skin as slack, so it need not reproduce
@@ -727,15 +712,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
       const R sj = a_s;
       const bool parked = lane >= min(total, 64);
       if (parked) pj.x = (R)1e18;
-      const unsigned entry = L16 ? a_entry >> 16 : a_entry & ~1u;
+      const unsigned entry = a_entry & ~1u;
       // the original index of a flagged candidate (exclusion compares): gathered only by the chunks that hold one
       const unsigned long long special = __builtin_amdgcn_uicmp(parked ? 0u : (a_entry & 1u), 0u, 33 /* ne */);  // (a wave-wide mask)
       unsigned oj = 0xFFFFFFFFu;
-      if (special) {
-        unsigned sj = (a_entry >> 4) & 0x7FFFFFu;
-        if constexpr (L16) sj = (unsigned)(seg_start[(a_entry >> 24) & 63u] & 0x00FFFFFF) + ((a_entry >> 16) & 255u);
-        oj = (unsigned)binfo[sj] & (unsigned)kInfoIndexMask;
-      }
+      if (special) oj = (unsigned)binfo[(a_entry >> 4) & 0x7FFFFFu] & (unsigned)kInfoIndexMask;
       // what wrapped around the 64 lanes is the start of the next chunk (w_* stay live through the batch loop)
       struct Carry {
         R x, y, z, s;
@@ -760,9 +741,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
         if (__builtin_amdgcn_inverse_ballot_w64(mask) && (k < (unsigned)lg.maxn)) {
           const unsigned rowoff = (unsigned)ex.w >> 2;
           const unsigned kk = k >> lpas;
-          const unsigned slot = rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u);
-          if constexpr (L16) reinterpret_cast<unsigned short *>(nlist)[slot] = (unsigned short)entry;
-          else nlist[slot] = entry;
+          nlist[rowoff + ((kk >> 2) << 8) + ((k & kmask) << 2) + (kk & 3u)] = entry;
         }
         s_cnt[t] = base + (int)__popcll(mask);  // every lane writes the same value
       };
@@ -817,17 +796,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
             const unsigned k = min(__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[u], (unsigned)base[u])),
                                    vmaxn1);
             // byte offset of entry k in the row: iteration kk = k / LPA, lane part k % LPA (list_slot's layout)
-            unsigned posb = ro[u] + ((k & vmask_hi) << (sh_hi - (2u - EB)));
-            posb += (k & vmask_lo) << (2u + EB);
-            posb += __builtin_amdgcn_ubfe(k, lpas, 2u) << EB;
+            unsigned posb = ro[u] + ((k & vmask_hi) << sh_hi);
+            posb += (k & vmask_lo) << 4;
+            posb += __builtin_amdgcn_ubfe(k, lpas, 2u) << 2;
             // only the lanes with a hit store: exec = the hit mask for the one instruction (every lane of the block is
             // active here); a v_cndmask on an out-of-range offset would cost a half-rate VALU slot instead
-            if constexpr (L16)
-              asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_short %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
-                           :: "v"(entry), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
-            else
-              asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_dword %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
-                           :: "v"(entry), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
+            asm volatile("s_mov_b64 exec, %2\n\tbuffer_store_dword %0, %1, %3, 0 offen\n\ts_mov_b64 exec, -1"
+                         :: "v"(entry), "v"(posb), "s"(m[u]), "s"(nrsrc) : "memory");
             cnt[u] = base[u] + (int)__popcll(m[u]);
           }
           *reinterpret_cast<int4 *>(&s_cnt[t]) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);  // every lane writes the same values
@@ -872,9 +847,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
   if (lane == 0 && wmax > 0) atomicMax(status, wmax);
-  if constexpr (L16) {
-    if (__ballot(seg_overflow) != 0ull && lane == 0) status[F_LIST16 - F_MAXN] = 1;
-  }
 }
 
 // TMDHIP_DEBUG_TIMELINE=1: every block of the list build records its entry / exit cycle counters (4 x u64 per block),
@@ -977,14 +949,10 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
                        (R)ctx->d.cutoff, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, T.nlist->as<unsigned>(),
                        T.nneigh->as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes,
                        debug_timeline_buffer(blocks), split,
-                       (bin2 && !(prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells)) ? T.count->as<int>() : nullptr,
-                       rp.acell.as<int>(), rp.cellseg.as<int>(), rp.list16_nseg);
+                       (bin2 && !(prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells)) ? T.count->as<int>() : nullptr);
   };
 #define TMD_BUILD(LOOPED, BLOCKS)                                                                   \
-  if (std::is_same<R, float>::value && rp.list16) {                                                \
-    if (wskin) launch_build(build_list_kernel<R, LOOPED, true, -1, (sizeof(R) == 4)>, BLOCKS);      \
-    else launch_build(build_list_kernel<R, LOOPED, false, -1, (sizeof(R) == 4)>, BLOCKS);           \
-  } else if (rp.lg.lpa_shift == 3) {                                                                      \
+  if (rp.lg.lpa_shift == 3) {                                                                      \
     if (wskin) launch_build(build_list_kernel<R, LOOPED, true, 3>, BLOCKS);                        \
     else launch_build(build_list_kernel<R, LOOPED, false, 3>, BLOCKS);                             \
   } else {                                                                                         \

@@ -59,11 +59,7 @@ constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs
 // Other blocks still read the positions of this launch, so the new ones go to the OTHER position buffer and the
 // OTHER cell-sorted copy (the host swaps the two after every fused launch).  Same device functions in the same
 // order as md_step_bonded_kernel / md_step_kernel: trajectories are bit-identical to the separate kernels.
-// L16: the list holds 16-bit entries (engine.h: list16_code; lists that stream from HBM).  A wave reads 8 bytes per lane and
-// group instead of 16, stages the stencil-segment tables of its atoms' cells in LDS (64 words per atom, `cellseg` rows named
-// by `acell`) and expands every entry to the 32-bit form before the gathers are issued: a bit-field extract, one LDS read,
-// an add — on a launch that waits for HBM, not for the VALU.
-template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0, bool L16 = false>
+template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
 // (LJ-only systems — liquid argon, short lists of ~90 entries — run the plain loop at one wave more per SIMD: 10^6 atoms
 // 175.5 -> 168.5 us/step; with charges the pipelined loop at 5 waves wins, docs/history/round3.md)
 __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) void list_pair_fast_f32_kernel(
@@ -71,10 +67,8 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
     double *__restrict__ energies, unsigned *publish, unsigned publish_value, const int *__restrict__ ext,
-    int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep, int *__restrict__ padgen,
-    const int *__restrict__ acell, const int *__restrict__ cellseg, int nseg) {
+    int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep, int *__restrict__ padgen) {
   constexpr int APW = 64 / LPA;
-  constexpr unsigned EBYTES = L16 ? 2u : 4u;  // bytes per list entry
   constexpr int UNROLL = 4;
   // FUSED 1 / 2: interior steps (NVE / Langevin step blocks); 3 / 4: the LAST step of a call that wants energies (FINAL
   // step blocks, md_step.h: second half kick + bonded energies + kinetic energy + the complete force)
@@ -91,7 +85,6 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     }
   }
   __shared__ __align__(16) float2 stab[kEntryTypes * kEntryTypes];  // row of type i: 32 x {-12 A, 6 B}
-  __shared__ int s_seg[L16 ? (kFastThreads / LPA) * kList16SegStride : 1];  // L16: first slot of every stencil segment, per atom
   const int lane = threadIdx.x & 63;
   // pair blocks of the launch (FUSED: step blocks follow them)
   const unsigned npair = FUSED ? gridDim.x - (unsigned)fstep.nstep_blocks : gridDim.x;
@@ -116,21 +109,12 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   // atom record / list length, then the first list word — 5 500 of its ~40 000 cycles)
   // list words of this wave: group G (iterations 4G .. 4G+3 of all 64 lanes) is the 1 KB at byte G * 1024; rows are
   // padded, and reads past the buffer's end return 0
-  // (L16: 512 bytes per group, 8 per lane; a list word then travels in .x / .y)
-  const char *wrow = reinterpret_cast<const char *>(nlist) + (size_t)wave * maxn * APW * EBYTES;
+  const unsigned *wrow = nlist + (size_t)wave * maxn * APW;
   const __amdgpu_buffer_rsrc_t lrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wrow), 0, maxn * APW * (int)EBYTES + 4096, 0x00020000);
-  const unsigned lvoff = (unsigned)lane * 4u * EBYTES;
-  constexpr int kGroupBytes = 256 * (int)EBYTES;
-  auto list_word_load = [&](int g, auto aux) {
-    if constexpr (L16) {
-      const v2u h = __builtin_amdgcn_raw_buffer_load_b64(lrsrc, lvoff, g * kGroupBytes, decltype(aux)::value);
-      return (v4u){h.x, h.y, 0u, 0u};
-    } else {
-      return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * kGroupBytes, decltype(aux)::value);
-    }
-  };
-  v4u word = list_word_load(0, std::integral_constant<int, 0>{});  // list word of the next group to be gathered (in flight)
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(wrow), 0, maxn * APW * 4 + 4096, 0x00020000);
+  const unsigned lvoff = (unsigned)lane * 16u;
+  auto list_word_raw = [&](int g) { return __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, g * 1024, 0); };
+  v4u word = list_word_raw(0);  // list word of the next group to be gathered (in flight)
   float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
   int nn = 0, oi = 0;
   unsigned trow = 0;  // byte offset of this atom's row of the LDS table
@@ -139,16 +123,6 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     nn = nneigh[a];
     trow = (unsigned)stype[a] << 8;
     oi = order[a];
-  }
-  // this lane's atom's row of the LDS segment table (byte offset)
-  const unsigned segrow = ((threadIdx.x >> 6) * APW + lane / LPA) * (unsigned)(kList16SegStride * 4);
-  if constexpr (L16) {
-    if (active) {
-      const int *src = cellseg + (size_t)acell[a] * nseg;
-      int *dst = reinterpret_cast<int *>(reinterpret_cast<char *>(s_seg) + segrow);
-      for (int s0 = sub; s0 < nseg; s0 += LPA) dst[s0] = src[s0];
-      if (sub == 0) dst[kList16PadSeg] = n;  // (the two dummy records of padded rows)
-    }
   }
   // (only the rows of existing classes are ever read: ntypes x 32 entries instead of 32 x 32 — at 10^6 LJ atoms
   // with 64 atoms per block the full table was 15 625 x 8 KB of staging)
@@ -182,15 +156,9 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     padded = have == now;
     if (!padded) {
       const unsigned pad = pad_entry_for(c, n, pi.x, pi.y, pi.z);
+      unsigned *row = const_cast<unsigned *>(wrow);
       const int upto = (nkk + UNROLL - 1) / UNROLL * UNROLL;
-      if constexpr (L16) {
-        unsigned short *row = reinterpret_cast<unsigned short *>(const_cast<char *>(wrow));
-        const unsigned short pad16 = (unsigned short)list16_code(kList16PadSeg, (pad >> 4) - (unsigned)n, 0u);
-        for (int kk = myiters; kk < upto; ++kk) row[(((kk >> 2) << 6) + lane) * 4 + (kk & 3)] = pad16;
-      } else {
-        unsigned *row = reinterpret_cast<unsigned *>(const_cast<char *>(wrow));
-        for (int kk = myiters; kk < upto; ++kk) row[(((kk >> 2) << 6) + lane) * 4 + (kk & 3)] = pad;
-      }
+      for (int kk = myiters; kk < upto; ++kk) row[(((kk >> 2) << 6) + lane) * 4 + (kk & 3)] = pad;
       if (lane == 0) padgen[wave] = now;
     }
   }
@@ -301,16 +269,7 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   // issue the 4 gathers of the group whose list word is `w` and form its table offsets (unchecked: n <= 2^20, bits
   // 24..27 of an entry are zero; checked: padding words are garbage, the offset is masked)
   auto issue = [&](auto unchecked, const v4u &w, v4u (&raw)[UNROLL], unsigned (&tab)[UNROLL]) {
-    unsigned entry[UNROLL] = {w.x, w.y, w.z, w.w};
-    if constexpr (L16) {
-      const unsigned h[UNROLL] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
-      const char *segbase = reinterpret_cast<const char *>(s_seg) + segrow;
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const unsigned first = (unsigned)*reinterpret_cast<const int *>(segbase + ((h[u] >> 6) & 0xFCu));  // table[segment]
-        entry[u] = ((first + (h[u] & 0xFFu)) << 4) | ((h[u] >> 14) << kEntryTypeShift);
-      }
-    }
+    const unsigned entry[UNROLL] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, entry[u] & kEntryOffMask, 0, 0);
 #pragma unroll
@@ -329,8 +288,8 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   auto list_word = [&](int gg) {
     v4u w = (v4u){0u, 0u, 0u, 0u};
     if (gg < gall) {
-      if (stream_list) w = list_word_load(gg, std::integral_constant<int, 2>{} /* nt */);
-      else w = list_word_load(gg, std::integral_constant<int, 0>{});
+      if (stream_list) w = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, gg * 1024, 2 /* nt */);
+      else w = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, lvoff, gg * 1024, 0);
     }
     return w;
   };
@@ -453,19 +412,12 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
   } else {                                 \
     TMD_LAUNCH_FAST_S(L, A, B, false, F);  \
   }
-#define TMD_LAUNCH_FAST_S(L, A, B, S, F)                         \
-  if ((L == 4 || L == 8) && rp.list16) {                        \
-    TMD_LAUNCH_FAST_K(L, A, B, S, F, (L == 4 || L == 8));       \
-  } else {                                                      \
-    TMD_LAUNCH_FAST_K(L, A, B, S, F, false);                    \
-  }
-#define TMD_LAUNCH_FAST_K(L, A, B, S, F, W)                                                                                \
-  launch_with_events(list_pair_fast_f32_kernel<L, A, B, ENERGY, S, F, W>, dim3(npair8 + (F ? fstep.nstep_blocks : 0)),     \
+#define TMD_LAUNCH_FAST_S(L, A, B, S, F)                                                                                  \
+  launch_with_events(list_pair_fast_f32_kernel<L, A, B, ENERGY, S, F>, dim3(npair8 + (F ? fstep.nstep_blocks : 0)),        \
                      dim3(kFastThreads), 0u, st, e0, e1, n, rp.sorted.as<float4>(), rp.stype.as<int>(), rp.order.as<int>(), \
                      ctx->d.ntypes, ctx->tab.as<float2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
                      overwrite, ctx->escratch.as<double>(), rp.pub_ptr, rp.pub_val, rp.extent.as<int>(),                  \
-                     rp.flags.as<int>(), lmode, F ? fl->fst : nullptr, fstep, rp.padgen.as<int>(), rp.acell.as<int>(),    \
-                     rp.cellseg.as<int>(), rp.list16_nseg)
+                     rp.flags.as<int>(), lmode, F ? fl->fst : nullptr, fstep, rp.padgen.as<int>())
 #define TMD_LAUNCH_FAST(L, F)               \
   if (lj && el) {                           \
     TMD_LAUNCH_FAST_T(L, true, true, F);    \
@@ -529,7 +481,6 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
 #undef TMD_LAUNCH_FAST
 #undef TMD_LAUNCH_FAST_T
 #undef TMD_LAUNCH_FAST_S
-#undef TMD_LAUNCH_FAST_K
   TMD_HIP(hipGetLastError());
   return 0;
 }

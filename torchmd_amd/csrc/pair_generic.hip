@@ -365,30 +365,6 @@ int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *f
   return 0;
 }
 
-// A 16-bit list (Replica::list16, engine.h: list16_code) expanded to the 32-bit entries list_pair_kernel reads — the pair
-// count and the repulsion terms of a context whose everyday launches run the lean fp32 kernel on the 16-bit form.  One wave
-// per wave group of the list, every lane the four entries of its 8-byte word; slots past a row's end expand to garbage the
-// same way they hold garbage in a 32-bit list (nneigh bounds the reader).
-__global__ __launch_bounds__(64) void expand_list16_kernel(int n, ListGeom lg, const unsigned short *__restrict__ l16,
-                                                           unsigned *__restrict__ l32, const int *__restrict__ acell,
-                                                           const int *__restrict__ cellseg, int nseg) {
-  const int wave = blockIdx.x, lane = threadIdx.x;
-  const int a = wave * lg.apw + (lane >> lg.lpa_shift);
-  if (a >= n) return;
-  const int *seg = cellseg + (size_t)acell[a] * nseg;
-  const size_t row = (size_t)wave * lg.maxn * lg.apw;
-  for (int g = 0; g < lg.maxn / (4 * lg.lpa); ++g) {
-    const size_t at = row + ((size_t)g * 64 + lane) * 4;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned h = l16[at + u];
-      const unsigned s = (h >> 8) & 63u;
-      const unsigned first = s == (unsigned)kList16PadSeg ? (unsigned)n : (s < (unsigned)nseg ? (unsigned)seg[s] : 0u);
-      l32[at + u] = ((first + (h & 0xFFu)) << 4) | ((h >> 14) << kEntryTypeShift);
-    }
-  }
-}
-
 template <typename R, bool ENERGY>
 int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f, int overwrite, double *energies,
                      unsigned long long *paircount, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int lmode,
@@ -419,17 +395,10 @@ int launch_list_pair(tmdhip_ctx *ctx, Replica &rp, const PairConsts<R> &c, R *f,
     }
   }
   if (fl) return fail("fused MD step: the context does not run a lean pair kernel");
-  const unsigned *list32 = rp.nlist.as<unsigned>();
-  if (rp.list16) {
-    TMD_TRY(rp.nlist32.ensure(rp.nlist.bytes));
-    hipLaunchKernelGGL(expand_list16_kernel, dim3(waves), dim3(64), 0, st, n, rp.lg, rp.nlist.as<unsigned short>(),
-                       rp.nlist32.as<unsigned>(), rp.acell.as<int>(), rp.cellseg.as<int>(), rp.list16_nseg);
-    list32 = rp.nlist32.as<unsigned>();
-  }
 #define TMD_LAUNCH(L, F)                                                                                \
   launch_with_events(list_pair_kernel<R, ENERGY, L, F>, dim3(blocks), dim3(256), shmem, st, e0, e1, n,  \
                      rp.sorted.as<R4>(), rp.stype.as<int>(), rp.order.as<int>(), ctx->d.ntypes,          \
-                     ctx->tab.as<R2>(), list32, rp.nneigh.as<int>(), rp.lg.maxn, c, f,                  \
+                     ctx->tab.as<R2>(), rp.nlist.as<unsigned>(), rp.nneigh.as<int>(), rp.lg.maxn, c, f,  \
                      overwrite, ctx->escratch.as<double>(), paircount, rp.pub_ptr, rp.pub_val)
   // the generic kernel's branch-free FAST=1 body hard-codes LJ + electrostatics (krf = 0: plain Coulomb)
   const bool fast_generic =

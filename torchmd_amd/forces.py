@@ -720,7 +720,6 @@ class Forces:
             "pairs_in_cutoff": st.pairs_in_cutoff,
             "algorithm": {L.ALGO_ALLPAIRS: "allpairs", L.ALGO_CELLLIST: "celllist"}.get(st.algorithm, "?"),
             "max_neighbours": st.max_neighbours,
-            "list_entry_bits": int(st.list_entry_bits),
             "overflow": st.overflow,
             "ncell": tuple(st.ncell),
             "skin": st.skin,
