@@ -55,6 +55,12 @@ print(f"work per CU: max / mean = {cw.max() / cw.mean():.3f} over {len(ck)} CUs"
 dur = t1 - t0
 print(f"block duration cycles: mean {dur.mean():.0f} p5 {np.percentile(dur, 5):.0f} p50 {np.median(dur):.0f} p95 {np.percentile(dur, 95):.0f} max {dur.max()}")
 print("corr(duration, longest list of the cell)", np.corrcoef(dur, nmax)[0, 1])
+print("block duration by XCD (ticks of 10 ns): mean", [int(dur[xcc == x].mean()) for x in range(8)], " p95",
+      [int(np.percentile(dur[xcc == x], 95)) for x in range(8)], " max", [int(dur[xcc == x].max()) for x in range(8)])
+print("last exit by XCD relative to the first entry of the launch (10 ns):", [int(t1[xcc == x].max() - t0.min()) for x in range(8)],
+      " first entry:", [int(t0[xcc == x].min() - t0.min()) for x in range(8)])
+print("block duration by wave slot (10 ns):", [(int(w), int((hwid & 15 == w).sum()), int(dur[hwid & 15 == w].mean())) for w in sorted(set(hwid & 15))])
+print("corr(duration, work)", np.corrcoef(dur, work)[0, 1], " corr(duration, block index)", np.corrcoef(dur, np.arange(nb))[0, 1])
 for x in range(8):
     m = xcc == x
     tend = t1[m].max()

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
     int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split, int *__restrict__ count_zero) {
   if (*flag == 0) return;
-  const unsigned long long dbg_t0 = dbg ? __builtin_readcyclecounter() : 0ull;  // TMDHIP_DEBUG_TIMELINE (tools/build_timeline.py)
+  const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;  // (the device-wide 100 MHz clock: comparable across XCDs)  // TMDHIP_DEBUG_TIMELINE (tools/build_timeline.py)
   using R4 = typename Vec<R>::T4;
   // the whole list as a bounds-checked buffer (< 2^30 entries): an out-of-range store is dropped
   const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -834,10 +834,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
     wmax = max(wmax, lane < ni ? mycnt : 0);
   }
   } while (LOOP && (cell += gridDim.x) < ncell);
-  if (dbg && lane == 0) {  // per block: entry / exit cycle counters, XCC id, candidates x atoms of its (last) cell
+  if (dbg && lane == 0) {  // per block: entry / exit time (10 ns ticks of the device-wide clock), XCC id, candidates x atoms of its (last) cell
     unsigned long long *o = dbg + 4 * (size_t)blockIdx.x;
     o[0] = dbg_t0;
-    o[1] = __builtin_readcyclecounter();
+    o[1] = wall_clock64();
     // XCC id | HW_ID (wave 0-3, SIMD 4-5, pipe 6-7, CU 8-11, SH 12, SE 13-15) << 8; longest list | work << 32
     o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((6 << 11) | 20) |
            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8);
