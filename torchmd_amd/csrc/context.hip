@@ -169,6 +169,12 @@ bool list_streams(const tmdhip_ctx *ctx, const Replica &rp) {
   return (size_t)ctx->d.natoms * (size_t)rp.lg.maxn * 4u > ((size_t)384 << 20);
 }
 
+// The events that time a pair launch (tmdhip_timing_enable) carry no system-scope fence: nobody reads device memory on the
+// strength of them, and a default event makes its launch release to the system — an L2 write-back in front of the next launch
+// of the step loop (round 5, profiles/r05_event_fence_ab.txt: the event-timed launches of the 2 000-step run 46.85 -> 45.0 us,
+// the kernel trace's 45.4; 20-step runs 69.4 -> 68.5 us per step).
+constexpr unsigned kTimingEventFlags = hipEventDisableSystemFence;
+
 template <typename R>
 int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   using R4 = typename Vec<R>::T4;
@@ -328,8 +334,8 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     if (ctx->events_used >= 4096) TMD_TRY(tmdhip_timing_read(ctx, nullptr, nullptr, 0));
     if (ctx->events_used == ctx->events.size()) {
       hipEvent_t a, b;
-      TMD_HIP(hipEventCreate(&a));
-      TMD_HIP(hipEventCreate(&b));
+      TMD_HIP(hipEventCreateWithFlags(&a, kTimingEventFlags));
+      TMD_HIP(hipEventCreateWithFlags(&b, kTimingEventFlags));
       ctx->events.emplace_back(a, b);
     }
     e0 = ctx->events[ctx->events_used].first;
@@ -808,8 +814,8 @@ int tmdhip_timing_enable(tmdhip_ctx *ctx, int on) {
   // costs ~10 us of host time: twenty of them in a 20-step run made the loop enqueue-bound)
   while (ctx->timing && ctx->events.size() < 192) {
     hipEvent_t a, b;
-    TMD_HIP(hipEventCreate(&a));
-    TMD_HIP(hipEventCreate(&b));
+    TMD_HIP(hipEventCreateWithFlags(&a, kTimingEventFlags));
+    TMD_HIP(hipEventCreateWithFlags(&b, kTimingEventFlags));
     ctx->events.emplace_back(a, b);
   }
   return 0;
