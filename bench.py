@@ -572,7 +572,8 @@ def main():
     if valu_instr and pair_avg_s > 0:
         cyc = pair_avg_s * NOMINAL_GHZ * 1e9 * SIMDS / valu_instr
         valu_issue = {"wave_instr_per_launch": valu_instr, "cycles_per_instr_per_simd": cyc,
-                      "frac_of_2cyc_peak": 2.0 / cyc, "clock_ghz_assumed": NOMINAL_GHZ, "source": traffic_src}
+                      "frac_of_2cyc_peak": 2.0 / cyc, "clock_ghz_assumed": NOMINAL_GHZ,
+                      "clock_ghz_measured_under_this_kernel": "2.23-2.37 by XCD (profiles/r05_pair_clock.txt)", "source": traffic_src}
 
     out = {
         "metric": "ns/day (aggregate over replicas), 100k-atom TIP3P water box, 9 A cutoff + reaction field",

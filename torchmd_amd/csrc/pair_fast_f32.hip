@@ -59,6 +59,10 @@ constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs
 // Other blocks still read the positions of this launch, so the new ones go to the OTHER position buffer and the
 // OTHER cell-sorted copy (the host swaps the two after every fused launch).  Same device functions in the same
 // order as md_step_bonded_kernel / md_step_kernel: trajectories are bit-identical to the separate kernels.
+#ifdef TMD_PAIR_TIMELINE  // experiment builds only (tools/pair_timeline.py; nothing of it is in the product library): {entry, exit on
+                          // the device-wide 100 MHz clock, XCC id, core cycles} of every pair block
+__device__ unsigned long long g_pair_timeline[4 * 65536];
+#endif
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
 // (LJ-only systems — liquid argon, short lists of ~90 entries — run the plain loop at one wave more per SIMD: 10^6 atoms
 // 175.5 -> 168.5 us/step; with charges the pipelined loop at 5 waves wins, docs/history/round3.md)
@@ -70,6 +74,9 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep, int *__restrict__ padgen) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
+#ifdef TMD_PAIR_TIMELINE
+  const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
+#endif
   // FUSED 1 / 2: interior steps (NVE / Langevin step blocks); 3 / 4: the LAST step of a call that wants energies (FINAL
   // step blocks, md_step.h: second half kick + bonded energies + kinetic energy + the complete force)
   static_assert(FUSED == 0 || (FUSED <= 2 && !ENERGY) || (FUSED >= 3 && ENERGY), "interior steps carry no energies, the final step does");
@@ -360,6 +367,14 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     }
     checked_loop(fused_image{});  // tail
   }
+#ifdef TMD_PAIR_TIMELINE
+  if (threadIdx.x == 0 && blockIdx.x < 65536u) {
+    g_pair_timeline[4 * blockIdx.x + 0] = tl_t0;
+    g_pair_timeline[4 * blockIdx.x + 1] = wall_clock64();
+    g_pair_timeline[4 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((6 << 11) | 20) | ((unsigned long long)gridDim.x << 32);
+    g_pair_timeline[4 * blockIdx.x + 3] = __builtin_readcyclecounter() - tl_c0;
+  }
+#endif
   float sx = fx, sy = fy, sz = fz;
 #pragma unroll
   for (int o = LPA >> 1; o > 0; o >>= 1) {
@@ -491,3 +506,10 @@ template int launch_pair_fast_f32<false>(tmdhip_ctx *, Replica &, const PairCons
                                          hipEvent_t, hipEvent_t, int, const FusedLaunch *);
 
 }  // namespace tmd
+
+#ifdef TMD_PAIR_TIMELINE
+extern "C" int tmdhip_debug_pair_timeline(void *out, size_t bytes) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(tmd::g_pair_timeline), std::min(bytes, sizeof(tmd::g_pair_timeline))) == hipSuccess ? 0 : -1;
+}
+#endif
