@@ -30,30 +30,37 @@ TIMESTEP_FS = 1.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-PMC_TRAFFIC_FILES = ("r05_a_pmc_traffic.json", "r04_c_pmc_traffic.json", "r04_b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
+PMC_TRAFFIC_FILES_SWITCH = ("r06_switch_pmc_traffic.json",)  # the SWITCH variant of the launch (secondary.c3_switch)
+PMC_TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_a_pmc_traffic.json", "r04_c_pmc_traffic.json", "r04_b_pmc_traffic.json", "r04_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest committed PMC pass first
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 FLOP_PER_PAIR = 50.0             # ~50 FLOP + 1 rsqrt per in-cutoff pair
 SIMDS, NOMINAL_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues over 2 cycles per SIMD
 
 
-SHORT_TIMED = 4  # timed launches of a run shorter than 128 steps
+TIMING_PASS_STEPS = 96  # launches of the dominant kernel timed in the pass BEHIND the timed region
 
 
-def timing_stride(steps):
-    """HIP events time every n-th launch of the pair kernel: >= 128 steps: every 16th launch over the whole region;
-    shorter runs: launches 2-5 of the region, consecutively (a launch with events attached costs the stream ~7 us when
-    its neighbours are timed too and ~10 us alone among untimed ones — tools/short_call.py; eight of them were 56 us of
-    a 1 500-us region, i.e. 4 % of the figure being measured.  The first launch of a step() call is passed over: it is
-    the one launch of the call that does not make the next step itself)."""
-    return 16 if steps >= 128 else 1
+def time_pair_launches(forces, integ, system, nsteps=TIMING_PASS_STEPS):
+    """Average duration of the dominant kernel, measured live with HIP events attached to its dispatch
+    (hipExtLaunchKernel) on the launch stream — in a pass of its own right BEHIND the timed region: one `step()` call of
+    nsteps + 1 MD steps in which EVERY interior launch is timed, the first launch after a list build included (the
+    call's last launch returns energies — another variant of the kernel — and is left out).  Round 5 timed four picked
+    launches inside the timed region: the events cost that region ~3 % (profiles/r05_bench_order_ab.txt) and the four
+    launches were the optimistic end of the distribution; this is the all-launch average the kernel trace gives."""
+    forces.enable_timing(system.pos, True, every=1, interior_only=True)
+    forces.read_timing(system.pos, reset=True)
+    integ.step(nsteps + 1)
+    ms, launches = forces.read_timing(system.pos, reset=True)
+    forces.enable_timing(system.pos, False)
+    return ms, launches
 
 
-def pmc_traffic():
+def pmc_traffic(switched=False):
     """Counter figures of the dominant kernel from the newest committed PMC pass (profiles/): counters cannot be
     collected inside the timed run, so what `rocprofv3 --pmc` measured for the same kernel + workload is reported
     with its provenance (file and the commit the pass was run on): HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE,
     the guide's gfx950 correction) and VALU wave-instructions per launch (SQ_INSTS_VALU)."""
-    for name in PMC_TRAFFIC_FILES:
+    for name in (PMC_TRAFFIC_FILES_SWITCH if switched else PMC_TRAFFIC_FILES):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:
@@ -212,17 +219,14 @@ def c5_single_gpu(args, device, cpu_budget_s=15.0, steps=None, warmup=None):
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     integ.step(max(warmup, 1))
-    stride = timing_stride(steps)
-    f.enable_timing(s.pos, True, every=stride, limit=SHORT_TIMED if steps < 128 else 0, skip=1 if steps < 128 else 0)
-    f.read_timing(s.pos, reset=True)
     st0 = f.stats(s.pos)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ekin, epot, temp = integ.step(steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    pair_ms, pair_launches = f.read_timing(s.pos, reset=True)
     st1 = f.stats(s.pos)
+    pair_ms, pair_launches = time_pair_launches(f, integ, s)
     pcut = f.count_pairs(s.pos, s.box)[0]
     # (as in the C3 line: the timed launches also make the MD step -> SURVEY 8(d)'s whole-step bytes)
     fused = st1["steps_in_pair_launch"] - st0["steps_in_pair_launch"] >= steps - 2
@@ -394,10 +398,15 @@ def rccl_info(world, backend):
     info = {"ranks": world, "backend": backend, "version": ver, "is_rccl": bool(getattr(torch.version, "hip", None)) and backend == "nccl"}
     if dist.is_available() and dist.is_initialized():
         dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
-        t = torch.tensor([float(dev)], device=f"cuda:{dev}" if dev >= 0 else "cpu")
+        # (gloo has no all_gather of device tensors: gather on the host unless the backend is RCCL)
+        t = torch.tensor([float(dev)], device=f"cuda:{dev}" if (dev >= 0 and backend == "nccl") else "cpu")
         got = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(got, t)
-        info["local_device_of_rank"] = [int(x.item()) for x in got]
+        try:
+            dist.all_gather(got, t)
+            info["local_device_of_rank"] = [int(x.item()) for x in got]
+        except Exception as exc:  # noqa: BLE001  (the line must not be lost to its own provenance block)
+            info["local_device_of_rank"] = None
+            info["gather_error"] = f"{type(exc).__name__}: {exc}"[:200]
     return info
 
 
@@ -439,6 +448,18 @@ def cpu_baseline(par, system, box, budget_s=20.0):
     dt, gamma, vcoeff = orc.integrator_constants(TIMESTEP_FS, 0.1, 300.0, masses)
     kw = dict(cutoff=CUTOFF, rfa=True, pairs=pairs)
     orc.md_step(par, pos, vel, frc, cbox, masses, dt, TERMS, gamma, vcoeff, **kw)  # warm-up
+    # the best the host can do: a gather / scatter workload is oversubscribed by torch's default of one thread per
+    # hardware thread (round 5: 2.48 s/step on 128 threads, the reference's classes on 8 threads 1.39 s/step) — one timed
+    # step at 8 / 16 / 32 / all threads, the bounded sample with the fastest
+    default_threads = torch.get_num_threads()
+    tried = {}
+    for nt in sorted({min(t, default_threads) for t in (8, 16, 32, default_threads)}):
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        orc.md_step(par, pos, vel, frc, cbox, masses, dt, TERMS, gamma, vcoeff, **kw)
+        tried[nt] = time.perf_counter() - t0
+    threads_used = min(tried, key=tried.get)
+    torch.set_num_threads(threads_used)
     n, t0 = 0, time.perf_counter()
     while True:
         orc.md_step(par, pos, vel, frc, cbox, masses, dt, TERMS, gamma, vcoeff, **kw)
@@ -446,6 +467,7 @@ def cpu_baseline(par, system, box, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 50:
             break
+    torch.set_num_threads(default_threads)
     ref = None  # the reference's OWN Forces + Integrator with a sparse pair list, timed in the build container
     try:         # (tools/ref_cpu_sparse.py; /root/reference does not exist on the GPU box): recorded beside the port
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_ref_cpu_sparse.json")) as fh:
@@ -457,7 +479,10 @@ def cpu_baseline(par, system, box, budget_s=20.0):
     return {
         "value": ns_per_day(n, el),
         "unit": "ns/day",
-        "cores": torch.get_num_threads(),
+        "cores": threads_used,
+        "threads_used": threads_used,
+        "threads_tried_s_per_step": {str(k): v for k, v in tried.items()},
+        "host_hardware_threads": default_threads,
         "kind": "port",
         "reference_in_build_container": ref,
         "source": "oracle (pinned port of the reference arithmetic; /root/reference does not exist on the GPU box)",
@@ -465,6 +490,97 @@ def cpu_baseline(par, system, box, budget_s=20.0):
         "sample": f"{n} MD steps of the same {pos.shape[1]}-atom box (oracle/torchmd_oracle.py md_step, "
         f"{len(pairs)} candidate pairs, list build excluded)",
     }
+
+
+def c3_leg(forces, integ, system, natoms, steps, fan, pmc=True, switched=False):
+    """One timed leg on the water box: `integ.step(steps)` between barrier + synchronize on both sides (nothing else in
+    the region: no events, no read-backs), then — outside the region — the statistics, the pass that times the dominant
+    kernel (time_pair_launches) and the pair count; returns the elapsed time, the observables and the `roofline` /
+    `list` blocks of a bench line."""
+    st0 = forces.stats(system.pos)
+    replays0 = integ.replays
+    fan.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ekin, epot, temp = integ.step(steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0  # this rank's K steps are complete (barrier + synchronize in front, synchronize
+    fan.barrier()                       # + barrier behind); the job's time is the slowest rank's
+    elapsed = fan.max_over_ranks(elapsed)
+    st1 = forces.stats(system.pos)
+    replays = integ.replays - replays0
+    obs = fan.gather_observables(ekin, epot, temp)
+    sp0 = forces.stats(system.pos)
+    pair_ms, pair_launches = time_pair_launches(forces, integ, system)
+    sp1 = forces.stats(system.pos)
+    pcut = forces.count_pairs(system.pos, system.box)[0]
+    st2 = forces.stats(system.pos)
+    rebuilds = st1["n_rebuilds"] - st0["n_rebuilds"]
+
+    # roofline of the dominant kernel.  Algorithmic bytes of the pair part per launch = 4 B per unique in-cutoff pair
+    # (one int32 neighbour index) + 28 B per atom (16 B xyzq read, 12 B force write); since round 3 the timed
+    # launches of an MD run also make the step (step blocks behind the pair blocks: kicks, drift, displacement test,
+    # inline bonded terms), i.e. SURVEY.md 8(d)'s whole-step figure 4 B per pair + 132 B per atom.
+    fused_steps = st1["steps_in_pair_launch"] - st0["steps_in_pair_launch"]
+    fused = fused_steps >= steps - 2
+    pair_bytes = 4.0 * pcut + 28.0 * natoms
+    step_bytes = 4.0 * pcut + 132.0 * natoms  # whole step incl. integrator (SURVEY.md 8(d))
+    alg_bytes = step_bytes if fused else pair_bytes
+    pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
+    achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
+    traffic, traffic_src, traffic_commit, valu_instr = pmc_traffic(switched) if pmc else (None, None, None, None)
+    # the other two ceilings of SURVEY 8(d): fp32 vector ALU (50 FLOP per unique in-cutoff pair) and VALU issue
+    # (wave-instructions of the PMC pass x 2 cycles per SIMD at the nominal clock)
+    alu_tflops = FLOP_PER_PAIR * pcut / pair_avg_s / 1e12 if pair_avg_s > 0 else 0.0
+    valu_issue = None
+    if valu_instr and pair_avg_s > 0:
+        cyc = pair_avg_s * NOMINAL_GHZ * 1e9 * SIMDS / valu_instr
+        valu_issue = {"wave_instr_per_launch": valu_instr, "cycles_per_instr_per_simd": cyc,
+                      "frac_of_2cyc_peak": 2.0 / cyc, "clock_ghz_assumed": NOMINAL_GHZ,
+                      "clock_ghz_recorded_under_this_kernel": "2.23-2.37 by XCD (a recorded value: profiles/r05_pair_clock.txt, not measured in this run)",
+                      "source": traffic_src}
+    roofline = {
+        "kernel": "list_pair_fast_f32_kernel<8> (lean scalar fp32, LJ + reaction field" + (", LJ switching function" if switched else "") + ")"
+        + (" with the MD step in the same launch (step blocks: integrator + inline bonded terms)" if fused else ""),
+        # what the counters say bounds the launch; `achieved / peak / frac` stay the HBM view the contract asks for
+        # (SURVEY 8(d)'s algorithmic bytes against 8 TB/s), `alu` and `valu_issue` are the other two ceilings
+        "bound": "valu_issue+gather",
+        "frac_is": "hbm: algorithmic bytes / launch time / 8 TB/s",
+        "limited_by": "VALU issue + gather (texture-addresser) rate, not HBM: see `alu`, `valu_issue` and docs/history/round3.md",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "traffic_commit": traffic_commit,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "algorithmic_bytes": ("whole step, 4 B x pairs + 132 B x atoms (SURVEY 8(d)): the launch computes the pair forces AND "
+                              "makes the MD step" if fused else "pair part, 4 B x pairs + 28 B x atoms"),
+        "frac_pair_bytes_only": (pair_bytes / pair_avg_s / 1e9 / HBM_PEAK_GBS) if pair_avg_s > 0 else 0.0,
+        "steps_made_by_the_pair_launch": int(fused_steps),
+        "avg_kernel_us": pair_avg_s * 1e6,
+        "launches_timed": int(pair_launches),
+        "timing": (f"HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of EVERY interior pair-kernel launch of a "
+                   f"{TIMING_PASS_STEPS + 1}-step call right behind the timed region, on the launch stream (the first launch after a list "
+                   f"build included: {sp1['n_rebuilds'] - sp0['n_rebuilds']} builds in the pass); no events inside the timed region"),
+        "step_frac_of_hbm_roofline": (step_bytes / (elapsed / steps)) / 1e9 / HBM_PEAK_GBS,
+        "alu": {"flops_per_launch": FLOP_PER_PAIR * pcut, "achieved_tflops": alu_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": alu_tflops / FP32_VECTOR_PEAK_TFLOPS},
+        "valu_issue": valu_issue,
+    }
+    lst = {
+        "algorithm": st2["algorithm"],
+        "rebuilds_in_timed_region": int(rebuilds),
+        "steps_per_rebuild": (steps / rebuilds) if rebuilds else None,
+        "entries": int(st2["list_entries"]),
+        "skin": st2["skin"],
+        "rebuild_chains_left_out": int(st1["chains_skipped"] - st0["chains_skipped"]),
+        "batches_rewound_and_repeated": int(replays),  # (a list that outlived its skin in a step without a chain: the call repeats its batch)
+        "capacity_per_atom": int(st2["max_neighbours"]),
+        "ncell": list(st2["ncell"]),
+    }
+    return {"elapsed": elapsed, "obs": obs, "pairs_in_cutoff": pcut, "roofline": roofline, "list": lst}
 
 
 def main():
@@ -475,7 +591,7 @@ def main():
     ap.add_argument("--nside", type=int, default=32, help="molecules per box edge (32 -> 98 304 atoms)")
     ap.add_argument("--relax-steps", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary C5 leg of the default run")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs of the default run (switched C3, C5)")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin in A (default: the library's)")
     ap.add_argument("--skin-weights", default="mass", choices=["mass", "none"],
                     help="per-atom Verlet skins by mass (default) or one skin for every atom")
@@ -527,53 +643,10 @@ def main():
     if args.warmup:
         integ.step(args.warmup)
 
-    st0 = forces.stats(system.pos)
-    # HIP events on every 16th launch of the pair kernel, spread over the whole timed region (attached to the
-    # dispatch itself since round 2: events recorded in front of and behind a launch cost 6.6 us of stream time each pair)
-    stride = timing_stride(args.steps)
-    # short runs: exactly SHORT_TIMED timed launches (every event pair costs stream time that the step loop pays)
-    forces.enable_timing(system.pos, True, every=stride, limit=SHORT_TIMED if args.steps < 128 else 0, skip=1 if args.steps < 128 else 0)
-    forces.read_timing(system.pos, reset=True)
-    fan.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ekin, epot, temp = integ.step(args.steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0  # this rank's K steps are complete (barrier + synchronize in front, synchronize
-    fan.barrier()                       # + barrier behind); the job's time is the slowest rank's
-    elapsed = fan.max_over_ranks(elapsed)
-    pair_ms, pair_launches = forces.read_timing(system.pos, reset=True)
-    forces.enable_timing(system.pos, False)
-    st1 = forces.stats(system.pos)
-    obs = fan.gather_observables(ekin, epot, temp)
-
-    pcut = forces.count_pairs(system.pos, system.box)[0]
-    st2 = forces.stats(system.pos)
+    leg = c3_leg(forces, integ, system, natoms, args.steps, fan, pmc=args.nside == 32)
+    elapsed, obs, pcut = leg["elapsed"], leg["obs"], leg["pairs_in_cutoff"]
     steps_per_s = args.steps / elapsed
     value = ns_per_day(args.steps, elapsed) * world
-    rebuilds = st1["n_rebuilds"] - st0["n_rebuilds"]
-
-    # roofline of the dominant kernel.  Algorithmic bytes of the pair part per launch = 4 B per unique in-cutoff pair
-    # (one int32 neighbour index) + 28 B per atom (16 B xyzq read, 12 B force write); since round 3 the timed
-    # launches of an MD run also make the step (step blocks behind the pair blocks: kicks, drift, displacement test,
-    # inline bonded terms), i.e. SURVEY.md 8(d)'s whole-step figure 4 B per pair + 132 B per atom.
-    fused_steps = st1["steps_in_pair_launch"] - st0["steps_in_pair_launch"]
-    fused = fused_steps >= args.steps - 2
-    pair_bytes = 4.0 * pcut + 28.0 * natoms
-    step_bytes = 4.0 * pcut + 132.0 * natoms  # whole step incl. integrator
-    alg_bytes = step_bytes if fused else pair_bytes
-    pair_avg_s = (pair_ms / max(pair_launches, 1)) * 1e-3
-    achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
-    traffic, traffic_src, traffic_commit, valu_instr = pmc_traffic() if (args.nside == 32) else (None, None, None, None)
-    # the other two ceilings of SURVEY 8(d): fp32 vector ALU (50 FLOP per unique in-cutoff pair) and VALU issue
-    # (wave-instructions of the PMC pass x 2 cycles per SIMD at the nominal clock)
-    alu_tflops = FLOP_PER_PAIR * pcut / pair_avg_s / 1e12 if pair_avg_s > 0 else 0.0
-    valu_issue = None
-    if valu_instr and pair_avg_s > 0:
-        cyc = pair_avg_s * NOMINAL_GHZ * 1e9 * SIMDS / valu_instr
-        valu_issue = {"wave_instr_per_launch": valu_instr, "cycles_per_instr_per_simd": cyc,
-                      "frac_of_2cyc_peak": 2.0 / cyc, "clock_ghz_assumed": NOMINAL_GHZ,
-                      "clock_ghz_measured_under_this_kernel": "2.23-2.37 by XCD (profiles/r05_pair_clock.txt)", "source": traffic_src}
 
     out = {
         "metric": "ns/day (aggregate over replicas), 100k-atom TIP3P water box, 9 A cutoff + reaction field",
@@ -602,54 +675,48 @@ def main():
         "pairs_in_cutoff": pcut,
         "temperature_K": [float(x) for x in obs[:, 2]],
         "epot_kcal_mol": [float(x) for x in obs[:, 1]],
-        "list": {
-            "algorithm": st2["algorithm"],
-            "rebuilds_in_timed_region": int(rebuilds),
-            "steps_per_rebuild": (args.steps / rebuilds) if rebuilds else None,
-            "entries": int(st2["list_entries"]),
-            "skin": st2["skin"],
-            "skin_weights": args.skin_weights,
-            "rebuild_chains_left_out": int(st1["chains_skipped"] - st0["chains_skipped"]),
-            "capacity_per_atom": int(st2["max_neighbours"]),
-            "ncell": list(st2["ncell"]),
-        },
-        "roofline": {
-            "kernel": "list_pair_fast_f32_kernel<8> (lean scalar fp32, LJ + reaction field)"
-            + (" with the MD step in the same launch (step blocks: integrator + inline bonded terms)" if fused else ""),
-            # what the counters say bounds the launch; `achieved / peak / frac` stay the HBM view the contract asks for
-            # (SURVEY 8(d)'s algorithmic bytes against 8 TB/s), `alu` and `valu_issue` are the other two ceilings
-            "bound": "valu_issue+gather",
-            "frac_is": "hbm: algorithmic bytes / launch time / 8 TB/s",
-            "limited_by": "VALU issue + gather (texture-addresser) rate, not HBM: see `alu`, `valu_issue` and docs/history/round3.md",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-            "traffic_commit": traffic_commit,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "algorithmic_bytes": ("whole step, 4 B x pairs + 132 B x atoms (SURVEY 8(d)): the launch computes the pair forces AND "
-                                  "makes the MD step" if fused else "pair part, 4 B x pairs + 28 B x atoms"),
-            "frac_pair_bytes_only": (pair_bytes / pair_avg_s / 1e9 / HBM_PEAK_GBS) if pair_avg_s > 0 else 0.0,
-            "steps_made_by_the_pair_launch": int(fused_steps),
-            "avg_kernel_us": pair_avg_s * 1e6,
-            "launches_timed": int(pair_launches),
-            "timing": (f"HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of every {stride}th pair-kernel "
-                       "launch of the timed region, on the launch stream")
-            if stride > 1 else f"HIP start/stop events attached to the dispatch (hipExtLaunchKernel) of pair-kernel launches 2-{1 + SHORT_TIMED} "
-            "of the timed region, on the launch stream",
-            "step_frac_of_hbm_roofline": (step_bytes / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
-            "alu": {"flops_per_launch": FLOP_PER_PAIR * pcut, "achieved_tflops": alu_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": alu_tflops / FP32_VECTOR_PEAK_TFLOPS},
-            "valu_issue": valu_issue,
-        },
+        "list": dict(leg["list"], skin_weights=args.skin_weights),
+        "roofline": leg["roofline"],
     }
     if world > 1:
         out["rccl"] = rccl_info(world, args.backend)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(par, system, box)
-        out["speedup_vs_cpu_baseline"] = out["ns_per_day_per_replica"] / out["cpu_baseline"]["value"]
+        out["cpu_baseline"] = cb = cpu_baseline(par, system, box, budget_s=15.0)
+        # quoted against the FASTER of the two CPU figures (the port timed here, the reference's own classes in the build container)
+        ref = cb.get("reference_in_build_container") or {}
+        best_cpu = max(cb["value"], ref.get("value") or 0.0)
+        out["speedup_vs_cpu_baseline"] = out["ns_per_day_per_replica"] / best_cpu
+        out["speedup_is_against"] = "port" if best_cpu == cb["value"] else "reference_in_build_container"
+    secondary = {}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # Secondary leg on the SAME box and state: the reference's production settings switch the LJ term from 7.5 A
+        # (tests/prod_alanine_dipeptide_amber/conf.yaml:8-9, forces.py:399-413) — the SWITCH variant of the dominant launch.
+        # max(--steps, 200) steps so that the window holds the list rebuilds in their steady proportion.
+        try:
+            from torchmd_amd.forces import Forces
+
+            fsw = Forces(par, terms=TERMS, cutoff=CUTOFF, rfa=True, switch_dist=7.5,
+                         skin_weights=None if args.skin_weights == "none" else "mass", **({} if args.skin is None else {"skin": args.skin}))
+            fsw.compute(system.pos, system.box, system.forces)
+            isw = Integrator(system, fsw, TIMESTEP_FS, device, gamma=0.1, T=300.0)
+            isw.step(max(args.warmup, 50))
+            sw_steps = max(args.steps, 200)
+            lsw = c3_leg(fsw, isw, system, natoms, sw_steps, fan, pmc=args.nside == 32, switched=True)
+            secondary["c3_switch"] = {
+                "metric": "ns/day, the same water box with the LJ switching function from 7.5 A (the reference's production settings)",
+                "value": ns_per_day(sw_steps, lsw["elapsed"]), "unit": "ns/day", "steps": sw_steps, "warmup": max(args.warmup, 50),
+                "ms_per_step": lsw["elapsed"] / sw_steps * 1e3, "dtype": "f32",
+                "config": {"workload": "C3 box, terms and thermostat as the headline + switch_dist 7.5 A (explicit-force flavour of "
+                           "forces.py:410-412)", "natoms": natoms, "timestep_fs": TIMESTEP_FS},
+                "pairs_in_cutoff": lsw["pairs_in_cutoff"],
+                "pair_interactions_per_s": lsw["pairs_in_cutoff"] * sw_steps / lsw["elapsed"],
+                "temperature_K": [float(x) for x in lsw["obs"][:, 2]], "epot_kcal_mol": [float(x) for x in lsw["obs"][:, 1]],
+                "list": lsw["list"], "roofline": lsw["roofline"],
+            }
+            fsw.close()
+            del fsw, isw
+        except Exception as exc:  # noqa: BLE001
+            secondary["c3_switch"] = {"error": f"{type(exc).__name__}: {exc}"[:500]}
     forces.close()
     if rank == 0 and world == 1 and args.nside == 32 and not args.no_secondary:
         # Secondary configuration in the same line (headline keys untouched): BASELINE.json's config 5 on this one GPU —
@@ -661,9 +728,11 @@ def main():
             c5 = c5_single_gpu(args, device, cpu_budget_s=8.0, steps=max(args.steps, 200), warmup=max(args.warmup, 50))
             c5["metric"] = "ns/day, 1M-atom Lennard-Jones box, 9 A cutoff, 1 GPU (the cpu_baseline is extrapolated from a 125k-atom sample)"
             c5["config"] = {"workload": c5_workload(c5["natoms"], c5["box"]), "natoms": c5["natoms"], "timestep_fs": TIMESTEP_FS}
-            out["secondary"] = {"c5": c5}
+            secondary["c5"] = c5
         except Exception as exc:  # noqa: BLE001
-            out["secondary"] = {"c5": {"error": f"{type(exc).__name__}: {exc}"[:500]}}
+            secondary["c5"] = {"error": f"{type(exc).__name__}: {exc}"[:500]}
+    if secondary:
+        out["secondary"] = secondary
     if rank == 0:
         print(json.dumps(out), flush=True)
     if launched:

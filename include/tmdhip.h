@@ -244,7 +244,8 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out);
 
 /* HIP-event timing of the dominant (pair) kernel, recorded on the launch stream.  on = 0: off; low 16 bits = n:
  * every n-th launch (1: every launch); bits 16..27 = stop after that many timed launches (0: no limit); bits 28..30 =
- * launches passed over before the first timed one.  The
+ * launches passed over before the first timed one; bit 31 = launches that also return energies (the last step of a
+ * tmdhip_md_run call, tmdhip_compute: another variant of the kernel) are neither timed nor counted.  The
  * start / stop events are attached to the kernel's own dispatch (hipExtLaunchKernel), not recorded around it. */
 int tmdhip_timing_enable(tmdhip_ctx *ctx, int on);
 int tmdhip_timing_read(tmdhip_ctx *ctx, double *pair_kernel_ms, int64_t *launches, int reset);

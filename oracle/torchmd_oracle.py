@@ -237,12 +237,18 @@ def compute(
     switch_dist=None,
     pairs=None,
     exclusions=("bonds", "angles", "1-4"),
+    explicit_forces=True,
 ):
     """Explicit-force evaluation of one `Forces.compute(pos, box, forces, returnDetails=True)` call
     (forces.py:83-346) for CPU tensors.  `pos [R,N,3]`, `box [R,3,3]`; `pairs` = [P,2] int64 numpy
     or tensor (per replica list allowed) of non-excluded i<j candidates in (i,j) ascending order;
     None = dense all-pairs list.  Returns (list of per-term energy dicts (python floats), forces
-    tensor [R,N,3], per-replica number of nonbonded pairs inside the cutoff)."""
+    tensor [R,N,3], per-replica number of nonbonded pairs inside the cutoff).
+    `explicit_forces=False` (forces.py:94-98, 328-336): `pos` must require gradients; no term scatters its
+    analytic force, the forces are minus the autograd gradient of the summed energies — the flavour without
+    the switching quirk of forces.py:410-412."""
+    if not explicit_forces and not pos.requires_grad:
+        raise RuntimeError("The positions passed don't require gradients. Please use pos.detach().requires_grad_(True) before passing.")
     terms = [t.lower() for t in terms]
     R, N = pos.shape[0], pos.shape[1]
     dt = pos.dtype
@@ -264,6 +270,8 @@ def compute(
         F = forces[r]
 
         def scatter_pair(idx, unit, coef):
+            if not explicit_forces:  # forces.py:140-143 etc.: every scatter sits under `if explicit_forces`
+                return
             fv = unit * coef[:, None]
             F.index_add_(0, idx[:, 0], -fv)
             F.index_add_(0, idx[:, 1], fv)
@@ -285,10 +293,10 @@ def compute(
             _, _, r23 = pair_geometry(spos, idx[:, [2, 1]], sbox)
             E, ff = angles(r21, r23, prm)
             pot["angles"] = pot["angles"] + E.sum()
-            for c in range(3):
+            for c in range(3 if explicit_forces else 0):
                 F.index_add_(0, idx[:, c], ff[c])
         if "dihedrals" in terms and par.dihedral_params is not None:  # forces.py:163-183
-            _torsion_block(spos, sbox, par.dihedral_params, pot, "dihedrals", F)
+            _torsion_block(spos, sbox, par.dihedral_params, pot, "dihedrals", F if explicit_forces else None)
         if "1-4" in terms and par.nonbonded_14_params is not None and len(par.nonbonded_14_params["idx"]):
             tab = par.nonbonded_14_params  # forces.py:185-236
             idx = tab["idx"]
@@ -303,7 +311,7 @@ def compute(
                 pot["electrostatics"] = pot["electrostatics"] + E.sum()
                 scatter_pair(idx, u, fc)
         if "impropers" in terms and par.improper_params is not None:  # forces.py:238-258
-            _torsion_block(spos, sbox, par.improper_params, pot, "impropers", F)
+            _torsion_block(spos, sbox, par.improper_params, pot, "impropers", F if explicit_forces else None)
 
         nin = 0
         if need_pairs:  # forces.py:260-319
@@ -329,8 +337,15 @@ def compute(
                     pot[t] = pot[t] + E.sum()
                     scatter_pair(idx, u, fc)
         npairs.append(nin)
-        pots.append({k: v.item() for k, v in pot.items()})
-    return pots, forces, npairs
+        pots.append(pot)
+    if not explicit_forces:  # forces.py:328-336
+        enesum = torch.zeros(1, dtype=dt)
+        for pot in pots:
+            for ene in pot:
+                if pot[ene].requires_grad:
+                    enesum = enesum + pot[ene]
+        forces[:] = -torch.autograd.grad(enesum, pos, only_inputs=True, retain_graph=True)[0]
+    return [{k: v.item() for k, v in pot.items()} for pot in pots], forces, npairs
 
 
 def _torsion_block(spos, sbox, tab, pot, name, F):
@@ -340,7 +355,7 @@ def _torsion_block(spos, sbox, tab, pot, name, F):
     _, _, r34 = pair_geometry(spos, idx[:, [2, 3]], sbox)
     E, ff = torsions(r12, r23, r34, tab["map"][:, 0], tab["params"][tab["map"][:, 1]])
     pot[name] = pot[name] + E.sum()
-    for c in range(4):
+    for c in range(4 if F is not None else 0):
         F.index_add_(0, idx[:, c], ff[c])
 
 

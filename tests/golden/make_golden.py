@@ -50,14 +50,17 @@ def pack_parameters(par, out, prefix="par_"):
         out[prefix + name + "_params"] = tab["params"].numpy()
 
 
-def run_reference(par, pos_np, box_np, terms, prec, R=1, **kw):
-    """One Forces.compute on the reference; returns (energy dicts, forces [R,N,3])."""
+def run_reference(par, pos_np, box_np, terms, prec, R=1, explicit_forces=True, **kw):
+    """One Forces.compute on the reference; returns (energy dicts, forces [R,N,3]).  explicit_forces=False: the
+    reference's autograd forces (forces.py:328-336), positions passed with requires_grad as its own test does
+    (tests/test_torchmd.py:496-517)."""
     n = pos_np.shape[0]
     system = RefSystem(n, R, PREC[prec], "cpu")
     system.set_positions(pos_np[:, :, None].astype(np.float64))
     system.set_box(np.asarray(box_np, dtype=np.float64))
     forces = RefForces(par, terms=terms, **kw)
-    pots = forces.compute(system.pos, system.box, system.forces, returnDetails=True)
+    pos = system.pos if explicit_forces else system.pos.detach().requires_grad_(True)
+    pots = forces.compute(pos, system.box, system.forces, returnDetails=True, explicit_forces=explicit_forces)
     return pots, system.forces.numpy().copy(), system
 
 
@@ -132,6 +135,10 @@ def ala2():
             store_case(out, f"{prec}_{label}_box0", pots, F)
             pots, F, _ = run_reference(par, xyz, np.zeros(3), tt, prec)  # no cutoff, plain Coulomb
             store_case(out, f"{prec}_{label}_nocut", pots, F)
+        # the autograd force flavour (explicit_forces=False: -dE/dr, without the switching quirk of forces.py:410-412)
+        for label, tt in (("full", ALL_TERMS), ("nb", ["electrostatics", "lj"])):
+            pots, F, _ = run_reference(par, xyz, box, tt, prec, explicit_forces=False, **settings)
+            store_case(out, f"{prec}_{label}_pbc_autograd", pots, F)
         # exact (no switch) variant, and each optional pair term on its own
         pots, F, _ = run_reference(par, xyz, box, ["electrostatics", "lj"], prec, cutoff=9.0, rfa=True)
         store_case(out, f"{prec}_nb_pbc_noswitch", pots, F)

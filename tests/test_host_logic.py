@@ -677,7 +677,7 @@ def test_bench_cpu_baseline_c5_sample_and_pmc_provenance():
     assert 0 < r["value"] < 10 and "512-atom" in r["sample"] and "atom ratio" in r["sample"]
     traffic, src, commit, valu = bench.pmc_traffic()
     assert traffic and traffic > 5e7 and src.startswith("profiles/") and commit and valu and valu > 1e6
-    assert bench.timing_stride(20) == 1 and bench.timing_stride(2000) == 16
+    assert bench.TIMING_PASS_STEPS >= 64  # the dominant kernel is timed in a pass of its own behind the timed region
 
 
 def test_launch_timeline_tool_on_a_synthetic_trace(tmp_path):

@@ -50,6 +50,27 @@ def test_ala2_bitexact(prec):
     _check(g, f"{prec}_repulsioncg_pbc", par, pos, pbc, ["repulsioncg"], cutoff=9.0)
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_ala2_autograd_forces_bitexact(prec):
+    """The reference's other force flavour (explicit_forces=False, forces.py:94-98, 328-336: minus the autograd
+    gradient of the summed energies — no switching quirk).  The energies are bit-identical; the forces are pinned to
+    the reference's own run-to-run spread: its backward scatters the per-pair gradients with index_put(accumulate)
+    over the host threads, whose summation order changes from run to run (measured here on the reference itself,
+    fp32, two calls in one process: 2.3e-5; one thread against eight: 3.6e-5).  They differ visibly from the explicit
+    forces (0.014 kcal/mol/A on this system)."""
+    g = load("ala2")
+    par = GoldenParameters(g, PREC[prec])
+    pbc = box_tensor(g["box"], 1, PREC[prec])
+    sw = dict(cutoff=9.0, switch_dist=7.5, rfa=True)
+    for label, terms in (("full", ALL_TERMS), ("nb", ["electrostatics", "lj"])):
+        pos = pos_tensor(g["pos"], 1, PREC[prec]).requires_grad_(True)
+        _check(g, f"{prec}_{label}_pbc_autograd", par, pos, pbc, terms, explicit_forces=False,
+               ftol=2e-4 if prec == "f32" else 1e-11, **sw)
+    assert np.abs(g["f64_nb_pbc_autograd_forces"] - g["f64_nb_pbc_forces"]).max() > 1e-2
+    with pytest.raises(RuntimeError):
+        orc.compute(par, pos_tensor(g["pos"], 1, PREC[prec]), pbc, ["lj"], explicit_forces=False, **sw)
+
+
 def test_sparse_candidates_equal_dense():
     """A cKDTree candidate list (superset of in-cutoff pairs, same order) gives bit-identical results."""
     g = load("ala2")

@@ -22,8 +22,10 @@ HOT_PATH = ("forces", "integrator", "systems", "wrapper")
 MIRRORS = ("parameters", "forcefields", "run", "minimizers", "utils")
 
 
-def install(everything: bool = False):
-    """Returns the list of `torchmd.*` module names that now point at this package."""
+def install(everything: bool = False, extra=()):
+    """Returns the list of `torchmd.*` module names that now point at this package.  `extra`: further mirrors to
+    register although the reference is importable — e.g. ("forcefields",) where the reference's AMBER backend needs
+    parmed (`torchmd/forcefields/ff_parmed.py:23`) and this package reads the prmtop natively."""
     try:
         ref = importlib.import_module("torchmd")
         have_ref = not getattr(ref, "__torchmd_amd_shim__", False)
@@ -34,11 +36,18 @@ def install(everything: bool = False):
         ref.__path__ = []  # mark as a package
         ref.__torchmd_amd_shim__ = True
         sys.modules["torchmd"] = ref
-    names = list(HOT_PATH) + (list(MIRRORS) if (everything or not have_ref) else [])
+    names = list(HOT_PATH) + (list(MIRRORS) if (everything or not have_ref) else [m for m in extra if m in MIRRORS])
     done = []
     for name in names:
         mod = importlib.import_module(f"torchmd_amd.{name}")
         sys.modules[f"torchmd.{name}"] = mod
         setattr(ref, name, mod)
         done.append(f"torchmd.{name}")
+        if hasattr(mod, "__path__"):  # a package (forcefields): its submodules under the reference's names too
+            import pkgutil
+
+            for sub in pkgutil.iter_modules(mod.__path__):
+                sm = importlib.import_module(f"torchmd_amd.{name}.{sub.name}")
+                sys.modules[f"torchmd.{name}.{sub.name}"] = sm
+                done.append(f"torchmd.{name}.{sub.name}")
     return done

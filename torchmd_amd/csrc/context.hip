@@ -326,8 +326,9 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
   hipEvent_t e0 = nullptr, e1 = nullptr;
   // every `timing_stride`-th launch is bracketed by events: an event pair costs ~3 us of stream time,
   // so timing every launch would slow down the very loop being measured
-  const int64_t seen = ctx->timing_seen++;
-  const bool timed = ctx->timing && seen >= 0 && (seen % ctx->timing_stride) == 0 &&
+  const bool timeable = ctx->timing && !(ctx->timing_interior_only && (flags & TMDHIP_WANT_ENERGY));
+  const int64_t seen = timeable ? ctx->timing_seen++ : -1;
+  const bool timed = timeable && seen >= 0 && (seen % ctx->timing_stride) == 0 &&
                      (ctx->timing_limit == 0 || ctx->timing_taken < ctx->timing_limit);
   if (timed) ctx->timing_taken++;
   if (timed) {
@@ -810,6 +811,7 @@ int tmdhip_timing_enable(tmdhip_ctx *ctx, int on) {
   ctx->timing_limit = (on >> 16) & 0xFFF;
   ctx->timing_taken = 0;
   ctx->timing_seen = -(int64_t)((on >> 28) & 7);  // the first launches are passed over
+  ctx->timing_interior_only = ((unsigned)on >> 31) != 0;
   // the events of the first launches are created here, not inside the region being timed (a hipEventCreate
   // costs ~10 us of host time: twenty of them in a 20-step run made the loop enqueue-bound)
   while (ctx->timing && ctx->events.size() < 192) {

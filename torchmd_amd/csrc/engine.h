@@ -563,6 +563,7 @@ struct tmdhip_ctx {
   int64_t timing_seen = 0;  // launches since timing was enabled
   int64_t timing_limit = 0; // stop after this many timed launches (0: no limit)
   int64_t timing_taken = 0;
+  bool timing_interior_only = false;  // launches that also return energies (another kernel variant) are not timed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   double timing_ms = 0;

@@ -44,6 +44,24 @@ namespace tmd {
 // stages of 4 KB per wave, four waves per SIMD — 49.2-50.5 against 45.6-46.9 us, identical checksums; the code is in commit
 // daee5f8, the record in profiles/r04_lds_gather_ab.txt.)
 constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs); measured at 4 / 6 / 7 / 8: docs/history/round3.md
+// Waves per SIMD a variant is compiled for.  Round 6: the variants with energies and / or the LJ switching function run the
+// pipelined loop too, at FOUR waves (110-120 VGPRs; at five they spill 36-104 bytes per lane).  C3, us per MD step /
+// per compute() with energies (profiles/r06_variants_ab.txt): plain loop at five waves (round 5) 75.9 / 110.3 (switched),
+// pipelined at five 78.7 / 168.5, pipelined at four 72.6 / 102.4 (unswitched compute(): 110.3 -> 102.4).
+// (TMD_FAST_WAVES_ES / _E / _S: A/B builds)
+#ifndef TMD_FAST_WAVES_E
+#define TMD_FAST_WAVES_E 4
+#endif
+#ifndef TMD_FAST_WAVES_S
+#define TMD_FAST_WAVES_S 4
+#endif
+#ifndef TMD_FAST_WAVES_ES
+#define TMD_FAST_WAVES_ES 4
+#endif
+constexpr int fast_waves(bool elec, bool energy, bool sw) {
+  if (!elec) return kFastWaves + 1;
+  return energy && sw ? TMD_FAST_WAVES_ES : energy ? TMD_FAST_WAVES_E : sw ? TMD_FAST_WAVES_S : kFastWaves;
+}
 // ---- the MD step inside the pair launch (FUSED variants; tmdhip_md_run, interior steps) -----------------------
 // Between two force evaluations an MD step is per-atom work on the force just computed: second half kick of step
 // `it` (+ thermostat), first half kick and drift of step it+1, the displacement test, the new record of the
@@ -66,7 +84,7 @@ __device__ unsigned long long g_pair_timeline[4 * 65536];
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
 // (LJ-only systems — liquid argon, short lists of ~90 entries — run the plain loop at one wave more per SIMD: 10^6 atoms
 // 175.5 -> 168.5 us/step; with charges the pipelined loop at 5 waves wins, docs/history/round3.md)
-__global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) void list_pair_fast_f32_kernel(
+__global__ __launch_bounds__(kFastThreads, fast_waves(ELEC, ENERGY, SWITCH)) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
     const int *__restrict__ nneigh, int maxn, PairConsts<float> c, float *__restrict__ forces, int overwrite,
@@ -74,6 +92,7 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     int *lflags, int lmode, const FusedStatic *__restrict__ fst, FusedStep fstep, int *__restrict__ padgen) {
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
+  constexpr bool kPipelined = ELEC;  // the software-pipelined loop over the unchecked groups (below)
 #ifdef TMD_PAIR_TIMELINE
   const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
 #endif
@@ -179,12 +198,21 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   const char *tbase = reinterpret_cast<const char *>(stab);
   const float two_krf = 2.0f * c.krf;
   const float qi2k = pi.w * two_krf;
-  const float sw_ir = c.inv_switch_range, sw_t0 = -c.switch_dist * c.inv_switch_range;
   auto in_vgpr = [](float sv) {  // a uniform value the compiler can no longer keep in an SGPR
     float v;
     asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(sv));
     return v;
   };
+  // LJ switching function (forces.py:399-413) with t = (r - r_s)/(r_c - r_s) clamped to [0, 1]:
+  //   S = 1 + t^3 (-10 + t (15 - 6 t)),   S' (r_c - r_s) = t^2 (-30 + 60 t - 30 t^2) = -30 (t (1 - t))^2
+  // and with p = (-12 A r^-6 + 6 B) r^-6 (the unswitched force coefficient times r^2) and e12 = p + 6 B r^-6 = -12 E_lj:
+  //   (dE/dr)/r = r^-2 [ S p + e12 w c x ],  w = (t (1 - t))^2, c = 2.5 / (r_c - r_s), x = 1 (the reference's explicit
+  //   force divides the switching term by r once more, forces.py:410-412) or r (exact: -dE/dr)
+  // ~14 plain VALU per entry on top of the unswitched body, no select; constants in VGPRs (see the head comment).
+  const float sw_ir = in_vgpr(c.inv_switch_range), sw_t0 = in_vgpr(-c.switch_dist * c.inv_switch_range);
+  const float sw_m0 = in_vgpr(c.switch_reference_mode ? 2.5f * c.inv_switch_range : 0.f);
+  const float sw_m1 = in_vgpr(c.switch_reference_mode ? 0.f : 2.5f * c.inv_switch_range);
+  const float vkrf = in_vgpr(c.krf), vcrf = in_vgpr(c.crf);
   const float vbx = in_vgpr(c.box[0]), vby = in_vgpr(c.box[1]), vbz = in_vgpr(c.box[2]);
   const float vibx = in_vgpr(c.invbox[0]), viby = in_vgpr(c.invbox[1]), vibz = in_vgpr(c.invbox[2]);
   const float vr2max = in_vgpr(c.r2max);
@@ -194,7 +222,8 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   const float cut_c0 = in_vgpr(__int_as_float(__float_as_int(c.r2max) + 1) * 1.2676506e30f);
 
   float fx = 0.f, fy = 0.f, fz = 0.f;
-  float e_lj = 0.f, e_el = 0.f;  // per-lane fp32 partial sums (~55 pairs), reduced in fp64
+  // per-lane fp32 partial sums (~55 pairs), reduced in fp64; e_lj in units of -12 E_lj (e12 above)
+  float e_lj = 0.f, e_el = 0.f;
 
   using checked_t = std::integral_constant<bool, false>;
   using unchecked_t = std::integral_constant<bool, true>;
@@ -203,7 +232,9 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   auto group = [&](auto image, auto unchecked, const auto &tab, const auto &raw, int kk0) {
     constexpr bool EXACT = decltype(image)::value;
     constexpr bool UNCHECKED = decltype(unchecked)::value;
-    constexpr bool ARITH_CUT = UNCHECKED && !ENERGY;
+    // (unchecked groups hold real pairs and dummy records only: every value below is finite and the cutoff can be a factor;
+    // the padding words of a checked group are garbage, inf / NaN are discarded by selects)
+    constexpr bool ARITH_CUT = UNCHECKED;
     constexpr int NU = (int)std::extent<std::remove_reference_t<decltype(tab)>>::value;
     static_assert(NU == 4, "a stage is one whole list word of a lane");
     float dx[NU], dy[NU], dz[NU], r2[NU], rinv[NU];
@@ -222,50 +253,46 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
       const bool valid = UNCHECKED || (kk0 + u < myiters);  // padding words are garbage
       const float pjw = __uint_as_float(raw[u].w);
       const bool hit = valid && (r2[u] <= vr2max);
+      float step = 1.f;
+      if (ARITH_CUT) asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(step) : "v"(r2[u]), "v"(cut_h), "v"(cut_c0));
       const float rinv2 = rinv[u] * rinv[u];
       const float rinv6 = rinv2 * rinv2 * rinv2;
-      float fs;  // (dE/dr) / r; rejected entries may produce inf/NaN here, the select below discards them
       float2 ab = make_float2(0.f, 0.f);  // (-12 A, 6 B)
       if (LJ) ab = *reinterpret_cast<const float2 *>(tbase + tab[u]);
-      // E_lj = (A r^-6 - B) r^-6 from the force coefficients (energy / switching variants only)
-      auto elj_of = [&](float r6) { return __builtin_fmaf(ab.x * (-1.0f / 12.0f), r6, ab.y * (-1.0f / 6.0f)) * r6; };
-      if (LJ && !SWITCH && ELEC) {
-        const float qq = pi.w * pjw;
-        const float p = __builtin_fmaf(ab.x, rinv6, ab.y) * rinv6;  // (a12 rinv6 + b6) rinv6
-        const float g = __builtin_fmaf(-qq, rinv[u], p);
-        fs = __builtin_fmaf(rinv2, g, qi2k * pjw);
-        if (ENERGY) e_lj += hit ? elj_of(rinv6) : 0.f;
-      } else {
-        fs = 0.f;
-        float sw = 1.f;  // switching function S(r) of the LJ term (forces.py:402-412), 1 below switch_dist
-        if (LJ) {
-          fs = __builtin_fmaf(ab.x, rinv6, ab.y) * (rinv6 * rinv2);
-          if (SWITCH) {
-            // t = (r - r_s)/(r_c - r_s) clamped at 0: S = 1 + t^3 (-10 + t (15 - 6 t)),
-            // S' = t^2 (-30 + t (60 - 30 t)) / (r_c - r_s);  (dE/dr)/r = S f + E S' x, x = 1/r (exact) or
-            // 1/r^2 (the reference's explicit-force expression divides the switching term by r once more)
-            const float r = r2[u] * rinv[u];
-            const float t = fmaxf(__builtin_fmaf(r, sw_ir, sw_t0), 0.f);
-            const float t2 = t * t;
-            const float pp = __builtin_fmaf(t, __builtin_fmaf(t, -6.f, 15.f), -10.f);
-            sw = __builtin_fmaf(t2 * t, pp, 1.f);
-            const float dq = __builtin_fmaf(t, __builtin_fmaf(t, -30.f * sw_ir, 60.f * sw_ir), -30.f * sw_ir);
-            const float elj = elj_of(rinv6);
-            const float x = c.switch_reference_mode ? rinv2 : rinv[u];
-            fs = __builtin_fmaf(sw, fs, elj * (t2 * dq) * x);
-          }
-          if (ENERGY) e_lj += hit ? sw * elj_of(rinv6) : 0.f;
+      // LJ: P = r^2 (dE_lj/dr)/r, e12 = -12 E_lj (both switched where SWITCH)
+      float P = 0.f, e12 = 0.f;
+      if (LJ) {
+        P = __builtin_fmaf(ab.x, rinv6, ab.y) * rinv6;  // (a12 rinv6 + b6) rinv6
+        if (ENERGY || SWITCH) e12 = __builtin_fmaf(ab.y, rinv6, P);
+        if (SWITCH) {
+          const float r = r2[u] * rinv[u];
+          float t;
+          asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(r), "v"(sw_ir), "v"(sw_t0));
+          const float t2 = t * t;
+          const float pp = __builtin_fmaf(t, __builtin_fmaf(t, -6.f, 15.f), -10.f);
+          const float sw = __builtin_fmaf(t2 * t, pp, 1.f);
+          const float tu = __builtin_fmaf(-t, t, t);  // t (1 - t)
+          const float w = tu * tu;
+          const float xc = __builtin_fmaf(r, sw_m1, sw_m0);
+          P = __builtin_fmaf(e12, w * xc, sw * P);
+          if (ENERGY) e12 *= sw;
         }
-        if (ELEC) fs += (pi.w * pjw) * (two_krf - rinv2 * rinv[u]);
       }
-      if (ENERGY && ELEC) e_el += hit ? (pi.w * pjw) * (rinv[u] + c.krf * r2[u] - c.crf) : 0.f;  // krf = crf = 0: plain Coulomb
-      if (ARITH_CUT) {
-        float step;
-        asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(step) : "v"(r2[u]), "v"(cut_h), "v"(cut_c0));
-        fs *= step;  // (every entry of the unchecked loop is a real pair, not a padding word: fs is finite)
+      float fs;  // (dE/dr) / r; rejected entries of a checked group may produce inf/NaN here, the select below discards them
+      if (ELEC) {
+        const float qq = pi.w * pjw;
+        const float g = __builtin_fmaf(-qq, rinv[u], P);
+        fs = __builtin_fmaf(rinv2, g, qi2k * pjw);
+        if (ENERGY) {  // krf = crf = 0: plain Coulomb
+          const float eel = qq * __builtin_fmaf(vkrf, r2[u], rinv[u] - vcrf);
+          e_el = ARITH_CUT ? __builtin_fmaf(step, eel, e_el) : e_el + (hit ? eel : 0.f);
+        }
       } else {
-        fs = hit ? fs : 0.f;
+        fs = P * rinv2;
       }
+      if (ENERGY && LJ) e_lj = ARITH_CUT ? __builtin_fmaf(step, e12, e_lj) : e_lj + (hit ? e12 : 0.f);
+      if (ARITH_CUT) fs *= step;
+      else fs = hit ? fs : 0.f;
       fx = __builtin_fmaf(-dx[u], fs, fx);
       fy = __builtin_fmaf(-dy[u], fs, fy);
       fz = __builtin_fmaf(-dz[u], fs, fz);
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
     // requests it made a whole group's arithmetic earlier (counters of the unpipelined loop: 44 % of a wave's cycles
     // in s_waitcnt, 27 % issuing — at the ~5 cycles per instruction a wave can issue by itself, six such waves do
     // not fill the VALU pipe).  94 VGPRs: five waves per SIMD.
-    if constexpr (ENERGY || SWITCH || !ELEC) {  // (the variants with more live values keep the plain loop: no spills at 5 waves)
+    if constexpr (!kPipelined) {  // (LJ-only systems: short lists, the plain loop at one wave more per SIMD)
       for (; g < gfull; ++g) {
         v4u raw[UNROLL];
         unsigned tab[UNROLL];
@@ -404,7 +431,7 @@ __global__ __launch_bounds__(kFastThreads, !ELEC ? kFastWaves + 1 : kFastWaves) 
   if (ENERGY) {  // every pair is listed from both atoms: half of the sum
     if (LJ) {
       const double s = wave_sum((double)e_lj);
-      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_LJ], 0.5 * s);
+      if (lane == 0 && s != 0.0) unsafeAtomicAdd(&energy_row(energies)[TMDHIP_E_LJ], (-0.5 / 12.0) * s);  // (e_lj holds -12 E_lj)
     }
     if (ELEC) {
       const double s = wave_sum((double)e_el);
@@ -475,22 +502,26 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
     TMD_LAUNCH_FAST(L, kNve);          \
   }
       switch (rp.lg.lpa) {
-        case 4: TMD_LAUNCH_FUSED(4); break;
         case 8: TMD_LAUNCH_FUSED(8); break;
+#ifndef TMD_DEV_LPA8_ONLY  // (developer builds: one lanes-per-atom variant compiles in a fifth of the time)
+        case 4: TMD_LAUNCH_FUSED(4); break;
         case 16: TMD_LAUNCH_FUSED(16); break;
         case 32: TMD_LAUNCH_FUSED(32); break;
         case 64: TMD_LAUNCH_FUSED(64); break;
+#endif
         default: return fail("fused MD step: unsupported lanes-per-atom");
       }
 #undef TMD_LAUNCH_FUSED
     }
   } else {
     switch (rp.lg.lpa) {  // (pick_lpa never returns less than 4)
+#ifndef TMD_DEV_LPA8_ONLY
       case 4: TMD_LAUNCH_FAST(4, 0); break;
-      case 8: TMD_LAUNCH_FAST(8, 0); break;
       case 16: TMD_LAUNCH_FAST(16, 0); break;
       case 32: TMD_LAUNCH_FAST(32, 0); break;
-      default: TMD_LAUNCH_FAST(64, 0); break;
+      case 64: TMD_LAUNCH_FAST(64, 0); break;
+#endif
+      default: TMD_LAUNCH_FAST(8, 0); break;
     }
   }
 #undef TMD_LAUNCH_FAST

@@ -728,12 +728,16 @@ class Forces:
             "fused_step_timeouts": int(st.fused_step_timeouts),
         }
 
-    def enable_timing(self, pos, on=True, every=1, limit=0, skip=0):
+    def enable_timing(self, pos, on=True, every=1, limit=0, skip=0, interior_only=False):
         """HIP events around every `every`-th launch of the list pair kernel (an event pair costs 3-6 us of stream
-        time), at most `limit` of them (0: no limit), after passing over the first `skip` (<= 7) launches."""
+        time), at most `limit` of them (0: no limit), after passing over the first `skip` (<= 7) launches;
+        `interior_only`: the launches that also return energies (another variant of the kernel: the last step of a
+        `step()` call, `compute()`) are neither timed nor counted."""
         eng = self._engine(pos.detach())
         code = (min(max(1, int(every)), 0xFFFF) | (min(max(0, int(limit)), 0xFFF) << 16) | (min(max(0, int(skip)), 7) << 28)) if on else 0
-        L.check(eng.lib.tmdhip_timing_enable(eng.ctx, code))
+        if on and interior_only:
+            code |= 1 << 31
+        L.check(eng.lib.tmdhip_timing_enable(eng.ctx, C.c_int(code - (1 << 32) if code >= (1 << 31) else code)))
 
     def read_timing(self, pos, reset=True):
         """(total ms, launches) of the list pair kernel measured with HIP events on the launch stream."""

@@ -124,6 +124,7 @@ class Integrator:
         self._seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
         self._nstep = 0
         self._ke = None
+        self.replays = 0  # batches that were rewound and repeated (list validity failure / step-block time-out)
 
     def _check_layout(self):
         s = self.systems
@@ -209,6 +210,7 @@ class Integrator:
                 # repeat the batch with the rebuild chain on every step (and, after a time-out, the separate
                 # integrator kernel); the noise stream is counter based, so it is the same trajectory
                 if not replay:
+                    self.replays += 1
                     return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
                 raise RuntimeError(_REPLAY_FAILED + L.last_error())
             cols = self.forces.energy_columns()
@@ -249,6 +251,7 @@ class Integrator:
             if not self.forces._verify(eng, s.pos):
                 why = L.last_error()  # (tmdhip_check's verdict, set by judge_flags a moment ago)
                 if fused and not replay:  # (batch mode of the fused loop: same rewind as above)
+                    self.replays += 1
                     return self._step_body(lib, s, dev, code, R, N, fast, fused, niter, replay=True)
                 raise RuntimeError((_REPLAY_FAILED + why) if (fused and replay) else (_LIST_INVALID + ": " + why))
         else:

@@ -159,7 +159,7 @@ def setup(args):
         ff = ForceField.create(mol, ff_src)
     terms = args.forceterms if args.forceterms else ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
     print("Force terms: ", terms)
-    parameters = Parameters(ff, mol, terms, precision=precision, device="cpu")
+    parameters = Parameters(ff, mol, terms, precision=precision, device=device)  # (on the device, as run.py:181-183 does)
     external = load_external(args.external, args.replicas, device)
     system = System(mol.numAtoms, args.replicas, precision, device)
     system.set_positions(mol.coords)
