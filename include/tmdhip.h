@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TMDHIP_ABI_VERSION 7
+#define TMDHIP_ABI_VERSION 8
 
 /* dtype */
 #define TMDHIP_F32 0
@@ -137,6 +137,9 @@ typedef struct tmdhip_stats {
   int64_t chains_skipped;   /* MD steps whose rebuild chain the host left out (tmdhip_md_run)  */
   int64_t steps_in_pair_launch; /* MD steps made by step blocks of the pair launch instead of an integrator launch (ABI 4) */
   int64_t fused_step_timeouts;  /* batches rewound because a step block of a fused launch gave up waiting (ABI 5; whole context) */
+  int64_t final_steps_in_pair_launch; /* tmdhip_md_run calls whose LAST step (final kick, bonded + kinetic energies) was made by the
+                                       * step blocks of the last pair launch (ABI 8; whole context) */
+  int64_t batched_launches;     /* pair + step launches that served several replicas of a cell-list context at once (ABI 8; whole context) */
 } tmdhip_stats;
 
 int tmdhip_abi_version(void);
@@ -184,10 +187,12 @@ int tmdhip_check(tmdhip_ctx *ctx, int replica, void *stream);
  * Between steps the second half kick of step s-1, the first half step of step s and the neighbour-list
  * displacement test are ONE fused kernel.  Forces of the previous evaluation must be in forces_dev on
  * entry (as the reference requires: run.py:261 primes system.forces); on return forces_dev holds the
- * forces of the last step and velocities have received both half kicks.  (Round 5: where the lean fp32 kernel serves
- * one replica, the last step — with its energies — is made by the last pair launch itself; energies_dev is complete in
- * stream order when the call returns either way, and tmdhip_md_observe of the same vel_dev then finds the kinetic energy
- * already summed.) */
+ * forces of the last step and velocities have received both half kicks.  (Where the lean fp32 kernel serves the
+ * context, the last step — with its energies — is made by the last pair launch itself; energies_dev is complete in
+ * stream order when the call returns either way, and a tmdhip_md_observe with TMDHIP_OBSERVE_AFTER_RUN finds the kinetic
+ * energy already summed.  Cell-list contexts with several replicas: the pair + step blocks of all replicas share ONE
+ * launch per step — ABI 8 —, every replica with its own neighbour state; TMDHIP_BATCH_REPLICAS=0 in the environment
+ * keeps the replica-by-replica loop.) */
 typedef struct tmdhip_md_desc {
   int32_t struct_size;
   int32_t niter;
@@ -208,9 +213,14 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream);
 /* What Integrator.step returns after its loop (integrator.py:121-125), with ONE read-back and ONE host
  * synchronisation: kinetic energy per replica (integrator.py:8-31), the per-term energies of the last step
  * (energies_dev = the buffer given to tmdhip_md_run; NULL: zeros) and the neighbour-list validity check.
- * out_host: double [R][TMDHIP_NENERGY + 1] = per-term energies, then Ekin.  Returns as tmdhip_check. */
+ * out_host: double [R][TMDHIP_NENERGY + 1] = per-term energies, then Ekin.  Returns as tmdhip_check.
+ * flags (ABI 8): TMDHIP_OBSERVE_AFTER_RUN = the caller vouches that vel_dev / mass_dev are the buffers of the tmdhip_md_run
+ * call of this context that has just returned and that NOTHING has written the velocities since (no rescaling, no
+ * tmdhip_second_vv, no restore).  Only then may the kinetic energy that the run's last launch has already summed be
+ * reused; without the flag (0) the kinetic-energy kernel always runs. */
+#define TMDHIP_OBSERVE_AFTER_RUN 1
 int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev, const double *energies_dev,
-                      double *out_host, void *stream);
+                      double *out_host, int flags, void *stream);
 /* Rewind: copy the state tmdhip_md_run saved at its entry (positions, velocities, forces of every replica)
  * back into desc's buffers.  Used after tmdhip_md_observe / tmdhip_check returned 1 for an MD batch (a list was
  * truncated: the capacity has been grown); the noise stream is counter based, so running the batch again gives

@@ -340,6 +340,75 @@ def test_replica_batched_md_matches_single_replica_runs():
     assert np.abs(pb[0] - pb[2]).max() > 1e-3
 
 
+@pytest.mark.parametrize("case", ["langevin", "nve", "langevin-switch", "nve-boxes", "nve-f64"])
+def test_replicas_of_a_celllist_context_in_one_launch_are_bit_identical(case, monkeypatch):
+    """The reference's batch axis on the cell-list path (systems.py:6-18, forces.py:105,116): fp32 contexts with several
+    replicas make ONE pair + step launch per MD step for all of them (round 6; every replica keeps its own neighbour state,
+    rebuild flags and pacing reports).  3 replicas of the 5 184-atom water box with different coordinates and velocities
+    (`boxes`: and different boxes), 2 x 30 steps (device-side rebuilds inside, two calls that end in a launch with
+    energies): positions, velocities and forces are bit-identical to the replica-by-replica loop of the same context
+    (TMDHIP_BATCH_REPLICAS=0), the returned energies to 1e-12 / 2e-7 (sums of the same terms in another order), and — without
+    thermostat, whose noise rows are numbered through the replicas of a context — to separate single-replica contexts.
+    fp64 contexts keep the loop (`f64`: batch and single-replica runs agree all the same)."""
+    import numpy as np
+
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev = torch.device("cuda:0")
+    dt = torch.float64 if case.endswith("f64") else torch.float32
+    langevin = case.startswith("langevin")
+    mol, pos0, box0 = tip3p_box(12, seed=3)
+    n = mol.numAtoms
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    rng = np.random.default_rng(5)
+    R = 3
+    scale = [1.0, 1.0, 1.0] if "boxes" not in case else [1.0, 1.004, 0.997]
+    starts = [(pos0 + 0.05 * rng.standard_normal(pos0.shape)) * scale[r] for r in range(R)]
+    vels = [0.02 * (1 + r) * rng.standard_normal(pos0.shape) for r in range(R)]
+    kw = dict(cutoff=9.0, rfa=True, **({"switch_dist": 7.5} if "switch" in case else {}))
+    monkeypatch.setenv("TMDHIP_LPA", "16")  # (a context picks its lanes per atom from the atoms that share a launch: pin it)
+
+    def run(idx, batch):
+        monkeypatch.setenv("TMDHIP_BATCH_REPLICAS", "1" if batch else "0")
+        k = len(idx)
+        s = System(n, k, dt, dev)
+        s.set_positions(np.stack([starts[i] for i in idx], axis=2))
+        s.set_box(np.stack([box0 * scale[i] for i in idx], axis=1))
+        s.set_velocities(torch.tensor(np.stack([vels[i] for i in idx])))
+        f = Forces(par, terms=terms, **kw)
+        f.compute(s.pos, s.box, s.forces)
+        torch.manual_seed(3)
+        integ = Integrator(s, f, 1.0, dev, **(dict(gamma=0.5, T=300.0) if langevin else {}))
+        out = [integ.step(30), integ.step(30)]
+        st = f.stats(s.pos)
+        res = (s.pos.clone(), s.vel.clone(), s.forces.clone(), out, st)
+        f.close()
+        return res
+
+    pb, vb, fb, ob, stb = run(list(range(R)), True)
+    ps, vs, fs, os_, sts = run(list(range(R)), False)
+    assert stb["n_rebuilds"] > 1 and sts["batched_launches"] == 0
+    if dt == torch.float32:
+        assert stb["batched_launches"] >= 58 and stb["final_steps_in_pair_launch"] == 2, stb  # 2 x (29 interior + 1 final) launches
+        assert stb["steps_in_pair_launch"] >= 56
+    else:
+        assert stb["batched_launches"] == 0
+    assert torch.equal(pb, ps) and torch.equal(vb, vs) and torch.equal(fb, fs)
+    for a, b in zip(ob, os_):
+        assert np.allclose(a[1], b[1], rtol=1e-12) and np.allclose(a[0], b[0], rtol=2e-7) and np.allclose(a[2], b[2], rtol=2e-7)
+    assert (pb[0] - pb[2]).abs().max().item() > 1e-3  # the replicas really differ
+    if not langevin:
+        for r in range(R):
+            p1, v1, f1, o1, _ = run([r], True)
+            assert torch.equal(pb[r], p1[0]) and torch.equal(vb[r], v1[0]) and torch.equal(fb[r], f1[0]), r
+            assert abs(ob[1][1][r] - o1[1][1][0]) <= 1e-12 * max(1.0, abs(o1[1][1][0]))
+
+
 def test_replica_batched_langevin_equals_stepwise_loop():
     """Batched all-pairs MD (one launch per kernel for all replicas) with the Langevin thermostat against
     the step-by-step Python loop over the stateless integrator kernels: same noise rows (replica * natoms +

@@ -21,9 +21,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIBPATH = os.path.join(LIBDIR, "libtmdhip.so")
-SOURCES = ["context.hip", "list_build.hip", "pair_generic.hip", "pair_fast_f32.hip", "pair_lean_f64.hip", "md_loop.hip",
+SOURCES = ["context.hip", "list_build.hip", "pair_generic.hip", "pair_fast_f32.hip", "pair_fast_f32_batch.hip", "pair_lean_f64.hip", "md_loop.hip",
            "bonded.hip", "integrator.hip", "domain.hip", "dd_migrate.hip"]
-HEADERS = ["common.h", "pair_math.h", "rng.h", "bonded_math.h", "engine.h", "md_step.h", "dd_comm.h",
+HEADERS = ["common.h", "pair_math.h", "rng.h", "bonded_math.h", "engine.h", "md_step.h", "pair_fast_kernel.h", "dd_comm.h",
            os.path.join("..", "..", "include", "tmdhip.h")]
 ARCH = "gfx950"
 FLAGS = ["-fno-slp-vectorize"]  # the SLP vectoriser packs the pair kernel into v_pk_* ops + v_mov transposes: measured slower

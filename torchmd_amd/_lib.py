@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # TMDHIP_LIB: developer knob for A/B runs of differently built libraries (kernel experiments)
 LIBPATH = os.environ.get("TMDHIP_LIB") or os.path.join(PKG, "lib", "libtmdhip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 F32, F64 = 0, 1
 TERM_LJ, TERM_ELECTROSTATICS, TERM_REPULSION, TERM_REPULSIONCG = 1, 2, 4, 8
 E_LJ, E_ELECTROSTATICS, E_REPULSION, E_REPULSIONCG, E_BONDS, E_ANGLES, E_DIHEDRALS, E_IMPROPERS = range(8)
@@ -23,6 +23,7 @@ ALL_REPLICAS = -1  # TMDHIP_ALL_REPLICAS
 DD_OVERRUN = 2  # TMDHIP_DD_OVERRUN: tmdhip_dd_run measured a displacement beyond the halo's half skin
 ALGO_AUTO, ALGO_ALLPAIRS, ALGO_CELLLIST = 0, 1, 2
 SWITCH_REFERENCE, SWITCH_EXACT = 0, 1
+OBSERVE_AFTER_RUN = 1  # TMDHIP_OBSERVE_AFTER_RUN
 
 ENERGY_SLOT = {
     "lj": E_LJ,
@@ -199,6 +200,8 @@ class Stats(C.Structure):
         ("chains_skipped", C.c_int64),
         ("steps_in_pair_launch", C.c_int64),
         ("fused_step_timeouts", C.c_int64),
+        ("final_steps_in_pair_launch", C.c_int64),
+        ("batched_launches", C.c_int64),
     ]
 
 
@@ -221,7 +224,7 @@ SIGNATURES = {
     "tmdhip_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "tmdhip_md_run": (C.c_int, [C.c_void_p, C.POINTER(MdDesc), C.c_void_p]),
     "tmdhip_md_restore": (C.c_int, [C.c_void_p, C.POINTER(MdDesc), C.c_void_p]),
-    "tmdhip_md_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
+    "tmdhip_md_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p]),
     "tmdhip_invalidate_list": (C.c_int, [C.c_void_p, C.c_int]),
     "tmdhip_update_atoms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "tmdhip_set_skin_weights": (C.c_int, [C.c_void_p, C.c_void_p]),

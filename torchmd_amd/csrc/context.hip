@@ -58,7 +58,7 @@ const void *set_boxes(tmdhip_ctx *ctx, const double *box_host, hipStream_t st) {
   return ctx->boxes.p;
 }
 
-int pick_lpa(int n, int capacity) {
+int pick_lpa(int64_t n, int capacity) {  // n: atoms whose waves share a launch (the replicas of a batched launch count together)
   if (const char *e = std::getenv("TMDHIP_LPA")) {  // tuning override: lanes per atom (power of two, 1..64)
     const int v = std::atoi(e);
     if (v >= 4 && v <= 64 && (v & (v - 1)) == 0) return v;
@@ -70,7 +70,7 @@ int pick_lpa(int n, int capacity) {
   int64_t want_waves = 2560;
   if (const char *e = std::getenv("TMDHIP_LPA_WAVES")) want_waves = std::max(1, std::atoi(e));
   int lpa = 1;
-  while (lpa < 64 && (int64_t)n * lpa < want_waves * 64) lpa <<= 1;
+  while (lpa < 64 && n * lpa < want_waves * 64) lpa <<= 1;
   // (2) list length: measured optimum LPA = 8 for water (440 entries per atom; 4 and 16 are 10 % slower)
   //     and 4 for liquid argon at 10^6 atoms (90 entries per atom; 1: +25 %, 2: +6 %, 8: +13 %);
   //     capacity = ~1.25 x the expected entries + 32
@@ -197,7 +197,9 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.ref.ensure(sizeof(R) * 3 * n));
   TMD_TRY(rp.nneigh.ensure(sizeof(int) * n));
   // lanes per atom from the MEAN list length (capacities are sized for the longest lists); fixed once a list exists
-  if (rp.lg.maxn == 0 || !rp.have_list) rp.lg.lpa = pick_lpa(n, (int)((maxn - 32) * ctx->mean_list_scale) + 32);
+  // (fp32 contexts with several replicas make ONE launch for all of them, md_loop.hip: their waves count together)
+  const int64_t launch_atoms = (int64_t)n * (ctx->d.dtype == TMDHIP_F32 ? std::min<int64_t>((int64_t)ctx->rep.size(), kBatchMax) : 1);
+  if (rp.lg.maxn == 0 || !rp.have_list) rp.lg.lpa = pick_lpa(launch_atoms, (int)((maxn - 32) * ctx->mean_list_scale) + 32);
   rp.lg.apw = 64 / rp.lg.lpa;
   rp.lg.lpa_shift = 0;
   while ((1 << rp.lg.lpa_shift) < rp.lg.lpa) rp.lg.lpa_shift++;
@@ -221,7 +223,7 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
 
 template <typename R>
 int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces,
-                 double *energies, int flags, hipStream_t st, const FusedLaunchT<R> *fused) {
+                 double *energies, int flags, hipStream_t st, const FusedLaunchT<R> *fused, ListOnlyOut *list_only) {
   const int n = ctx->d.natoms;
   const R *pos = (const R *)pos_v;
   const PairConsts<R> c = make_consts<R>(ctx, box);
@@ -316,6 +318,13 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
     }
     rp.have_list = true;
     TMD_TRY(alloc_replica<R>(ctx, rp, std::max(want, rp.lg.maxn)));
+  }
+  if (flags & kListOnly) {  // the caller launches (md_run's replica batch): rp.step counts the NEXT step by now
+    if (!list_only) return fail("compute_list: kListOnly without an output block");
+    list_only->lmode = ((flags & kViolationCheck) ? kLmViolation : 0) | (((rp.step - 1) & 1) ? kLmParity : 0) |
+                       (rp.pad_rows ? kLmPadded : 0) | (list_streams(ctx, rp) ? kLmStream : 0);
+    list_only->next_parity = (int)(rp.step & 1);
+    return 0;
   }
   R *f = (flags & TMDHIP_WANT_FORCES) ? (R *)forces : nullptr;
   unsigned long long *pc = nullptr;
@@ -435,9 +444,9 @@ int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
 template int alloc_replica<float>(tmdhip_ctx *, Replica &, int);
 template int alloc_replica<double>(tmdhip_ctx *, Replica &, int);
 template int compute_list<float>(tmdhip_ctx *, Replica &, const void *, const double *, void *, double *, int, hipStream_t,
-                                 const FusedLaunchT<float> *);
+                                 const FusedLaunchT<float> *, ListOnlyOut *);
 template int compute_list<double>(tmdhip_ctx *, Replica &, const void *, const double *, void *, double *, int, hipStream_t,
-                                  const FusedLaunchT<double> *);
+                                  const FusedLaunchT<double> *, ListOnlyOut *);
 
 }  // namespace tmd
 
@@ -549,7 +558,7 @@ void tmdhip_destroy(tmdhip_ctx *ctx) {
     rp.hostpub = nullptr;
     rp.release();
   }
-  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->half_skin, &ctx->half_skin2, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all, &ctx->snap})
+  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->half_skin, &ctx->half_skin2, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all, &ctx->snap, &ctx->batch_tab})
     b->release();
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
@@ -618,6 +627,7 @@ int tmdhip_update_atoms(tmdhip_ctx *ctx, int natoms, const int32_t *types_host, 
   TMD_HIP(hipDeviceSynchronize());  // nothing may still be reading the old per-atom arrays
   const int n = natoms;
   ctx->d.natoms = n;
+  ctx->ke_from_run = nullptr;
   ctx->nactive = nactive > 0 ? nactive : 0x7fffffff;
   ctx->open_bounds_valid = false;
   TMD_TRY(ctx->types.ensure(sizeof(int) * n));
@@ -719,6 +729,8 @@ int tmdhip_get_stats(tmdhip_ctx *ctx, int replica, tmdhip_stats *out) {
   out->chains_skipped = rp.chains_skipped;
   out->steps_in_pair_launch = rp.steps_in_pair_launch;
   out->fused_step_timeouts = ctx->fused_step_timeouts;
+  out->final_steps_in_pair_launch = ctx->final_steps_in_pair_launch;
+  out->batched_launches = ctx->batched_launches;
   out->pairs_in_cutoff = (int64_t)pc;
   out->algorithm = ctx->algorithm;
   out->max_neighbours = rp.lg.maxn;

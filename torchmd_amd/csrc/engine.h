@@ -419,6 +419,43 @@ struct FusedStaticT {
 };
 using FusedStatic = FusedStaticT<float>;
 
+// ---- the replicas of a cell-list context in one launch (list_pair_fast_f32_batch_kernel, pair_fast_kernel.h) --------------
+// BatchRep: one replica's buffers, device table [nreplicas] uploaded when an entry changes.  The two position buffers and the
+// two cell-sorted copies alternate from one fused launch to the next: the table holds both, BatchLaunch::bits says which is
+// current.
+struct BatchRep {
+  float4 *sorted[2];
+  float *pos[2];
+  const int *stype, *order;
+  const unsigned *nlist;
+  const int *nneigh;
+  float *forces;       // the caller's force array of this replica (FINAL step blocks)
+  double *escratch;    // this replica's rows of the energy scratch
+  const int *ext;
+  int *lflags;
+  int *padgen;
+  const FusedStatic *fst;
+  float4 *fsort;
+  unsigned *hostpub;   // host-mapped words of the pacing host: [0] progress, [1 + (seq & 1)] near reports (null: none)
+  float box[3], invbox[3];
+  int maxn;
+  int pad_;
+};
+constexpr int kBatchMax = 16;  // replicas per batched launch (larger contexts: several launches)
+// BatchLaunch::bits of a replica: the low bits are the launch's lmode (kLm*)
+constexpr unsigned kBlLmodeMask = 0xFFu;
+constexpr unsigned kBlSortedCur = 1u << 8;    // index of the current cell-sorted copy in BatchRep::sorted
+constexpr unsigned kBlPosCur = 1u << 9;       // index of the current position buffer in BatchRep::pos
+constexpr unsigned kBlNextParity = 1u << 10;  // parity of the NEXT step (FusedStepT::parity)
+constexpr unsigned kBlReports = 1u << 11;     // the step blocks report to the pacing host (FusedStepT::near_host)
+constexpr unsigned kBlPublish = 1u << 12;     // the replica's first block publishes `pub` as progress
+struct BatchLaunch {
+  int nrep, pair_blocks, step_blocks, bonded;
+  unsigned poll_limit, pad_;
+  uint64_t noise_step;
+  unsigned gen[kBatchMax], seq[kBatchMax], pub[kBatchMax], bits[kBatchMax];
+};
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -537,7 +574,7 @@ struct tmdhip_ctx {
   int64_t fused_step_timeouts = 0;
   // the last step of the last tmdhip_md_run was made by FINAL step blocks (md_step.h): the kinetic energy of the velocities
   // `ke_from_run` points at is in obs_ke already (tmdhip_md_observe then launches no kinetic-energy kernel)
-  const void *ke_from_run = nullptr;
+  const void *ke_from_run = nullptr, *ke_from_run_mass = nullptr;
   int64_t final_steps_in_pair_launch = 0;
   // velocity-dependent skins inside tmdhip_md_run (place_sorted_kernel): s_i = min(floor * static_i + time * |v_i|, cap)
   double vskin_floor = 0.8, vskin_time = 0, vskin_cap = 1.2, vskin_cap_len = 0;
@@ -545,6 +582,9 @@ struct tmdhip_ctx {
   tmd::DevBuf escratch;  // nreplicas x kEnergySlots x kEnergyStride doubles, all zero between calls (pair_math.h)
   tmd::DevBuf boxes;     // nreplicas x {box[3], 1/box[3]} for the replica-batched kernels
   tmd::DevBuf pos_alt_all;  // second position buffer [nreplicas][natoms][3] of the batched MD loop
+  tmd::DevBuf batch_tab;    // BatchRep[nreplicas]: the replicas' buffers for the batched pair + step launch (cell-list contexts)
+  std::vector<tmd::BatchRep> batch_host;  // what batch_tab holds
+  int64_t batched_launches = 0;
   std::vector<double> boxes_host;  // what `boxes` currently holds
   int max_excl = 0;
   int nactive = 0x7fffffff;  // atoms with original index >= nactive get empty lists (tmdhip_update_atoms)
@@ -654,6 +694,12 @@ constexpr int kSkipChain = 1 << 18;   // internal compute flag: the host leaves 
 constexpr int kDeferFold = 1 << 20;  // internal compute flag: a bonded evaluation with energies follows and folds the scratch rows
 constexpr int kViolationCheck = 1 << 19;  // internal compute flag: ... and the step's displacement test (epilogue of the
                                           // previous pair launch) did not know that: the pair launch looks itself
+constexpr int kListOnly = 1 << 21;   // internal compute flag: list bookkeeping only (displacement test / rebuild chain / chain skipped); the
+                                     // caller makes the pair launch itself — the replica-batched launch of md_run — from ListOnlyOut
+struct ListOnlyOut {
+  int lmode;        // list duties of the launch's first thread (kLm*)
+  int next_parity;  // parity of the step the launch's step blocks make
+};
 constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
 
 // ---- functions the translation units call across each other ---------------------------------------
@@ -665,7 +711,7 @@ template <typename R>
 int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn);
 template <typename R>
 int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *box, void *forces, double *energies,
-                 int flags, hipStream_t st, const FusedLaunchT<R> *fused = nullptr);
+                 int flags, hipStream_t st, const FusedLaunchT<R> *fused = nullptr, ListOnlyOut *list_only = nullptr);
 // bonded.hip
 void bonded_release(tmdhip_ctx *ctx);
 int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<float> &A);
@@ -690,6 +736,10 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
 template <bool ENERGY>
 int launch_pair_lean_f64(tmdhip_ctx *ctx, Replica &rp, const PairConsts<double> &c, double *f, int overwrite,
                          hipStream_t st, hipEvent_t e0, hipEvent_t e1, int lmode);
+// pair_fast_f32_batch.hip: the replicas rep0 .. rep0 + bl.nrep - 1 of a cell-list context in one FUSED launch (BatchRep / BatchLaunch)
+void fused_grid_shape(const tmdhip_ctx *ctx, const Replica &rp, int bonded, int &pair_blocks, int &step_blocks);
+int launch_pair_fast_f32_batch(tmdhip_ctx *ctx, int rep0, const PairConsts<float> &c, const BatchLaunch &bl, int lpa, bool energy,
+                               bool langevin, hipStream_t st);
 // md_loop.hip
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st);

@@ -215,6 +215,110 @@ bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairCon
   return only_lj_el && ctx->d.ntypes <= kEntryTypes && rp.lg.lpa >= 4 && rp.lg.lpa <= 64 && kFastThreads / rp.lg.lpa <= 64;
 }
 
+
+// ---- the replicas of a cell-list context in one pair + step launch (pair_fast_kernel.h: list_pair_fast_f32_batch_kernel) ----
+__global__ void batch_upload_kernel(BatchRep v, BatchRep *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+
+// what md_run collects per replica while it walks the replicas of an iteration that ends in ONE batched launch
+struct BatchItem {
+  FusedLaunchT<float> fl;
+  ListOnlyOut lo;
+  float *pos;       // positions of this launch's forces (cur[r])
+  float *home, *f;  // the caller's position / force rows of the replica
+  unsigned *pub_ptr;
+  unsigned pub_val;
+  double box[3];
+};
+
+// TMDHIP_BATCH_REPLICAS=0: the replica-by-replica loop (A/B, tests; read per call)
+static bool batch_replicas_on() {
+  const char *e = std::getenv("TMDHIP_BATCH_REPLICAS");
+  return !(e && std::atoi(e) == 0);
+}
+
+// One launch for the replicas of `items` (all of the context's): table entries that changed are re-uploaded (stream-ordered
+// one-thread kernels), the per-launch words travel as the kernel argument.  `energy`: the call's last step (FINAL step blocks).
+static int launch_replica_batch(tmdhip_ctx *ctx, std::vector<BatchItem> &items, int bonded, uint64_t noise_step, bool energy,
+                                bool langevin, hipStream_t st) {
+  const int nrep = (int)items.size(), n = ctx->d.natoms;
+  TMD_TRY(ctx->batch_tab.ensure(sizeof(BatchRep) * (size_t)nrep));
+  if ((int)ctx->batch_host.size() != nrep) {
+    ctx->batch_host.assign(nrep, BatchRep{});
+    for (auto &e : ctx->batch_host) std::memset(&e, 0xFF, sizeof(e));  // (matches nothing: every entry is uploaded)
+  }
+  int pair_blocks = 0, step_blocks = 0;
+  fused_grid_shape(ctx, ctx->rep[0], bonded, pair_blocks, step_blocks);
+  for (int g0 = 0; g0 < nrep; g0 += kBatchMax) {
+    const int gn = std::min(kBatchMax, nrep - g0);
+    BatchLaunch bl;
+    std::memset(&bl, 0, sizeof(bl));
+    bl.nrep = gn;
+    bl.pair_blocks = pair_blocks;
+    bl.step_blocks = step_blocks;
+    bl.bonded = bonded;
+    bl.poll_limit = 1u << 22;  // ~4 s of polling
+    bl.noise_step = noise_step;
+    PairConsts<float> c0 = make_consts<float>(ctx, items[g0].box);
+    for (int k = 0; k < gn; ++k) {
+      const int r = g0 + k;
+      Replica &rp = ctx->rep[r];
+      BatchItem &it = items[r];
+      if (rp.fsort.bytes < sizeof(float4) * (size_t)n) {
+        TMD_TRY(rp.fsort.ensure(sizeof(float4) * (size_t)n));
+        TMD_HIP(hipMemsetAsync(rp.fsort.p, 0, rp.fsort.bytes, st));  // launch number 0 = never written
+        rp.fused_gen = 0;
+      }
+      if (++rp.fused_gen == 0) rp.fused_gen = 1;
+      rp.fused_launches++;
+      const PairConsts<float> c = make_consts<float>(ctx, it.box);
+      BatchRep e;
+      std::memset(&e, 0, sizeof(e));
+      float4 *sa = rp.sorted.as<float4>(), *sb = rp.sorted_alt.as<float4>();
+      e.sorted[0] = std::min(sa, sb);
+      e.sorted[1] = std::max(sa, sb);
+      e.pos[0] = it.home;
+      e.pos[1] = rp.pos_alt.as<float>();
+      e.stype = rp.stype.as<int>();
+      e.order = rp.order.as<int>();
+      e.nlist = rp.nlist.as<unsigned>();
+      e.nneigh = rp.nneigh.as<int>();
+      e.forces = it.f;
+      e.escratch = ctx->escratch.as<double>() + (size_t)r * kEnergySlots * kEnergyStride;
+      e.ext = rp.extent.as<int>();
+      e.lflags = rp.flags.as<int>();
+      e.padgen = rp.padgen.as<int>();
+      e.fst = it.fl.fst;
+      e.fsort = rp.fsort.as<float4>();
+      e.hostpub = rp.hostpub;
+      for (int x = 0; x < 3; ++x) {
+        e.box[x] = c.box[x];
+        e.invbox[x] = c.invbox[x];
+      }
+      e.maxn = rp.lg.maxn;
+      if (std::memcmp(&e, &ctx->batch_host[r], sizeof(e)) != 0) {
+        hipLaunchKernelGGL(batch_upload_kernel, dim3(1), dim3(64), 0, st, e, ctx->batch_tab.as<BatchRep>() + r);
+        TMD_HIP(hipGetLastError());
+        ctx->batch_host[r] = e;
+      }
+      if (it.pos != e.pos[0] && it.pos != e.pos[1]) return fail("batched pair + step launch: positions in neither buffer of the replica");
+      unsigned bits = (unsigned)it.lo.lmode & kBlLmodeMask;
+      if (sa == e.sorted[1]) bits |= kBlSortedCur;
+      if (it.pos == e.pos[1]) bits |= kBlPosCur;
+      if (it.lo.next_parity) bits |= kBlNextParity;
+      if (it.fl.step.near_host) bits |= kBlReports;
+      if (it.pub_ptr) bits |= kBlPublish;
+      bl.bits[k] = bits;
+      bl.gen[k] = rp.fused_gen;
+      bl.seq[k] = it.fl.step.seq;
+      bl.pub[k] = it.pub_val;
+    }
+    TMD_TRY(launch_pair_fast_f32_batch(ctx, g0, c0, bl, ctx->rep[g0].lg.lpa, energy, langevin, st));
+  }
+  return 0;
+}
+
 template <typename R>
 int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   using R4 = typename Vec<R>::T4;
@@ -335,6 +439,33 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
       }
       continue;
     }
+    // The replicas of a cell-list context in ONE pair + step launch (round 6): when every replica of this iteration would make a
+    // fused launch of its own — same conditions as below — the loop over the replicas does the per-replica part (pacing, the
+    // first half step of a call, the rebuild chain) and the launch follows behind it.
+    std::vector<BatchItem> batch_items;
+    bool batching = false;
+    int batch_bonded = 0;
+    if constexpr (std::is_same<R, float>::value) {
+      const bool want_e = it == d->niter - 1 && d->energies_dev;
+      const bool interior = it + 1 < d->niter && !want_e, final_step = it + 1 == d->niter && want_e && final_on;
+      batching = first && nrep > 1 && ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0 && (interior || final_step) &&
+                 batch_replicas_on();
+      for (int r = 0; batching && r < nrep; ++r) {
+        const Replica &rp = ctx->rep[r];
+        const double *box = d->box_host + 3 * r;
+        const PairConsts<R> c = make_consts<R>(ctx, box);
+        BondedArgs<R> A;
+        std::memset(&A, 0, sizeof(A));
+        batching = rp.have_list && box[0] == rp.box[0] && box[1] == rp.box[1] && box[2] == rp.box[2] && !owed[r] && !finalized[r] &&
+                   fused_step_possible<R>(ctx, rp, c) && rp.lg.lpa == ctx->rep[0].lg.lpa;
+        if (batching) {
+          const int bm = tmd::bonded_inline_args(ctx, box, A);
+          batching = bm >= 0 && (r == 0 || bm == batch_bonded);
+          batch_bonded = bm;
+        }
+      }
+      if (batching) batch_items.resize(nrep);
+    }
     for (int r = 0; r < nrep; ++r) {
       Replica &rp = ctx->rep[r];
       const double *box = d->box_host + 3 * r;
@@ -449,7 +580,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
             // interior steps: the launch makes the next step; the last step of a call that wants energies (one replica):
             // the launch makes the final kick, the bonded force + energies and the kinetic energy (FINAL step blocks)
             const bool interior = it + 1 < d->niter && !en;
-            const bool final_step = it + 1 == d->niter && en && nrep == 1 && final_on && std::is_same<R, float>::value;
+            const bool final_step = it + 1 == d->niter && en && (nrep == 1 || batching) && final_on && std::is_same<R, float>::value;
             const int bm = (check && (interior || final_step) && fused_step_possible<R>(ctx, rp, c))
                                ? tmd::bonded_inline_args(ctx, box, A) : -1;
             if (bm >= 0) {
@@ -503,6 +634,25 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               fuse = true;
             }
           }
+          if constexpr (std::is_same<R, float>::value) {
+            if (batching) {  // list bookkeeping of this replica now, its blocks in the launch behind the loop
+              if (!fuse) return fail("tmdhip_md_run: a replica of the batch cannot make a fused launch");
+              BatchItem &bi = batch_items[r];
+              bi.fl = fl;
+              bi.pos = pos;
+              bi.home = home;
+              bi.f = f;
+              for (int k = 0; k < 3; ++k) bi.box[k] = box[k];
+              TMD_TRY(compute_list<R>(ctx, rp, pos, box, f, en,
+                                      flags_c | TMDHIP_OVERWRITE_FORCES | kListOnly | (check ? kPrechecked : 0) | (skip_chain ? kSkipChain : 0) |
+                                          (skip_chain && was_stepped ? kViolationCheck : 0),
+                                      st, &fl, &bi.lo));
+              bi.pub_ptr = rp.pub_ptr;
+              bi.pub_val = rp.pub_val;
+              rp.pub_ptr = nullptr;
+              continue;
+            }
+          }
           const int rc = compute_list<R>(ctx, rp, pos, box, f, en,
                                          flags_c | TMDHIP_OVERWRITE_FORCES | (check ? kPrechecked : 0) |
                                              (skip_chain ? kSkipChain : 0) |
@@ -519,6 +669,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
             TMD_HIP(hipGetLastError());
             finalized[r] = 1;
             ctx->ke_from_run = d->vel_dev;
+            ctx->ke_from_run_mass = d->mass_dev;
             ctx->final_steps_in_pair_launch++;
             continue;
           }
@@ -556,6 +707,32 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
         owed[r] = 1;
       } else {
         TMD_TRY(tmdhip_compute_bonded(ctx, r, pos, box, f, en, flags_c, st));
+      }
+    }
+    if constexpr (std::is_same<R, float>::value) {
+      if (batching) {
+        const bool want_e = it == d->niter - 1 && d->energies_dev;
+        TMD_TRY(launch_replica_batch(ctx, batch_items, batch_bonded, d->step0 + (uint64_t)it, want_e, langevin, st));
+        if (want_e) {
+          // the call's last step: forces (pair + bonded) in `forces`, velocities kicked; one fold block per replica adds its
+          // scratch rows (pair, bonded, kinetic) into the call's energy buffer and the context's kinetic-energy words
+          TMD_TRY(ctx->obs_ke.ensure(sizeof(double) * ctx->rep.size()));
+          hipLaunchKernelGGL(final_fold_kernel, dim3(nrep), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), d->energies_dev,
+                             ctx->obs_ke.as<double>());
+          TMD_HIP(hipGetLastError());
+          for (int r = 0; r < nrep; ++r) finalized[r] = 1;
+          ctx->ke_from_run = d->vel_dev;
+          ctx->ke_from_run_mass = d->mass_dev;
+          ctx->final_steps_in_pair_launch++;
+        } else {
+          for (int r = 0; r < nrep; ++r) {
+            Replica &rp = ctx->rep[r];
+            cur[r] = batch_items[r].fl.step.pos_out;
+            std::swap(rp.sorted, rp.sorted_alt);
+            stepped[r] = 1;
+            rp.steps_in_pair_launch++;
+          }
+        }
       }
     }
   }
@@ -619,7 +796,7 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
 }
 
 int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev, const double *energies_dev,
-                      double *out_host, void *stream) {
+                      double *out_host, int flags, void *stream) {
   if (!ctx || !vel_dev || !mass_dev || !out_host) return fail("tmdhip_md_observe: null argument");
   hipStream_t st = (hipStream_t)stream;
   const size_t nrep = ctx->rep.size();
@@ -633,8 +810,9 @@ int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev
   double *he = (double *)ctx->obs_host, *hk = he + TMDHIP_NENERGY * nrep;
   int *hf = (int *)((char *)ctx->obs_host + ebytes + kbytes);
   volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->obs_host + ebytes + kbytes + fbytes + 32);
-  if (ctx->ke_from_run == vel_dev && nrep == 1) {
-    // (the FINAL step blocks of the run that just ended have summed the kinetic energy of these velocities)
+  if ((flags & TMDHIP_OBSERVE_AFTER_RUN) && ctx->ke_from_run == vel_dev && ctx->ke_from_run_mass == mass_dev) {
+    // (the FINAL step blocks of the run that just ended have summed the kinetic energy of these velocities — every replica's —
+    // and the caller vouches that nothing has written them since)
   } else {
     TMD_TRY(tmdhip_kinetic_energy(ctx->d.dtype, (int64_t)nrep, ctx->d.natoms, vel_dev, mass_dev, ctx->obs_ke.as<double>(), stream));
   }
@@ -679,6 +857,7 @@ int tmdhip_md_restore(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream)
   TMD_HIP(hipMemcpyAsync(desc->forces_dev, sn + 2 * padded, bytes, hipMemcpyDeviceToDevice, st));
   for (auto &rp : ctx->rep) rp.box[0] = -1;  // re-plan + rebuild from the restored positions
   ctx->no_chain_skip_once = true;            // and no chain is left out while the batch is repeated
+  ctx->ke_from_run = nullptr;                // (the velocities are no longer those of the run that ended)
   return 0;
 }
 

@@ -154,10 +154,13 @@ static __global__ __launch_bounds__(kEnergySlots) void energy_fold_kernel(double
 }
 
 // the same for the final step of an MD call made by FINAL step blocks (md_step.h): slot TMDHIP_NENERGY of the rows holds
-// the kinetic energy; one block of kEnergySlots threads (one replica)
+// the kinetic energy; one block of kEnergySlots threads per replica (blockIdx.x: its scratch rows, its 8 energies, its word of `ke`)
 static __global__ __launch_bounds__(kEnergySlots) void final_fold_kernel(double *__restrict__ scratch, double *__restrict__ out,
                                                                   double *__restrict__ ke) {
   __shared__ double part[kEnergySlots / 64][TMDHIP_NENERGY + 1];
+  scratch += (size_t)blockIdx.x * kEnergySlots * kEnergyStride;
+  out += (size_t)blockIdx.x * TMDHIP_NENERGY;
+  ke += blockIdx.x;
   double *row = scratch + (size_t)threadIdx.x * kEnergyStride;
 #pragma unroll
   for (int k = 0; k <= TMDHIP_NENERGY; ++k) {

@@ -723,6 +723,8 @@ class Forces:
             "overflow": st.overflow,
             "ncell": tuple(st.ncell),
             "skin": st.skin,
+            "final_steps_in_pair_launch": st.final_steps_in_pair_launch,
+            "batched_launches": st.batched_launches,
             "chains_skipped": int(st.chains_skipped),
             "steps_in_pair_launch": int(st.steps_in_pair_launch),
             "fused_step_timeouts": int(st.fused_step_timeouts),

@@ -200,8 +200,9 @@ class Integrator:
             # ONE host synchronisation (tmdhip_md_observe)
             obs = np.empty((R, L.NENERGY + 1), dtype=np.float64)
             rc = L.check(
+                # (AFTER_RUN: nothing has touched the velocities since the tmdhip_md_run a few lines up returned)
                 lib.tmdhip_md_observe(eng.ctx, s.vel.data_ptr(), self.masses.data_ptr(), ebuf.data_ptr(),
-                                      obs.ctypes.data_as(C.POINTER(C.c_double)), _stream(dev)),
+                                      obs.ctypes.data_as(C.POINTER(C.c_double)), L.OBSERVE_AFTER_RUN, _stream(dev)),
                 "tmdhip_md_observe",
             )
             if rc != 0:
