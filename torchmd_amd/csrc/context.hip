@@ -287,6 +287,12 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
       rp.chains_skipped++;
       break;
     }
+    if (!force && (flags & kDeferChain) && (flags & kPrechecked) && list_only) {  // (the caller enqueues the chain, with other replicas')
+      list_only->chain = 1;
+      list_only->chain_parity = (int)(rp.step & 1);
+      rp.step++;
+      break;
+    }
     TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked)));
     rp.step++;
     if (!force) break;
@@ -558,7 +564,7 @@ void tmdhip_destroy(tmdhip_ctx *ctx) {
     rp.hostpub = nullptr;
     rp.release();
   }
-  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->half_skin, &ctx->half_skin2, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all, &ctx->snap, &ctx->batch_tab})
+  for (DevBuf *b : {&ctx->types, &ctx->qs, &ctx->tab, &ctx->excl_off, &ctx->excl_idx, &ctx->half_skin, &ctx->half_skin2, &ctx->escratch, &ctx->boxes, &ctx->pos_alt_all, &ctx->snap, &ctx->batch_tab, &ctx->chain_tab})
     b->release();
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);

@@ -585,6 +585,9 @@ struct tmdhip_ctx {
   tmd::DevBuf batch_tab;    // BatchRep[nreplicas]: the replicas' buffers for the batched pair + step launch (cell-list contexts)
   std::vector<tmd::BatchRep> batch_host;  // what batch_tab holds
   int64_t batched_launches = 0;
+  tmd::DevBuf chain_tab;    // ChainRepT[nreplicas] (list_build.hip): the replicas' arguments of the batched rebuild chain
+  std::vector<unsigned char> chain_host;  // what chain_tab holds
+  int64_t batched_chains = 0;
   std::vector<double> boxes_host;  // what `boxes` currently holds
   int max_excl = 0;
   int nactive = 0x7fffffff;  // atoms with original index >= nactive get empty lists (tmdhip_update_atoms)
@@ -699,7 +702,11 @@ constexpr int kListOnly = 1 << 21;   // internal compute flag: list bookkeeping 
 struct ListOnlyOut {
   int lmode;        // list duties of the launch's first thread (kLm*)
   int next_parity;  // parity of the step the launch's step blocks make
+  int chain;        // kDeferChain: this step's rebuild chain is wanted (the host has not left it out) ...
+  int chain_parity; // ... behind the flag word of this parity
 };
+constexpr int kDeferChain = 1 << 22;  // internal compute flag (with kListOnly): do not enqueue the rebuild chain, report it (the caller
+                                      // enqueues ONE chain for all replicas that want it: enqueue_chain_batch)
 constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
 
 // ---- functions the translation units call across each other ---------------------------------------
@@ -720,6 +727,10 @@ int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A
 template <typename R>
 int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force, hipStream_t st,
                         bool prechecked = false);
+// the rebuild chains of several replicas in one launch per kernel (list_build.hip)
+template <typename R>
+int enqueue_chain_batch(tmdhip_ctx *ctx, int nsel, const int *reps, const R *const *pos, const int *parity, const double *const *box,
+                        hipStream_t st);
 // pair_generic.hip
 template <typename R>
 int launch_allpairs(tmdhip_ctx *ctx, const void *pos, const double *box, void *forces, double *energies, int flags,

@@ -206,8 +206,8 @@ __device__ __forceinline__ void place_dummy(const PlaceArgs<R> &P, int which) {
 // The counts are cleared for the next build by the build kernel (one cell per block), not here: other blocks of
 // scan_place_kernel may still be reading them.
 template <typename R>
-__global__ void bin_members_kernel(int n, const R *__restrict__ pos, Grid g, int *__restrict__ cell_of, int *__restrict__ count,
-                                   int *__restrict__ members, int *flags, const int *flag) {
+__device__ __forceinline__ void bin_members_body(int n, const R *__restrict__ pos, const Grid &g, int *__restrict__ cell_of,
+                                                 int *__restrict__ count, int *__restrict__ members, int *flags, const int *flag) {
   if (*flag == 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -222,9 +222,14 @@ __global__ void bin_members_kernel(int n, const R *__restrict__ pos, Grid g, int
 }
 
 template <typename R>
-__global__ __launch_bounds__(256) void scan_place_kernel(int n, int ncell, const int *__restrict__ count,
-                                                         const int *__restrict__ members, int *__restrict__ cell_start_out,
-                                                         PlaceArgs<R> P, const int *flag) {
+__global__ void bin_members_kernel(int n, const R *__restrict__ pos, Grid g, int *__restrict__ cell_of, int *__restrict__ count,
+                                   int *__restrict__ members, int *flags, const int *flag) {
+  bin_members_body<R>(n, pos, g, cell_of, count, members, flags, flag);
+}
+
+template <typename R>
+__device__ __forceinline__ void scan_place_body(int n, int ncell, const int *__restrict__ count, const int *__restrict__ members,
+                                                int *__restrict__ cell_start_out, const PlaceArgs<R> &P, const int *flag) {
   if (*flag == 0) return;
   extern __shared__ int s_start[];  // [ncell + 1]
   __shared__ int wsum[4];
@@ -274,6 +279,13 @@ __global__ __launch_bounds__(256) void scan_place_kernel(int n, int ncell, const
 }
 
 template <typename R>
+__global__ __launch_bounds__(256) void scan_place_kernel(int n, int ncell, const int *__restrict__ count,
+                                                         const int *__restrict__ members, int *__restrict__ cell_start_out,
+                                                         PlaceArgs<R> P, const int *flag) {
+  scan_place_body<R>(n, ncell, count, members, cell_start_out, P, flag);
+}
+
+template <typename R>
 __global__ void place_sorted_kernel(int n, PlaceArgs<R> P, const int *flag) {
   if (*flag == 0) return;
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,9 +303,9 @@ __global__ void place_sorted_kernel(int n, PlaceArgs<R> P, const int *flag) {
 constexpr int kPrepSmallMaxCells = 4096;
 constexpr int kPrepSmallMaxAtoms = 8192;
 template <typename R>
-__global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__restrict__ pos, Grid g, int ncell,
-                                                          int *cell_of, int *__restrict__ slot, int *cell_start,
-                                                          int *order_tmp, PlaceArgs<R> P, const int *flag) {
+__device__ __forceinline__ void prep_small_body(int n, const R *__restrict__ pos, const Grid &g, int ncell, int *cell_of,
+                                                int *__restrict__ slot, int *cell_start, int *order_tmp, const PlaceArgs<R> &P,
+                                                const int *flag) {
   // (cell_of, cell_start and order_tmp are read back through P by place_atom below: no __restrict__ on them)
   if (*flag == 0) return;
   __shared__ int s_count[kPrepSmallMaxCells];
@@ -354,6 +366,12 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__rest
   }
   if (t < 2) place_dummy<R>(P, t);
 }
+template <typename R>
+__global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__restrict__ pos, Grid g, int ncell,
+                                                          int *cell_of, int *__restrict__ slot, int *cell_start,
+                                                          int *order_tmp, PlaceArgs<R> P, const int *flag) {
+  prep_small_body<R>(n, pos, g, ncell, cell_of, slot, cell_start, order_tmp, P, flag);
+}
 
 // ---- K2: Verlet list build ---------------------------------------------------------------------
 // One wave per cell.  The candidates (all atoms of the (2m+1)^3 stencil cells, which are contiguous
@@ -366,12 +384,10 @@ __global__ __launch_bounds__(1024) void prep_small_kernel(int n, const R *__rest
 // LPAS: log2 of the lanes per atom of the list layout as a compile-time constant (3 = the C3 / water layout: the masks and
 // shifts of a hit's byte offset become literals — full-rate VALU, no registers), or -1: read from ListGeom.
 template <typename R, bool LOOP, bool WSKIN, int LPAS>
-// (fp32: held to seven waves per SIMD — 72 VGPRs; the allocator is one register over without the hint and spills 16 bytes
-// in the prologue with it — because all 6 859 cell blocks of C3 are then resident at once: 7 168 slots)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 7 : 1, 8))) void build_list_kernel(
+__device__ __forceinline__ void build_list_body(
     int n, const typename Vec<R>::T4 *__restrict__ bsorted, const int *__restrict__ binfo,
-    const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
-    const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
+    const int *__restrict__ cell_start, const Grid &g, const PairConsts<R> &c, R rlist2, R rcut,
+    const int *__restrict__ excl_off, const int *__restrict__ excl_idx, const ListGeom &lg,
     unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
     int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split, int *__restrict__ count_zero) {
   if (*flag == 0) return;
@@ -848,6 +864,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) ==
   for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
   if (lane == 0 && wmax > 0) atomicMax(status, wmax);
 }
+template <typename R, bool LOOP, bool WSKIN, int LPAS>
+// (fp32: held to seven waves per SIMD — 72 VGPRs; the allocator is one register over without the hint and spills 16 bytes
+// in the prologue with it — because all 6 859 cell blocks of C3 are then resident at once: 7 168 slots)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 7 : 1, 8))) void build_list_kernel(
+    int n, const typename Vec<R>::T4 *__restrict__ bsorted, const int *__restrict__ binfo,
+    const int *__restrict__ cell_start, Grid g, PairConsts<R> c, R rlist2, R rcut,
+    const int *__restrict__ excl_off, const int *__restrict__ excl_idx, ListGeom lg,
+    unsigned *__restrict__ nlist, int *__restrict__ nneigh, int *__restrict__ status, const int *flag,
+    int ncell, int nactive, int type_in_entry, unsigned long long *dbg, int split, int *__restrict__ count_zero) {
+  build_list_body<R, LOOP, WSKIN, LPAS>(n, bsorted, binfo, cell_start, g, c, rlist2, rcut, excl_off, excl_idx, lg, nlist, nneigh, status, flag,
+                                        ncell, nactive, type_in_entry, dbg, split, count_zero);
+}
 
 // TMDHIP_DEBUG_TIMELINE=1: every block of the list build records its entry / exit cycle counters (4 x u64 per block),
 // read back with tmdhip_debug_build_timeline (tools/build_timeline.py).  Null otherwise: the kernel stores nothing.
@@ -861,6 +889,79 @@ unsigned long long *debug_timeline_buffer(int blocks) {
   return g_dbg_timeline.as<unsigned long long>();
 }
 
+
+// ---- the rebuild chains of several replicas in one launch per kernel (round 6) ---------------------------------------------------
+// The replicas of a cell-list context rebuild on their own steps, each behind its own flag; enqueued one after the other, R
+// chains are 2-3 R launches on every step on which somebody is near a limit, and a small box's rebuild runs on a fraction of
+// the chip while the others wait.  Here blockIdx.y picks the replica: its arguments come from a device table (ChainRepT: what
+// enqueue_chain would have passed by value, uploaded when an entry changes), what alternates from step to step — positions,
+// flag word, target copy — as a kernel argument (ChainSelT).  Same bodies, same per-replica results.
+template <typename R>
+struct ChainRepT {
+  Grid g;
+  PlaceArgs<R> P;
+  PairConsts<R> c;
+  ListGeom lg;
+  int *cell_of, *count, *members, *flags, *slot, *cell_start, *order_tmp;
+  const typename Vec<R>::T4 *bsorted;
+  const int *binfo;
+  unsigned *nlist;
+  int *nneigh;
+  int *count_zero;
+  R rlist2, rcut;
+  int ncell, nactive, type_in_entry, split, build_blocks;
+  int mode;  // 0: prep_small + build, 1: bin_members + scan_place + build
+  int wskin, lpas3;
+};
+template <typename R>
+struct ChainSelT {
+  int nsel;
+  int rep[kBatchMax];
+  const R *pos[kBatchMax];
+  const int *flag[kBatchMax];
+  typename Vec<R>::T4 *sorted[kBatchMax];
+};
+// the entry's PlaceArgs with this launch's positions and target copy (dummy_a / dummy_b are "both copies": order does not matter)
+template <typename R>
+__device__ __forceinline__ PlaceArgs<R> chain_place_args(const ChainRepT<R> &A, const ChainSelT<R> &sel, int y) {
+  PlaceArgs<R> P = A.P;
+  P.pos = sel.pos[y];
+  P.sorted = sel.sorted[y];
+  return P;
+}
+template <typename R>
+__global__ void bin_members_batch_kernel(int n, const ChainRepT<R> *__restrict__ tab, ChainSelT<R> sel) {
+  const int y = blockIdx.y;
+  const ChainRepT<R> &A = tab[sel.rep[y]];
+  bin_members_body<R>(n, sel.pos[y], A.g, A.cell_of, A.count, A.members, A.flags, sel.flag[y]);
+}
+template <typename R>
+__global__ __launch_bounds__(256) void scan_place_batch_kernel(int n, const ChainRepT<R> *__restrict__ tab, ChainSelT<R> sel) {
+  const int y = blockIdx.y;
+  const ChainRepT<R> &A = tab[sel.rep[y]];
+  if (*sel.flag[y] == 0) return;
+  const PlaceArgs<R> P = chain_place_args(A, sel, y);
+  scan_place_body<R>(n, A.ncell, A.count, A.members, A.cell_start, P, sel.flag[y]);
+}
+template <typename R>
+__global__ __launch_bounds__(1024) void prep_small_batch_kernel(int n, const ChainRepT<R> *__restrict__ tab, ChainSelT<R> sel) {
+  const int y = blockIdx.y;
+  const ChainRepT<R> &A = tab[sel.rep[y]];
+  if (*sel.flag[y] == 0) return;
+  const PlaceArgs<R> P = chain_place_args(A, sel, y);
+  prep_small_body<R>(n, sel.pos[y], A.g, A.ncell, A.cell_of, A.slot, A.cell_start, A.order_tmp, P, sel.flag[y]);
+}
+template <typename R, bool WSKIN, int LPAS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 7 : 1, 8))) void build_list_batch_kernel(
+    int n, const int *__restrict__ excl_off, const int *__restrict__ excl_idx, const ChainRepT<R> *__restrict__ tab, ChainSelT<R> sel) {
+  const int y = blockIdx.y;
+  const ChainRepT<R> &A = tab[sel.rep[y]];
+  if ((int)blockIdx.x >= A.build_blocks) return;
+  build_list_body<R, false, WSKIN, LPAS>(n, A.bsorted, A.binfo, A.cell_start, A.g, A.c, A.rlist2, A.rcut, excl_off, excl_idx, A.lg, A.nlist,
+                                         A.nneigh, A.flags + F_MAXN, sel.flag[y], A.ncell, A.nactive, A.type_in_entry, nullptr, A.split,
+                                         A.count_zero);
+}
+
 // the buffers a rebuild chain reads and writes (the replica's own)
 struct ListTarget {
   DevBuf *cell_of, *slot, *order_tmp, *count, *cell_start, *order, *inv, *stype, *ref, *sorted_hs, *hs2_dyn, *nlist, *nneigh, *sorted, *members;
@@ -868,8 +969,10 @@ struct ListTarget {
 
 // The rebuild chain: cell binning (one launch for small systems, two or four otherwise) and the list build, all on `st`.
 // Every kernel returns at once unless *flag != 0.
+// `plan`: fill the replica's entry of the batched chain's table instead of launching (enqueue_chain_batch)
 template <typename R>
-static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, const int *flag, hipStream_t st) {
+static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, const int *flag, hipStream_t st,
+                         ChainRepT<R> *plan = nullptr) {
   const ListTarget T = {&rp.cell_of, &rp.slot, &rp.order_tmp, &rp.count, &rp.cell_start, &rp.order, &rp.inv, &rp.stype, &rp.ref,
                         &rp.sorted_hs, &rp.hs2_dyn, &rp.nlist, &rp.nneigh, &rp.sorted, &rp.members};
   const hipStream_t st_build = st;
@@ -917,7 +1020,59 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
   static const bool prep_small_on = !(std::getenv("TMDHIP_PREP_SMALL") && std::atoi(std::getenv("TMDHIP_PREP_SMALL")) == 0);
   const bool bin2 = !rp.cell_cap_fallback && rp.ncell <= kScanPlaceMaxCells &&
                     T.members->bytes >= sizeof(int) * (size_t)rp.ncell * kCellCap;
-  if (prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells) {
+  const bool prep_small = prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells;
+  if (plan) {
+    // (the batched kernels run the one-launch and the two-launch binning; a replica on the four launches, or with more cells
+    // than one block per cell covers, keeps a chain of its own: mode -1)
+    constexpr int kMaxBlocks = 16384;
+    // (blocks per cell as for a lone replica.  Cutting small grids finer because the chip idles behind a batched chain was
+    // measured and is slower — 12 288 atoms x 8 / 5 184 atoms x 16, us per step at 2 / 4 / 8 blocks per cell: 92.7 / 97.7 /
+    // 105.8 and 98.5 / 99.9 / 110.2, profiles/r06_replica_batch.txt; TMDHIP_BATCH_BUILD_SPLIT overrides)
+    int split = 1;
+    if (const char *e = std::getenv("TMDHIP_BUILD_SPLIT")) split = std::max(1, std::min(std::atoi(e), 8));
+    else if (const char *e2 = std::getenv("TMDHIP_BATCH_BUILD_SPLIT")) split = std::max(1, std::min(std::atoi(e2), 8));
+    else if (rp.ncell <= 1100) split = 2;
+    if (rp.ncell * split > kMaxBlocks) split = 1;
+    std::memset(plan, 0, sizeof(*plan));
+    // (the one-block binning of small systems is a saving of launches for a lone replica — it takes 44 us on its one CU at 5 184
+    // atoms; a batch shares its launches among the replicas and bins in parallel: two-launch binning wherever it applies)
+    static const bool batch_prep_small = std::getenv("TMDHIP_BATCH_PREP_SMALL") && std::atoi(std::getenv("TMDHIP_BATCH_PREP_SMALL")) != 0;
+    plan->mode = (rp.ncell > kMaxBlocks) ? -1 : (bin2 && !(prep_small && batch_prep_small)) ? 1 : prep_small ? 0 : -1;
+    plan->g = rp.grid;
+    plan->P = P;
+    plan->P.pos = nullptr;     // (per launch: ChainSelT)
+    plan->P.sorted = nullptr;
+    if (rp.pad_rows) {         // both copies get the dummy records, whichever is current
+      R4 *a = rp.sorted.as<R4>() + n, *b = rp.sorted_alt.p ? rp.sorted_alt.as<R4>() + n : nullptr;
+      plan->P.dummy_a = (b && b < a) ? b : a;
+      plan->P.dummy_b = (b && b < a) ? a : b;
+    }
+    plan->c = c;
+    plan->lg = rp.lg;
+    plan->cell_of = T.cell_of->as<int>();
+    plan->count = T.count->as<int>();
+    plan->members = T.members->as<int>();
+    plan->flags = flags;
+    plan->slot = T.slot->as<int>();
+    plan->cell_start = T.cell_start->as<int>();
+    plan->order_tmp = T.order_tmp->as<int>();
+    plan->bsorted = rp.bsorted.as<R4>();
+    plan->binfo = rp.binfo.as<int>();
+    plan->nlist = T.nlist->as<unsigned>();
+    plan->nneigh = T.nneigh->as<int>();
+    plan->count_zero = plan->mode == 1 ? T.count->as<int>() : nullptr;
+    plan->rlist2 = (R)ctx->rlist * (R)ctx->rlist;
+    plan->rcut = (R)ctx->d.cutoff;
+    plan->ncell = rp.ncell;
+    plan->nactive = ctx->nactive;
+    plan->type_in_entry = ctx->d.ntypes <= kEntryTypes;
+    plan->split = split;
+    plan->build_blocks = rp.ncell * split;
+    plan->wskin = ctx->half_skin.p != nullptr;
+    plan->lpas3 = rp.lg.lpa_shift == 3;
+    return 0;
+  }
+  if (prep_small) {
     hipLaunchKernelGGL((prep_small_kernel<R>), dim3(1), dim3(1024), 0, st, n, pos, rp.grid, rp.ncell, T.cell_of->as<int>(),
                        T.slot->as<int>(), T.cell_start->as<int>(), T.order_tmp->as<int>(), P, flag);
   } else if (bin2) {
@@ -968,6 +1123,88 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
   TMD_HIP(hipGetLastError());
   return 0;
 }
+
+
+template <typename R>
+__global__ void chain_upload_kernel(ChainRepT<R> v, ChainRepT<R> *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+
+// The rebuild chains of the replicas reps[0 .. nsel) in one launch per kernel (see ChainRepT).  pos[k] / parity[k] / box[k]: what
+// enqueue_list_update would have been given for replica reps[k] (its displacement test has run already).  Replicas the batched
+// kernels do not cover (four-launch binning, more than 16 384 cells) or that differ in kernel variant get chains of their own.
+template <typename R>
+int enqueue_chain_batch(tmdhip_ctx *ctx, int nsel, const int *reps, const R *const *pos, const int *parity, const double *const *box,
+                        hipStream_t st) {
+  using R4 = typename Vec<R>::T4;
+  const int n = ctx->d.natoms, nrep = (int)ctx->rep.size();
+  std::vector<ChainRepT<R>> plan(nsel);
+  std::vector<PairConsts<R>> cs(nsel);
+  bool uniform = nsel > 1;
+  for (int k = 0; k < nsel; ++k) {
+    Replica &rp = ctx->rep[reps[k]];
+    cs[k] = make_consts<R>(ctx, box[k]);
+    TMD_TRY(enqueue_chain<R>(ctx, rp, pos[k], cs[k], rp.flags.as<int>() + F_REBUILD0 + parity[k], st, &plan[k]));
+    uniform = uniform && plan[k].mode >= 0 && plan[k].mode == plan[0].mode && plan[k].wskin == plan[0].wskin && plan[k].lpas3 == plan[0].lpas3;
+  }
+  if (!uniform) {
+    for (int k = 0; k < nsel; ++k) {
+      Replica &rp = ctx->rep[reps[k]];
+      TMD_TRY(enqueue_chain<R>(ctx, rp, pos[k], cs[k], rp.flags.as<int>() + F_REBUILD0 + parity[k], st));
+    }
+    return 0;
+  }
+  const size_t row = sizeof(ChainRepT<R>);
+  TMD_TRY(ctx->chain_tab.ensure(row * (size_t)nrep));
+  if (ctx->chain_host.size() != row * (size_t)nrep) ctx->chain_host.assign(row * (size_t)nrep, 0xA5);  // (matches nothing)
+  ChainRepT<R> *tab = ctx->chain_tab.as<ChainRepT<R>>();
+  for (int k = 0; k < nsel; ++k) {
+    unsigned char *have = ctx->chain_host.data() + row * (size_t)reps[k];
+    if (std::memcmp(have, &plan[k], row) != 0) {
+      hipLaunchKernelGGL((chain_upload_kernel<R>), dim3(1), dim3(64), 0, st, plan[k], tab + reps[k]);
+      TMD_HIP(hipGetLastError());
+      std::memcpy(have, &plan[k], row);
+    }
+  }
+  for (int g0 = 0; g0 < nsel; g0 += kBatchMax) {
+    const int gn = std::min(kBatchMax, nsel - g0);
+    ChainSelT<R> sel;
+    std::memset(&sel, 0, sizeof(sel));
+    sel.nsel = gn;
+    int max_cells = 0, max_blocks = 0;
+    for (int k = 0; k < gn; ++k) {
+      Replica &rp = ctx->rep[reps[g0 + k]];
+      sel.rep[k] = reps[g0 + k];
+      sel.pos[k] = pos[g0 + k];
+      sel.flag[k] = rp.flags.as<int>() + F_REBUILD0 + parity[g0 + k];
+      sel.sorted[k] = rp.sorted.as<R4>();
+      max_cells = std::max(max_cells, plan[g0 + k].ncell);
+      max_blocks = std::max(max_blocks, plan[g0 + k].build_blocks);
+    }
+    const int nb = (n + 255) / 256;
+    if (plan[0].mode == 0) {
+      hipLaunchKernelGGL((prep_small_batch_kernel<R>), dim3(1, gn), dim3(1024), 0, st, n, tab, sel);
+    } else {
+      hipLaunchKernelGGL((bin_members_batch_kernel<R>), dim3(nb, gn), dim3(256), 0, st, n, tab, sel);
+      hipLaunchKernelGGL((scan_place_batch_kernel<R>), dim3(nb, gn), dim3(256), sizeof(int) * ((size_t)max_cells + 1), st, n, tab, sel);
+    }
+    const dim3 bgrid(max_blocks, gn);
+#define TMD_BB(W, L) \
+  hipLaunchKernelGGL((build_list_batch_kernel<R, W, L>), bgrid, dim3(64), 0, st, n, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), tab, sel)
+    if (plan[0].lpas3) {
+      if (plan[0].wskin) TMD_BB(true, 3);
+      else TMD_BB(false, 3);
+    } else {
+      if (plan[0].wskin) TMD_BB(true, -1);
+      else TMD_BB(false, -1);
+    }
+#undef TMD_BB
+    TMD_HIP(hipGetLastError());
+    ctx->batched_chains++;
+  }
+  return 0;
+}
+template int enqueue_chain_batch<float>(tmdhip_ctx *, int, const int *, const float *const *, const int *, const double *const *, hipStream_t);
 
 // Enqueue: displacement check -> conditional rebuild chain.  `force` forces a rebuild.
 // `prechecked`: the fused MD-step kernel already ran the displacement test of this step.

@@ -643,8 +643,9 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               bi.home = home;
               bi.f = f;
               for (int k = 0; k < 3; ++k) bi.box[k] = box[k];
+              bi.lo.chain = 0;
               TMD_TRY(compute_list<R>(ctx, rp, pos, box, f, en,
-                                      flags_c | TMDHIP_OVERWRITE_FORCES | kListOnly | (check ? kPrechecked : 0) | (skip_chain ? kSkipChain : 0) |
+                                      flags_c | TMDHIP_OVERWRITE_FORCES | kListOnly | kDeferChain | (check ? kPrechecked : 0) | (skip_chain ? kSkipChain : 0) |
                                           (skip_chain && was_stepped ? kViolationCheck : 0),
                                       st, &fl, &bi.lo));
               bi.pub_ptr = rp.pub_ptr;
@@ -712,6 +713,19 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
     if constexpr (std::is_same<R, float>::value) {
       if (batching) {
         const bool want_e = it == d->niter - 1 && d->energies_dev;
+        {  // the rebuild chains the host has not left out: one launch per kernel for all of them
+          std::vector<int> reps, par;
+          std::vector<const float *> ps;
+          std::vector<const double *> bx;
+          for (int r = 0; r < nrep; ++r)
+            if (batch_items[r].lo.chain) {
+              reps.push_back(r);
+              par.push_back(batch_items[r].lo.chain_parity);
+              ps.push_back(batch_items[r].pos);
+              bx.push_back(batch_items[r].box);
+            }
+          if (!reps.empty()) TMD_TRY(enqueue_chain_batch<float>(ctx, (int)reps.size(), reps.data(), ps.data(), par.data(), bx.data(), st));
+        }
         TMD_TRY(launch_replica_batch(ctx, batch_items, batch_bonded, d->step0 + (uint64_t)it, want_e, langevin, st));
         if (want_e) {
           // the call's last step: forces (pair + bonded) in `forces`, velocities kicked; one fold block per replica adds its
