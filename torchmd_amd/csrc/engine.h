@@ -356,6 +356,11 @@ struct MdStepArgs {
   typename Vec<R>::T4 *sorted;
   const int *inv;
   const R *qs;
+  // the first kernel of a tmdhip_md_run call (first half step only) also saves the state at entry for tmdhip_md_restore —
+  // what snapshot3_kernel does as a launch of its own — and clears the call's energy buffer (null: neither)
+  R *snap_pos, *snap_vel, *snap_f;
+  double *zero;
+  int nzero;
 };
 
 // Everything the update of one atom reads, loaded in ONE batch before any arithmetic or store: the kernel is
@@ -557,11 +562,18 @@ struct tmdhip_ctx {
   double rlist = 0;         // cutoff + skin
   tmd::DevBuf snap;              // pos, vel, forces at the entry of the last tmdhip_md_run (replay)
   size_t snap_bytes = 0;
+  bool snap_pending = false;     // tmdhip_md_run has left the snapshot (and the zeroing of `snap_zero`) to md_run's first kernel
+  double *snap_zero = nullptr;
+  int snap_nzero = 0;
   tmd::DevBuf sync_e;            // tmdhip_compute: per-term energies [R][NENERGY] on the device ...
   void *sync_host = nullptr;  // ... and their pinned host landing zone (+ the list flags of every replica)
   tmd::DevBuf obs_ke;              // tmdhip_md_observe: kinetic energies [R] ...
   void *obs_host = nullptr;   // ... and the pinned landing zone of energies, kinetic energies and list flags
   unsigned obs_seq = 0;       // sequence number of the last observe_publish_kernel
+  // the last tmdhip_md_run reported its results itself (final_fold_publish_kernel): sequence number it wrote (0: it did not)
+  // and the energy buffer the report is of
+  unsigned run_published_seq = 0;
+  const double *run_published_energies = nullptr;
   tmd::DevBuf types, qs, tab, excl_off, excl_idx;
   // per-atom Verlet skins (tmdhip_set_skin_weights): half_skin[i] = w_i * skin / 2 and its square, original atom
   // order; empty = skin / 2 for every atom

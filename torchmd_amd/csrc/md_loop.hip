@@ -18,6 +18,17 @@ __global__ void md_step_kernel(MdStepArgs<R> s, PairConsts<R> c) {
   const uint64_t row0 = s.row0 + (CHECK ? 0 : (uint64_t)blockIdx.y * (uint64_t)s.n);
   const R none[3] = {0, 0, 0};
   const AtomIn<R> x = md_load_atom<R, SECOND, LANGEVIN, FIRST, CHECK>(s, i, off);
+  if constexpr (FIRST && !SECOND && CHECK) {
+    if (s.snap_pos) {  // the state at the entry of the call (tmdhip_md_restore), from the registers just loaded
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        s.snap_pos[3 * i + k] = x.p[k];
+        s.snap_vel[3 * i + k] = x.v[k];
+        s.snap_f[3 * i + k] = x.f[k];
+      }
+      if (i < s.nzero) s.zero[i] = 0.0;
+    }
+  }
   md_step_atom<R, SECOND, LANGEVIN, FIRST, CHECK>(s, c, i, off, row0, x, none, false);
 }
 
@@ -126,6 +137,64 @@ int publish_observables(tmdhip_ctx *ctx, const double *energies_dev, const doubl
                      host_flags, const_cast<unsigned *>(host_seq), ctx->obs_seq);
   TMD_HIP(hipGetLastError());
   return wait_observed(host_seq, ctx->obs_seq, st);
+}
+
+// the host-mapped landing zone of tmdhip_md_observe: energies [R][NENERGY] | kinetic energies [R] | list flags [R][F_COUNT] | sequence word
+struct ObsHost {
+  double *e, *ke;
+  int *flags;
+  volatile unsigned *seq;
+};
+static int obs_host_zone(tmdhip_ctx *ctx, ObsHost &z) {
+  const size_t nrep = ctx->rep.size();
+  const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, kbytes = sizeof(double) * nrep, fbytes = sizeof(int) * F_COUNT * nrep;
+  if (!ctx->obs_host) {
+    TMD_HIP(hipHostMalloc(&ctx->obs_host, ebytes + kbytes + fbytes + 64, hipHostMallocMapped));
+    std::memset(ctx->obs_host, 0, ebytes + kbytes + fbytes + 64);
+  }
+  z.e = (double *)ctx->obs_host;
+  z.ke = z.e + TMDHIP_NENERGY * nrep;
+  z.flags = (int *)((char *)ctx->obs_host + ebytes + kbytes);
+  z.seq = (volatile unsigned *)((char *)ctx->obs_host + ebytes + kbytes + fbytes + 32);
+  return 0;
+}
+
+// The last kernel of a tmdhip_md_run call whose final step was made by FINAL step blocks (one replica): final_fold_kernel's sums
+// AND observe_publish_kernel's report in one launch (round 6) — the energies of the call, the kinetic energy and the list flags go
+// to the host-mapped zone with the sequence word behind them, so that a tmdhip_md_observe(TMDHIP_OBSERVE_AFTER_RUN) launches
+// nothing and only waits for the word.
+__global__ __launch_bounds__(kEnergySlots) void final_fold_publish_kernel(double *__restrict__ scratch, double *__restrict__ out,
+                                                                          double *__restrict__ ke, const int *__restrict__ flags,
+                                                                          double *host_e, double *host_ke, int *host_flags,
+                                                                          unsigned *host_seq, unsigned seq) {
+  __shared__ double part[kEnergySlots / 64][TMDHIP_NENERGY + 1];
+  double *row = scratch + (size_t)threadIdx.x * kEnergyStride;
+#pragma unroll
+  for (int k = 0; k <= TMDHIP_NENERGY; ++k) {
+    const double v = row[k];
+    if (v != 0.0) row[k] = 0.0;
+    const double s = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x <= TMDHIP_NENERGY) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kEnergySlots / 64; ++w) s += part[w][threadIdx.x];
+    if (threadIdx.x < TMDHIP_NENERGY) {
+      const double e = out[threadIdx.x] + s;  // (the bonded kernel of a heavy topology has left its energies there already)
+      if (s != 0.0) out[threadIdx.x] = e;
+      host_e[threadIdx.x] = e;
+    } else {
+      ke[0] = s;
+      host_ke[0] = s;
+    }
+  } else if (threadIdx.x >= 64 && threadIdx.x < 64 + F_COUNT) {
+    host_flags[threadIdx.x - 64] = flags ? flags[threadIdx.x - 64] : 0;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // state at the entry of an MD batch (positions, velocities, forces) in one launch; n4 = 16-byte words per array
@@ -354,6 +423,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   std::vector<char> stepped(nrep, 0);  // the previous pair launch of the replica has made this iteration's step (FusedStep)
   std::vector<char> finalized(nrep, 0);  // the last pair launch made the call's final kick, bonded force and energies itself (FINAL step blocks)
   ctx->ke_from_run = nullptr;
+  ctx->run_published_seq = 0;
   const char *e_final = std::getenv("TMDHIP_FUSED_FINAL");  // (A/B, tests: 0 = the separate kernels behind the last pair launch)
   const bool final_on = !(e_final && std::atoi(e_final) == 0);
   for (int r = 0; r < nrep; ++r) cur[r] = (R *)d->pos_dev + r * stride;
@@ -362,6 +432,21 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
   R *bcur = home_all;
   bool bowed = false;
 
+  if (ctx->snap_pending) {
+    // the first kernel of the call takes the snapshot only when it is the plain first half step of a list replica with a valid
+    // list (the common case); otherwise the copy kernel runs after all
+    const Replica &rp0 = ctx->rep[0];
+    const double *box0 = d->box_host;
+    const bool takes = nrep == 1 && ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0 && rp0.have_list &&
+                       box0[0] == rp0.box[0] && box0[1] == rp0.box[1] && box0[2] == rp0.box[2];
+    if (!takes) {
+      const size_t bytes = sizeof(R) * stride * nrep, n4 = bytes / 16;
+      hipLaunchKernelGGL(snapshot3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4, (const uint4 *)d->pos_dev,
+                         (const uint4 *)d->vel_dev, (const uint4 *)d->forces_dev, ctx->snap.as<uint4>(), ctx->snap_zero, ctx->snap_nzero);
+      TMD_HIP(hipGetLastError());
+      ctx->snap_pending = false;
+    }
+  }
   for (int it = 0; it <= d->niter; ++it) {
     const bool first = it < d->niter, second = it > 0;
     a.noise_step = d->step0 + (uint64_t)(it > 0 ? it - 1 : 0);
@@ -555,7 +640,18 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
           a.pos_out = rp.pos_alt.as<R>();
           cur[r] = a.pos_out;
         }
+        if (ctx->snap_pending && check && nrep == 1) {  // (tmdhip_md_run left the snapshot of the entry state to this kernel)
+          const size_t padded = (sizeof(R) * stride + 15) / 16 * 16;
+          a.snap_pos = ctx->snap.as<R>();
+          a.snap_vel = (R *)(ctx->snap.as<char>() + padded);
+          a.snap_f = (R *)(ctx->snap.as<char>() + 2 * padded);
+          a.zero = ctx->snap_zero;
+          a.nzero = ctx->snap_nzero;
+          ctx->snap_pending = false;
+        }
         launch_md_step<R, false, false, true>(a, c, check, st);
+        a.snap_pos = a.snap_vel = a.snap_f = nullptr;
+        a.zero = nullptr;
       } else {
         if (langevin) launch_md_step<R, true, true, false>(a, c, check, st);
         else launch_md_step<R, true, false, false>(a, c, check, st);
@@ -665,8 +761,19 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
             // the call's last step: forces (pair + bonded) are in `forces`, velocities kicked, the energy rows (pair,
             // bonded, kinetic) folded here — into the call's energy buffer and the context's kinetic-energy word
             TMD_TRY(ctx->obs_ke.ensure(sizeof(double) * ctx->rep.size()));
-            hipLaunchKernelGGL(final_fold_kernel, dim3(1), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), en,
-                               ctx->obs_ke.as<double>());
+            if (nrep == 1) {  // ... and reported to the host in the same launch (tmdhip_md_observe then only waits for the word)
+              ObsHost z;
+              TMD_TRY(obs_host_zone(ctx, z));
+              if (++ctx->obs_seq == 0) ctx->obs_seq = 1;
+              hipLaunchKernelGGL(final_fold_publish_kernel, dim3(1), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), en,
+                                 ctx->obs_ke.as<double>(), rp.flags.as<int>(), z.e, z.ke, z.flags, const_cast<unsigned *>(z.seq),
+                                 ctx->obs_seq);
+              ctx->run_published_seq = ctx->obs_seq;
+              ctx->run_published_energies = en;
+            } else {
+              hipLaunchKernelGGL(final_fold_kernel, dim3(1), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), en,
+                                 ctx->obs_ke.as<double>());
+            }
             TMD_HIP(hipGetLastError());
             finalized[r] = 1;
             ctx->ke_from_run = d->vel_dev;
@@ -791,10 +898,10 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     if (aligned) {
       const size_t n4 = bytes / 16;
       const bool fits = (size_t)nzero <= n4;
-      hipLaunchKernelGGL(snapshot3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4,
-                         (const uint4 *)desc->pos_dev, (const uint4 *)desc->vel_dev, (const uint4 *)desc->forces_dev,
-                         (uint4 *)sn, fits ? desc->energies_dev : nullptr, nzero);
-      TMD_HIP(hipGetLastError());
+      // (md_run's first kernel saves the state itself where it can — one launch less per call —, else runs snapshot3_kernel)
+      ctx->snap_pending = true;
+      ctx->snap_zero = fits ? desc->energies_dev : nullptr;
+      ctx->snap_nzero = nzero;
       zeroed = zeroed || fits;
     } else {
       TMD_HIP(hipMemcpyAsync(sn, desc->pos_dev, bytes, hipMemcpyDeviceToDevice, st));
@@ -806,6 +913,11 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
   if (!zeroed) TMD_HIP(hipMemsetAsync(desc->energies_dev, 0, sizeof(double) * nzero, st));
   const int rc = ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
   for (auto &rp : ctx->rep) rp.skin_vel = nullptr;  // rebuilds outside an MD run know no velocities: static skins
+  if (rc == 0 && ctx->snap_pending) {
+    ctx->snap_pending = false;
+    return fail("tmdhip_md_run: the state at entry was not saved (internal error)");
+  }
+  ctx->snap_pending = false;
   return rc;
 }
 
@@ -815,16 +927,17 @@ int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev
   hipStream_t st = (hipStream_t)stream;
   const size_t nrep = ctx->rep.size();
   const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, kbytes = sizeof(double) * nrep;
-  const size_t fbytes = sizeof(int) * F_COUNT * nrep;
   TMD_TRY(ctx->obs_ke.ensure(kbytes));
-  if (!ctx->obs_host) {
-    TMD_HIP(hipHostMalloc(&ctx->obs_host, ebytes + kbytes + fbytes + 64, hipHostMallocMapped));
-    std::memset(ctx->obs_host, 0, ebytes + kbytes + fbytes + 64);
-  }
-  double *he = (double *)ctx->obs_host, *hk = he + TMDHIP_NENERGY * nrep;
-  int *hf = (int *)((char *)ctx->obs_host + ebytes + kbytes);
-  volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->obs_host + ebytes + kbytes + fbytes + 32);
-  if ((flags & TMDHIP_OBSERVE_AFTER_RUN) && ctx->ke_from_run == vel_dev && ctx->ke_from_run_mass == mass_dev) {
+  ObsHost z;
+  TMD_TRY(obs_host_zone(ctx, z));
+  double *he = z.e, *hk = z.ke;
+  int *hf = z.flags;
+  volatile unsigned *hseq = z.seq;
+  const bool after_run = (flags & TMDHIP_OBSERVE_AFTER_RUN) && ctx->ke_from_run == vel_dev && ctx->ke_from_run_mass == mass_dev;
+  const bool published = after_run && ctx->run_published_seq != 0 && ctx->run_published_energies == energies_dev;
+  const unsigned published_seq = ctx->run_published_seq;
+  ctx->run_published_seq = 0;
+  if (after_run) {
     // (the FINAL step blocks of the run that just ended have summed the kinetic energy of these velocities — every replica's —
     // and the caller vouches that nothing has written them since)
   } else {
@@ -832,7 +945,9 @@ int tmdhip_md_observe(tmdhip_ctx *ctx, const void *vel_dev, const void *mass_dev
   }
   ctx->ke_from_run = nullptr;
   const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
-  if (nrep <= 16) {
+  if (published) {  // the run's last kernel has reported already: nothing to launch
+    TMD_TRY(wait_observed(hseq, published_seq, st));
+  } else if (nrep <= 16) {
     TMD_TRY(publish_observables(ctx, energies_dev, ctx->obs_ke.as<double>(), lists, he, hk, hf, hseq, st));
   } else {
     if (energies_dev) TMD_HIP(hipMemcpyAsync(he, energies_dev, ebytes, hipMemcpyDeviceToHost, st));
