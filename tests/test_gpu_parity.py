@@ -328,7 +328,9 @@ def test_replicas_independent_lists():
     F1 = torch.zeros_like(p[1:2])
     e1 = f.compute(p[1:2].contiguous(), b[1:2], F1)
     assert abs(e2[1] - e1[0]) < 1e-4 * abs(e1[0])
-    assert (F[1:2] - F1).abs().max().item() < 1e-3
+    # (the 0.3 A noise makes close contacts: |F| up to 1e9, and a two-replica context picks its lanes per atom from the atoms
+    # that share a launch — another summation order than the one-replica context's: compare relative to the largest force)
+    assert (F[1:2] - F1).abs().max().item() < 2e-6 * max(1.0, F1.abs().max().item())
     assert abs(e2[0] - e2[1]) > 1.0  # replicas really differ
 
 

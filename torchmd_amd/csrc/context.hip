@@ -188,7 +188,7 @@ int alloc_replica(tmdhip_ctx *ctx, Replica &rp, int maxn) {
   TMD_TRY(rp.sorted.ensure(sizeof(R4) * ((size_t)n + 2)));
   TMD_TRY(rp.sorted_alt.ensure(sizeof(R4) * ((size_t)n + 2)));
   TMD_TRY(rp.stype.ensure(sizeof(int) * n));
-  TMD_TRY(rp.bsorted.ensure(sizeof(R4) * (size_t)n));
+  TMD_TRY(rp.bsorted.ensure(sizeof(float4) * (size_t)n));  // (the build's records are fp32 in either precision)
   TMD_TRY(rp.binfo.ensure(sizeof(int) * (size_t)n));
   if (ctx->half_skin.p) {
     TMD_TRY(rp.sorted_hs.ensure(ctx->real_size * (size_t)n));

@@ -95,6 +95,11 @@ __device__ __forceinline__ R wrap_into_box(R x, R box, R invbox) {
 //                 this build is incomplete; the caller switches the replica to the four-launch binning and repeats
 enum { F_REBUILD0 = 0, F_REBUILD1 = 1, F_MAXN = 2, F_NREBUILD = 3, F_VIOLATION = 4, F_STEP_TIMEOUT = 5, F_RESERVED = 6, F_CELLCAP = 7,
        F_COUNT = 8 };
+// The list build runs in fp32 in fp64 contexts too (round 6: its fp64 form took 223 us per rebuild at C3 against 146): positions
+// folded into the box and half skins are rounded to float (< 1e-5 A at a 100 A box) and every pair radius is widened by this
+// margin, so the fp32 build lists a superset of what the fp64 criterion would — completeness is what the displacement test
+// guarantees, the pair kernel applies the exact cutoff in the context's precision.
+constexpr double kBuildMarginF64 = 2.0e-4;
 constexpr int kCellCap = 64;             // members per cell of the two-launch binning
 constexpr int kScanPlaceMaxCells = 12288;  // cells whose prefix a block of scan_place_kernel can hold in LDS (48 KB)
 
@@ -237,7 +242,7 @@ struct PlaceArgs {
   // the list build's own view of the atoms (round 5), written here so that the build kernel neither wraps positions nor
   // loads four arrays per candidate: bsorted[slot] = {position folded into [0, box), the atom's half skin of this list
   // (0 without per-atom skins)}, binfo[slot] = original index | LJ class << 27 (class 0 where the entries carry none)
-  typename Vec<R>::T4 *bsorted;
+  float4 *bsorted;  // (fp32 in either precision: the list criterion has the skin as slack, engine.h: kBuildMarginF64)
   int *binfo;
   R box[3], invbox[3];
   int type_in_entry;

@@ -169,11 +169,11 @@ __device__ __forceinline__ typename Vec<R>::T4 place_atom_at(const PlaceArgs<R> 
     if (P.hs2_dyn) P.hs2_dyn[me] = h * h;
     hrec = h;
   }
-  typename Vec<R>::T4 b;
-  b.x = wrap_into_box(v.x, P.box[0], P.invbox[0]);
-  b.y = wrap_into_box(v.y, P.box[1], P.invbox[1]);
-  b.z = wrap_into_box(v.z, P.box[2], P.invbox[2]);
-  b.w = hrec;
+  float4 b;  // (fp64 contexts: folded in fp64, then rounded — kBuildMarginF64)
+  b.x = (float)wrap_into_box(v.x, P.box[0], P.invbox[0]);
+  b.y = (float)wrap_into_box(v.y, P.box[1], P.invbox[1]);
+  b.z = (float)wrap_into_box(v.z, P.box[2], P.invbox[2]);
+  b.w = (float)hrec;
   P.bsorted[dst] = b;
   P.ref[3 * me + 0] = v.x;
   P.ref[3 * me + 1] = v.y;
@@ -900,15 +900,15 @@ template <typename R>
 struct ChainRepT {
   Grid g;
   PlaceArgs<R> P;
-  PairConsts<R> c;
+  PairConsts<float> c;  // (of the build: fp32 in either precision)
   ListGeom lg;
   int *cell_of, *count, *members, *flags, *slot, *cell_start, *order_tmp;
-  const typename Vec<R>::T4 *bsorted;
+  const float4 *bsorted;
   const int *binfo;
   unsigned *nlist;
   int *nneigh;
   int *count_zero;
-  R rlist2, rcut;
+  float rlist2, rcut;
   int ncell, nactive, type_in_entry, split, build_blocks;
   int mode;  // 0: prep_small + build, 1: bin_members + scan_place + build
   int wskin, lpas3;
@@ -952,12 +952,12 @@ __global__ __launch_bounds__(1024) void prep_small_batch_kernel(int n, const Cha
   prep_small_body<R>(n, sel.pos[y], A.g, A.ncell, A.cell_of, A.slot, A.cell_start, A.order_tmp, P, sel.flag[y]);
 }
 template <typename R, bool WSKIN, int LPAS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 4 ? 7 : 1, 8))) void build_list_batch_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void build_list_batch_kernel(
     int n, const int *__restrict__ excl_off, const int *__restrict__ excl_idx, const ChainRepT<R> *__restrict__ tab, ChainSelT<R> sel) {
   const int y = blockIdx.y;
   const ChainRepT<R> &A = tab[sel.rep[y]];
   if ((int)blockIdx.x >= A.build_blocks) return;
-  build_list_body<R, false, WSKIN, LPAS>(n, A.bsorted, A.binfo, A.cell_start, A.g, A.c, A.rlist2, A.rcut, excl_off, excl_idx, A.lg, A.nlist,
+  build_list_body<float, false, WSKIN, LPAS>(n, A.bsorted, A.binfo, A.cell_start, A.g, A.c, A.rlist2, A.rcut, excl_off, excl_idx, A.lg, A.nlist,
                                          A.nneigh, A.flags + F_MAXN, sel.flag[y], A.ncell, A.nactive, A.type_in_entry, nullptr, A.split,
                                          A.count_zero);
 }
@@ -1000,8 +1000,17 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
   P.vs_cap = (R)ctx->vskin_cap_len;
   P.hs2_dyn = T.hs2_dyn->as<R>();
   P.ext = rp.extent.as<int>();
-  P.bsorted = rp.bsorted.as<R4>();
+  P.bsorted = rp.bsorted.as<float4>();
   P.binfo = rp.binfo.as<int>();
+  // the build's own constants: fp32 in either precision, every pair radius widened by kBuildMarginF64 in fp64 contexts
+  const double bmargin = std::is_same<R, double>::value ? kBuildMarginF64 : 0.0;
+  PairConsts<float> cb;
+  std::memset(&cb, 0, sizeof(cb));
+  for (int k = 0; k < 3; ++k) {
+    cb.box[k] = (float)c.box[k];
+    cb.invbox[k] = (float)c.invbox[k];
+  }
+  const float rlb = (float)(ctx->rlist + bmargin), rcb = (float)(ctx->d.cutoff + bmargin);
   for (int k = 0; k < 3; ++k) {
     P.box[k] = c.box[k];
     P.invbox[k] = c.invbox[k];
@@ -1047,7 +1056,7 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
       plan->P.dummy_a = (b && b < a) ? b : a;
       plan->P.dummy_b = (b && b < a) ? a : b;
     }
-    plan->c = c;
+    plan->c = cb;
     plan->lg = rp.lg;
     plan->cell_of = T.cell_of->as<int>();
     plan->count = T.count->as<int>();
@@ -1056,13 +1065,13 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
     plan->slot = T.slot->as<int>();
     plan->cell_start = T.cell_start->as<int>();
     plan->order_tmp = T.order_tmp->as<int>();
-    plan->bsorted = rp.bsorted.as<R4>();
+    plan->bsorted = rp.bsorted.as<float4>();
     plan->binfo = rp.binfo.as<int>();
     plan->nlist = T.nlist->as<unsigned>();
     plan->nneigh = T.nneigh->as<int>();
     plan->count_zero = plan->mode == 1 ? T.count->as<int>() : nullptr;
-    plan->rlist2 = (R)ctx->rlist * (R)ctx->rlist;
-    plan->rcut = (R)ctx->d.cutoff;
+    plan->rlist2 = rlb * rlb;
+    plan->rcut = rcb;
     plan->ncell = rp.ncell;
     plan->nactive = ctx->nactive;
     plan->type_in_entry = ctx->d.ntypes <= kEntryTypes;
@@ -1089,7 +1098,6 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
                        T.cell_start->as<int>(), T.order_tmp->as<int>(), flag);
     hipLaunchKernelGGL((place_sorted_kernel<R>), dim3(nb), dim3(256), 0, st, n, P, flag);
   }
-  const R rl = (R)ctx->rlist;
   constexpr int kMaxBuildBlocks = 16384;
   const bool wskin = ctx->half_skin.p != nullptr;
   // few cells: several blocks per cell (see build_list_kernel), so that ~2 000 waves are in flight
@@ -1099,20 +1107,20 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
                                          // MD step at split 1, 2, 4): 29.7 27.7 (28-37) / 37.8 35.5 35.0 / 43.0 44.6 48.3
   if (rp.ncell > kMaxBuildBlocks) split = 1;
   auto launch_build = [&](auto kernel, int blocks) {
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st_build, n, rp.bsorted.as<R4>(), rp.binfo.as<int>(),
-                       T.cell_start->as<int>(), rp.grid, c, rl * rl,
-                       (R)ctx->d.cutoff, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, T.nlist->as<unsigned>(),
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, st_build, n, rp.bsorted.as<float4>(), rp.binfo.as<int>(),
+                       T.cell_start->as<int>(), rp.grid, cb, rlb * rlb,
+                       rcb, ctx->excl_off.as<int>(), ctx->excl_idx.as<int>(), rp.lg, T.nlist->as<unsigned>(),
                        T.nneigh->as<int>(), flags + F_MAXN, flag, rp.ncell, ctx->nactive, ctx->d.ntypes <= kEntryTypes,
                        debug_timeline_buffer(blocks), split,
                        (bin2 && !(prep_small_on && n <= kPrepSmallMaxAtoms && rp.ncell <= kPrepSmallMaxCells)) ? T.count->as<int>() : nullptr);
   };
 #define TMD_BUILD(LOOPED, BLOCKS)                                                                   \
   if (rp.lg.lpa_shift == 3) {                                                                      \
-    if (wskin) launch_build(build_list_kernel<R, LOOPED, true, 3>, BLOCKS);                        \
-    else launch_build(build_list_kernel<R, LOOPED, false, 3>, BLOCKS);                             \
+    if (wskin) launch_build(build_list_kernel<float, LOOPED, true, 3>, BLOCKS);                    \
+    else launch_build(build_list_kernel<float, LOOPED, false, 3>, BLOCKS);                         \
   } else {                                                                                         \
-    if (wskin) launch_build(build_list_kernel<R, LOOPED, true, -1>, BLOCKS);                       \
-    else launch_build(build_list_kernel<R, LOOPED, false, -1>, BLOCKS);                            \
+    if (wskin) launch_build(build_list_kernel<float, LOOPED, true, -1>, BLOCKS);                   \
+    else launch_build(build_list_kernel<float, LOOPED, false, -1>, BLOCKS);                        \
   }
   if (rp.ncell <= kMaxBuildBlocks) {
     TMD_BUILD(false, rp.ncell * split)

@@ -32,37 +32,23 @@ __device__ __forceinline__ Philox philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi
 template <typename R>
 __device__ __forceinline__ void normal3(uint64_t seed, uint64_t step, uint64_t row, R &g0, R &g1, R &g2) {
   const Philox p = philox4x32_10(row, step, seed);
-  if constexpr (sizeof(R) == 4) {
-    // fp32: uniforms (c + 0.5) 2^-32 straight in fp32 (the top 24 bits of c survive, u never reaches 0; 1 is
-    // clamped off), and the hardware transcendentals: v_log_f32 (log2, ~1 ulp), v_sqrt_f32, v_sin/v_cos_f32
-    // (argument in revolutions, abs. error ~1e-6 — far below the statistical resolution of a thermostat).
-    // ~40 instructions instead of ~250 with the fp64 conversions and the libm routines.
-    const float inv32 = 2.3283064365386963e-10f;  // 2^-32
-    const float u0 = fminf(__builtin_fmaf((float)p.c[0], inv32, 0.5f * inv32), 0.99999994f);
-    const float u1 = __builtin_fmaf((float)p.c[1], inv32, 0.5f * inv32);
-    const float u2 = fminf(__builtin_fmaf((float)p.c[2], inv32, 0.5f * inv32), 0.99999994f);
-    const float u3 = __builtin_fmaf((float)p.c[3], inv32, 0.5f * inv32);
-    const float kLn2x2 = -1.3862943611198906f;  // -2 ln 2:  -2 ln u = kLn2x2 * log2 u
-    const float r0 = __builtin_amdgcn_sqrtf(kLn2x2 * __builtin_amdgcn_logf(u0));
-    const float r1 = __builtin_amdgcn_sqrtf(kLn2x2 * __builtin_amdgcn_logf(u2));
-    g0 = r0 * __builtin_amdgcn_cosf(u1);
-    g1 = r0 * __builtin_amdgcn_sinf(u1);
-    g2 = r1 * __builtin_amdgcn_cosf(u3);
-  } else {
-    const double inv32 = 2.3283064365386963e-10;  // 2^-32
-    const R u0 = (R)(((double)p.c[0] + 0.5) * inv32);
-    const R u1 = (R)(((double)p.c[1] + 0.5) * inv32);
-    const R u2 = (R)(((double)p.c[2] + 0.5) * inv32);
-    const R u3 = (R)(((double)p.c[3] + 0.5) * inv32);
-    R s0, c0, s1, c1;
-    const double r0 = sqrt(-2.0 * log(u0));
-    const double r1 = sqrt(-2.0 * log(u2));
-    sincospi(2.0 * u1, &s0, &c0);
-    sincospi(2.0 * u3, &s1, &c1);
-    g0 = r0 * c0;
-    g1 = r0 * s0;
-    g2 = r1 * c1;
-  }
+  // Uniforms (c + 0.5) 2^-32 straight in fp32 (the top 24 bits of c survive, u never reaches 0; 1 is clamped off), and the
+  // hardware transcendentals: v_log_f32 (log2, ~1 ulp), v_sqrt_f32, v_sin/v_cos_f32 (argument in revolutions, abs. error
+  // ~1e-6 — far below the statistical resolution of a thermostat).  ~40 instructions instead of ~250 with fp64 conversions
+  // and the libm routines.  fp64 contexts draw the same fp32 variates and widen them (round 6: the libm path was a third of
+  // the fp64 integrator kernel, 17.4 us at C3; the reference draws torch.randn_like from another generator anyway,
+  // integrator.py:73 — trajectory parity is statistical in either precision).
+  const float inv32 = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = fminf(__builtin_fmaf((float)p.c[0], inv32, 0.5f * inv32), 0.99999994f);
+  const float u1 = __builtin_fmaf((float)p.c[1], inv32, 0.5f * inv32);
+  const float u2 = fminf(__builtin_fmaf((float)p.c[2], inv32, 0.5f * inv32), 0.99999994f);
+  const float u3 = __builtin_fmaf((float)p.c[3], inv32, 0.5f * inv32);
+  const float kLn2x2 = -1.3862943611198906f;  // -2 ln 2:  -2 ln u = kLn2x2 * log2 u
+  const float r0 = __builtin_amdgcn_sqrtf(kLn2x2 * __builtin_amdgcn_logf(u0));
+  const float r1 = __builtin_amdgcn_sqrtf(kLn2x2 * __builtin_amdgcn_logf(u2));
+  g0 = (R)(r0 * __builtin_amdgcn_cosf(u1));
+  g1 = (R)(r0 * __builtin_amdgcn_sinf(u1));
+  g2 = (R)(r1 * __builtin_amdgcn_cosf(u3));
 }
 
 
