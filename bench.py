@@ -414,7 +414,7 @@ def ns_per_day(steps, seconds, timestep_fs=TIMESTEP_FS):
     return steps / seconds * timestep_fs * 1e-6 * 86400.0  # reference run.py:19,279 (FS2NS)
 
 
-def build_system(nside, device, dtype, seed, skin=None, skin_weights="mass"):
+def build_system(nside, device, dtype, seed, skin=None, skin_weights="mass", switch_dist=None):
     from torchmd_amd.builders import tip3p_box, water_forcefield
     from torchmd_amd.forces import Forces
     from torchmd_amd.integrator import maxwell_boltzmann
@@ -428,7 +428,7 @@ def build_system(nside, device, dtype, seed, skin=None, skin_weights="mass"):
     system.set_box(box)
     torch.manual_seed(seed)
     system.set_velocities(maxwell_boltzmann(par.masses, 300.0, 1))
-    forces = Forces(par, terms=TERMS, cutoff=CUTOFF, rfa=True, skin_weights=skin_weights,
+    forces = Forces(par, terms=TERMS, cutoff=CUTOFF, rfa=True, skin_weights=skin_weights, switch_dist=switch_dist,
                     **({} if skin is None else {"skin": skin}))
     return mol, par, system, forces, box
 
@@ -595,6 +595,9 @@ def main():
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin in A (default: the library's)")
     ap.add_argument("--skin-weights", default="mass", choices=["mass", "none"],
                     help="per-atom Verlet skins by mass (default) or one skin for every atom")
+    ap.add_argument("--switch-dist", type=float, default=None,
+                    help="profiling aid: run the MAIN leg with the LJ switching function from this distance (the line's "
+                    "`config.workload` says so; the default line carries the switched box as `secondary.c3_switch`)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --dry)")
     ap.add_argument("--dry", action="store_true", help="launcher/collective plumbing only, no GPU work (CPU test)")
     ap.add_argument("--config", default="c3", choices=["c3", "c5"],
@@ -631,7 +634,8 @@ def main():
 
     dtype = torch.float32
     mol, par, system, forces, box = build_system(args.nside, device, dtype, seed=1 + rank, skin=args.skin,
-                                                 skin_weights=None if args.skin_weights == "none" else "mass")
+                                                 skin_weights=None if args.skin_weights == "none" else "mass",
+                                                 switch_dist=args.switch_dist)
     fan.check_same_topology(mol.bonds, mol.angles, mol.charge)
     natoms = mol.numAtoms
 
@@ -643,7 +647,7 @@ def main():
     if args.warmup:
         integ.step(args.warmup)
 
-    leg = c3_leg(forces, integ, system, natoms, args.steps, fan, pmc=args.nside == 32)
+    leg = c3_leg(forces, integ, system, natoms, args.steps, fan, pmc=args.nside == 32, switched=args.switch_dist is not None)
     elapsed, obs, pcut = leg["elapsed"], leg["obs"], leg["pairs_in_cutoff"]
     steps_per_s = args.steps / elapsed
     value = ns_per_day(args.steps, elapsed) * world
@@ -664,7 +668,8 @@ def main():
         "config": {
             "workload": f"C3/C4 synthetic TIP3P water box: {natoms} atoms, L={box[0]:.3f} A, cutoff 9 A, "
             "reaction field, terms lj+electrostatics+bonds+angles (flexible water), Langevin 300 K "
-            "gamma 0.1/ps, timestep 1 fs; one independent replica per GPU",
+            "gamma 0.1/ps, timestep 1 fs; one independent replica per GPU"
+            + (f"; LJ switching function from {args.switch_dist} A (--switch-dist: NOT the headline configuration)" if args.switch_dist else ""),
             "natoms": natoms,
             "replicas": world,
             "timestep_fs": TIMESTEP_FS,
@@ -688,7 +693,7 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["ns_per_day_per_replica"] / best_cpu
         out["speedup_is_against"] = "port" if best_cpu == cb["value"] else "reference_in_build_container"
     secondary = {}
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary and args.switch_dist is None:
         # Secondary leg on the SAME box and state: the reference's production settings switch the LJ term from 7.5 A
         # (tests/prod_alanine_dipeptide_amber/conf.yaml:8-9, forces.py:399-413) — the SWITCH variant of the dominant launch.
         # max(--steps, 200) steps so that the window holds the list rebuilds in their steady proportion.

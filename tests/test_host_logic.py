@@ -615,23 +615,27 @@ def test_utils_mirror(tmp_path):
     assert out[0] == "2" and out[2].startswith("O 0.0 2.0 4.0") and len(out) == 8
 
 
-def test_bench_self_launch_gloo_world2():
-    """`python bench.py --gpus 2` outside torchrun starts its own two ranks (torch.distributed.run, 127.0.0.1)
-    — the path the driver's multi-GPU scaling run takes; here with the gloo backend and no GPU work (--dry).
-    Rank 0 prints ONE JSON line with n_gpus = 2 and both ranks' observables gathered."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_self_launch_gloo_world2(world):
+    """`python bench.py --gpus N` outside torchrun starts its own N ranks (torch.distributed.run, 127.0.0.1)
+    — the path the driver's multi-GPU scaling run takes (N = 1, 2, 4, 8 on one node); here with the gloo backend and no
+    GPU work (--dry), at world 2 and at the full 8 ranks of a node.  Rank 0 prints ONE JSON line with n_gpus = N and every
+    rank's observables gathered."""
     import json
     import subprocess
 
     env = dict(os.environ)
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry",
-                          "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--dry",
+                          "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["dry"] is True and out["ranks_seen"] == [0, 1] and out["steps"] == 5
+    assert out["n_gpus"] == world and out["dry"] is True and out["ranks_seen"] == list(range(world)) and out["steps"] == 5
+    if world != 2:
+        return
     # --gpus 1 needs no launcher (and no process group)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry", "--steps", "3"], capture_output=True,
                          text=True, timeout=300, env=env)

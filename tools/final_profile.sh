@@ -1,7 +1,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 R=$PWD
-TAG=${1:-r05_a}
+TAG=${1:-final}   # tools/final_profile.sh <tag>: kernel trace + PMC passes + bench lines of a round's last code commit
 bash tools/profile_round.sh $TAG > gpurun_out/profile_$TAG.log 2>&1
 bash tools/pmc_c5.sh $TAG > gpurun_out/pmc_c5_$TAG.log 2>&1
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err

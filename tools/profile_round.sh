@@ -9,7 +9,8 @@ TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 400 --warmup 100 --relax-steps 600 --no-cpu-baseline --no-secondary"
+# BENCH_EXTRA: further bench.py options, e.g. BENCH_EXTRA="--switch-dist 7.5" profiles the SWITCH variant of the launch
+CMD="python $R/bench.py --steps 400 --warmup 100 --relax-steps 600 --no-cpu-baseline --no-secondary ${BENCH_EXTRA:-}"
 timeout 280 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -- $CMD > /tmp/p_stats.log 2>&1
 for f in $(find /tmp/p_stats -name "*_results.db"); do python $R/profiles/summarize_rocpd.py $f > $OUT/kernel_stats.csv; done
 timeout 280 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -- $CMD > /tmp/p_fetch.log 2>&1

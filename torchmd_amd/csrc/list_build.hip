@@ -969,6 +969,14 @@ struct ListTarget {
 
 // The rebuild chain: cell binning (one launch for small systems, two or four otherwise) and the list build, all on `st`.
 // Every kernel returns at once unless *flag != 0.
+// INVARIANT: build_list_kernel is never launched without the placement kernels of the SAME chain in front of it — it reads
+// the atoms through bsorted / binfo, which only they write (wrapped positions and half skins of THIS build); a path that
+// rebuilt without re-placing (a capacity regrow that reused the cell order, say) would list from stale records.
+// The field widths the build relies on: slot and original indices < 2^23 (tmdhip_create refuses more atoms), a segment's
+// start in the low 24 bits of seg_start with the image code above it, the original index in kInfoIndexMask of binfo with
+// the LJ class above it.
+static_assert(kInfoIndexMask == (1 << kEntryTypeShift) - 1, "binfo: original index below the LJ class field");
+static_assert((kEntryOffMask >> 4) == (1u << 23) - 1u, "list entries carry 23-bit slots: seg_start packs a start < 2^23 below its image code (bit 24 up)");
 // `plan`: fill the replica's entry of the batched chain's table instead of launching (enqueue_chain_batch)
 template <typename R>
 static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, const int *flag, hipStream_t st,
