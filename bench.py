@@ -190,7 +190,7 @@ def dry_run_c5(args, rank, world):
         raise SystemExit("dry run of the domain decomposition FAILED: " + json.dumps(out))
 
 
-C5_TRAFFIC_FILES = ("r05_a_c5_pmc_traffic.json", "r04_c_c5_pmc_traffic.json", "r04_b_c5_pmc_traffic.json", "r04_c5_pmc_traffic.json", "r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json")  # newest committed PMC pass first
+C5_TRAFFIC_FILES = ("r06_c5_pmc_traffic.json", "r05_a_c5_pmc_traffic.json", "r04_c_c5_pmc_traffic.json", "r04_b_c5_pmc_traffic.json", "r04_c5_pmc_traffic.json", "r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json")  # newest committed PMC pass first
 
 
 def c5_single_gpu(args, device, cpu_budget_s=15.0, steps=None, warmup=None):

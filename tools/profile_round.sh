@@ -9,6 +9,7 @@ TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write /tmp/p_sq /tmp/p_tcp  # (a second pass on the same box must not find the first one's databases)
 # BENCH_EXTRA: further bench.py options, e.g. BENCH_EXTRA="--switch-dist 7.5" profiles the SWITCH variant of the launch
 CMD="python $R/bench.py --steps 400 --warmup 100 --relax-steps 600 --no-cpu-baseline --no-secondary ${BENCH_EXTRA:-}"
 timeout 280 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -- $CMD > /tmp/p_stats.log 2>&1
