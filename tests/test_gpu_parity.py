@@ -1213,3 +1213,52 @@ def test_more_than_2_pow_20_atoms_stay_on_the_lean_kernel():
     assert (F32 - F64).abs().max().item() < 1e-2
     assert abs(e32 - e64) < 2e-5 * abs(e64)
     assert -1.6 < e64 / mol.numAtoms < -0.6
+
+
+def test_plain_evaluations_leave_the_rebuild_chain_out_and_recover(monkeypatch):
+    """`compute()` with energies on the cell-list path (minimisers, callers that step the system themselves): the three
+    launches of the rebuild chain are left out while the previous evaluation found no atom near its displacement limit
+    (round 6, `tmdhip_compute`); an atom that crosses its limit all the same is caught by the flags the call reads back, and
+    the evaluation is repeated with a fresh list.  Same positions in, same energies and forces out as with the chain in
+    place on every evaluation (TMDHIP_SPEC_CHAIN=0) — small moves, a jump beyond the skin, small moves again."""
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev = _dev()
+    mol, pos, box = tip3p_box(12, seed=21)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=torch.float32)
+    rng = np.random.default_rng(2)
+    seq = [pos.copy()]
+    for k in range(5):
+        seq.append(seq[-1] + rng.normal(scale=0.01, size=pos.shape))
+    jump = seq[-1].copy()
+    jump[rng.choice(len(pos), 40, replace=False)] += rng.normal(scale=0.6, size=(40, 3))  # beyond the half skin of 0.6 A for many
+    seq.append(jump)
+    for k in range(4):
+        seq.append(seq[-1] + rng.normal(scale=0.01, size=pos.shape))
+    b = box_tensor(box, 1, torch.float32, dev)
+
+    def run(spec):
+        monkeypatch.setenv("TMDHIP_SPEC_CHAIN", "1" if spec else "0")
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        out = []
+        for x in seq:
+            p = pos_tensor(x, 1, torch.float32, dev)
+            F = torch.zeros_like(p)
+            e = f.compute(p, b, F, returnDetails=True)
+            out.append((e[0], F.cpu()))
+        st = f.stats(p)
+        f.close()
+        return out, st
+
+    a, sta = run(True)
+    c, stc = run(False)
+    # (evaluations 3-6 and the jump leave the chain out; the jump is caught and repeated, the evaluations behind it keep their chain)
+    assert sta["chains_skipped"] >= 4 and stc["chains_skipped"] == 0, (sta, stc)
+    assert sta["n_rebuilds"] >= 2  # the first list and the one behind the jump
+    for k, ((ea, Fa), (ec, Fc)) in enumerate(zip(a, c)):
+        for t in terms:
+            assert abs(ea[t] - ec[t]) <= 1e-12 * max(1.0, abs(ec[t])), (k, t, ea[t], ec[t])
+        assert torch.equal(Fa, Fc), k

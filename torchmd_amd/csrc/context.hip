@@ -293,7 +293,7 @@ int compute_list(tmdhip_ctx *ctx, Replica &rp, const void *pos_v, const double *
       rp.step++;
       break;
     }
-    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked)));
+    TMD_TRY(enqueue_list_update<R>(ctx, rp, pos, c, force, st, !force && (flags & kPrechecked), (flags & kSpecChain) != 0));
     rp.step++;
     if (!force) break;
     // forced builds are host-visible: size the list from the observed maximum so that later
@@ -432,6 +432,8 @@ int judge_flags(tmdhip_ctx *ctx, Replica &rp, const int *h, hipStream_t st) {
     (void)hipMemsetAsync(rp.flags.as<int>() + F_VIOLATION, 0, sizeof(int), st);
     ctx->no_chain_skip_once = true;
     rp.seq_valid = false;
+    rp.spec_valid = false;
+    rp.spec_backoff = 16;  // (plain evaluations: the next ones keep their chain)
     rp.box[0] = -1;  // re-plan + rebuild
     last_error() = "a neighbour list outlived its skin in a step without a rebuild chain (results since the last check are invalid)";
     if (h[F_MAXN] <= rp.lg.maxn) return 1;
@@ -788,8 +790,9 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
     if (ctx->d.terms == 0)  // no nonbonded kernel to store the forces: the bonded kernels add into zeros
       TMD_HIP(hipMemsetAsync(forces_dev, 0, (size_t)ctx->real_size * 3 * ctx->d.natoms * nrep, st));
   }
+  // (kSpecChain: this call reads every replica's list flags back before it returns and reports "repeat" on F_VIOLATION)
   TMD_TRY(tmdhip_compute_nonbonded(ctx, TMDHIP_ALL_REPLICAS, pos_dev, box_host, forces_dev, e,
-                                   flags | (forces_dev ? TMDHIP_OVERWRITE_FORCES : 0), stream));
+                                   flags | kSpecChain | (forces_dev ? TMDHIP_OVERWRITE_FORCES : 0), stream));
   TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos_dev, box_host, forces_dev, e, flags, stream));
   const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
   if (nrep <= 16) {  // results through host-mapped memory + a sequence word (md_loop.hip: observe_publish_kernel)

@@ -527,6 +527,10 @@ struct Replica {
   unsigned seq = 0;
   bool seq_valid = false;
   bool prev_skipped = false;
+  // plain evaluations through tmdhip_compute (which reads the flags back before it returns) leave the chain out the same way:
+  // the report of the PREVIOUS evaluation says whether anybody was near a limit (enqueue_list_update, `speculate`)
+  bool spec_valid = false;
+  int spec_backoff = 0;  // evaluations that keep their chain after a wrong guess
   unsigned *pub_ptr = nullptr;
   unsigned pub_val = 0;
   int64_t chains_skipped = 0;
@@ -722,6 +726,8 @@ struct ListOnlyOut {
   int chain;        // kDeferChain: this step's rebuild chain is wanted (the host has not left it out) ...
   int chain_parity; // ... behind the flag word of this parity
 };
+constexpr int kSpecChain = 1 << 23;   // internal compute flag (tmdhip_compute): the chain of a plain evaluation may be left out on the strength of the
+                                      // previous evaluation's report; the caller reads the flags back and repeats on F_VIOLATION
 constexpr int kDeferChain = 1 << 22;  // internal compute flag (with kListOnly): do not enqueue the rebuild chain, report it (the caller
                                       // enqueues ONE chain for all replicas that want it: enqueue_chain_batch)
 constexpr int kFallbackAllPairs = 77;  // compute_list: box too small for cells and algorithm = AUTO
@@ -743,7 +749,7 @@ int bonded_inline_args(tmdhip_ctx *ctx, const double *box, BondedArgs<double> &A
 // list_build.hip: displacement check -> conditional rebuild chain (every kernel returns at once unless the step's flag is set)
 template <typename R>
 int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force, hipStream_t st,
-                        bool prechecked = false);
+                        bool prechecked = false, bool speculate = false);
 // the rebuild chains of several replicas in one launch per kernel (list_build.hip)
 template <typename R>
 int enqueue_chain_batch(tmdhip_ctx *ctx, int nsel, const int *reps, const R *const *pos, const int *parity, const double *const *box,

@@ -1224,21 +1224,58 @@ template int enqueue_chain_batch<float>(tmdhip_ctx *, int, const int *, const fl
 
 // Enqueue: displacement check -> conditional rebuild chain.  `force` forces a rebuild.
 // `prechecked`: the fused MD-step kernel already ran the displacement test of this step.
+// `speculate` (plain evaluations through tmdhip_compute, round 6): the three launches of the chain return at once on almost every
+// evaluation of a minimiser or of a caller that steps the system itself (the External plugin, step(1) loops), and cost ~15 us of
+// a ~100-us evaluation.  The displacement test reports to host-mapped words like the MD loop's (ListCheck::near_host); when the
+// PREVIOUS evaluation found no atom beyond 75 % of its limit the chain is left out, and an atom that crosses its limit all the
+// same raises F_VIOLATION: tmdhip_compute reads the flags back before it returns, reports "repeat", and the repetition re-plans
+// and rebuilds (judge_flags); the next 16 evaluations keep their chain.
 template <typename R>
 int enqueue_list_update(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairConsts<R> &c, int force,
-                        hipStream_t st, bool prechecked) {
+                        hipStream_t st, bool prechecked, bool speculate) {
   using R4 = typename Vec<R>::T4;
   const int n = ctx->d.natoms;
   const int parity = (int)(rp.step & 1);
   const int *flag = rp.flags.as<int>() + F_REBUILD0 + parity;
-  if (!prechecked)
-    hipLaunchKernelGGL((check_displacement_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, pos, make_check<R>(ctx, rp), c,
+  bool skip = false;
+  if (!prechecked) {
+    ListCheck<R> k = make_check<R>(ctx, rp);
+    const char *e_spec = std::getenv("TMDHIP_SPEC_CHAIN");  // (0 switches it off; read per call: tests toggle it)
+    const bool spec_on = !(e_spec && std::atoi(e_spec) == 0);
+    if (speculate && spec_on && !force) {
+      if (!rp.hostpub) {
+        TMD_HIP(hipHostMalloc((void **)&rp.hostpub, 8 * sizeof(unsigned), hipHostMallocMapped));
+        for (int w = 0; w < 8; ++w) rp.hostpub[w] = 0u;
+        rp.seq = 0;
+      }
+      volatile unsigned *hp = rp.hostpub;
+      // (the previous evaluation's report: its call synchronised with the device before it returned)
+      if (rp.spec_valid && rp.spec_backoff == 0) skip = hp[1 + (rp.seq & 1u)] != rp.seq;
+      if (rp.spec_backoff > 0) rp.spec_backoff--;
+      if (++rp.seq == 0) rp.seq = 1;
+      k.near_host = rp.hostpub + 1 + (rp.seq & 1u);
+      k.seq = rp.seq;
+      k.near_frac2 = (R)(0.75 * 0.75);
+      k.skipped = skip ? 1 : 0;
+      rp.spec_valid = true;
+      rp.seq_valid = false;  // (the MD loop's pacing must not read a plain evaluation's report as its own)
+    } else {
+      rp.spec_valid = false;
+    }
+    hipLaunchKernelGGL((check_displacement_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st, n, pos, k, c,
                        force, rp.inv.as<int>(), ctx->qs.as<R>(), rp.sorted.as<R4>());
+  } else {
+    rp.spec_valid = false;
+  }
+  if (skip) {
+    rp.chains_skipped++;
+    return 0;
+  }
   return enqueue_chain<R>(ctx, rp, pos, c, flag, st);
 }
 
-template int enqueue_list_update<float>(tmdhip_ctx *, Replica &, const float *, const PairConsts<float> &, int, hipStream_t, bool);
-template int enqueue_list_update<double>(tmdhip_ctx *, Replica &, const double *, const PairConsts<double> &, int, hipStream_t, bool);
+template int enqueue_list_update<float>(tmdhip_ctx *, Replica &, const float *, const PairConsts<float> &, int, hipStream_t, bool, bool);
+template int enqueue_list_update<double>(tmdhip_ctx *, Replica &, const double *, const PairConsts<double> &, int, hipStream_t, bool, bool);
 
 }  // namespace tmd
 

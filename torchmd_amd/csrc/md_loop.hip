@@ -911,6 +911,7 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     ctx->snap_bytes = bytes;
   }
   if (!zeroed) TMD_HIP(hipMemsetAsync(desc->energies_dev, 0, sizeof(double) * nzero, st));
+  for (auto &rp : ctx->rep) rp.spec_valid = false;  // (a plain evaluation's report says nothing about positions this call moves)
   const int rc = ctx->d.dtype == TMDHIP_F32 ? md_run<float>(ctx, desc, st) : md_run<double>(ctx, desc, st);
   for (auto &rp : ctx->rep) rp.skin_vel = nullptr;  // rebuilds outside an MD run know no velocities: static skins
   if (rc == 0 && ctx->snap_pending) {
