@@ -18,12 +18,12 @@ from torchmd_amd.integrator import Integrator, maxwell_boltzmann  # noqa: E402
 from torchmd_amd.systems import System  # noqa: E402
 
 
-def run(name, terms, R, steps=4000, tutorial_loop=False, per_call=10, **kw):
+def run(name, terms, R, steps=4000, tutorial_loop=False, per_call=10, dtype=torch.float32, **kw):
     g = load(name)
     dev = torch.device("cuda:0")
-    par = GoldenParameters(g, torch.float32)
+    par = GoldenParameters(g, dtype)
     n = len(g["pos"])
-    s = System(n, R, torch.float32, dev)
+    s = System(n, R, dtype, dev)
     s.set_positions(g["pos"][:, :, None])
     s.set_box(g["box"])
     torch.manual_seed(1)
@@ -54,6 +54,8 @@ def run(name, terms, R, steps=4000, tutorial_loop=False, per_call=10, **kw):
     el = time.perf_counter() - t0
     if tutorial_loop:
         name += " (tutorial loop: wrap + host copy + CSV row every 10 steps)"
+    if dtype == torch.float64:
+        name += " fp64"
     print(f"{name} [step({per_call}) calls]: {n} atoms x {R} replicas, {el / steps * 1e6:.1f} us/step = {steps / el * 1e-6 * 86400:.0f} ns/day per replica, "
           f"T={T[0]:.0f} K, Epot={ep[0]:.1f}, algorithm={f.stats(s.pos)['algorithm']}")
 
@@ -62,6 +64,7 @@ if __name__ == "__main__":
     all7 = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
     run("ala2", all7, 1, cutoff=9.0, switch_dist=7.5, rfa=True)
     run("ala2", all7, 1, per_call=100, cutoff=9.0, switch_dist=7.5, rfa=True)  # (a call's fixed cost — ~50 us — spread over 100 steps)
+    run("ala2", all7, 1, per_call=100, dtype=torch.float64, cutoff=9.0, switch_dist=7.5, rfa=True)  # (C2's precision)
     run("ala2", all7, 1, tutorial_loop=True, cutoff=9.0, switch_dist=7.5, rfa=True)
     for R in (2, 16, 64):  # replicas share every launch (batched all-pairs / bonded / integrator kernels)
         run("water291", ["lj", "bonds", "angles", "electrostatics"], R, steps=2000, cutoff=7.3)
