@@ -127,8 +127,9 @@ int wait_observed(volatile unsigned *hseq, unsigned seq, hipStream_t st) {
   return 0;
 }
 
-int publish_observables(tmdhip_ctx *ctx, const double *energies_dev, const double *ke_dev, bool lists, double *host_e,
-                        double *host_ke, int *host_flags, volatile unsigned *host_seq, hipStream_t st) {
+// the launch of the report alone (<= 16 replicas); the caller waits for ctx->obs_seq (wait_observed) when it needs the values
+static int launch_publish(tmdhip_ctx *ctx, const double *energies_dev, const double *ke_dev, bool lists, double *host_e,
+                          double *host_ke, int *host_flags, volatile unsigned *host_seq, hipStream_t st) {
   const size_t nrep = ctx->rep.size();
   ObsFlagPtrs fp{};
   for (size_t r = 0; r < nrep; ++r) fp.p[r] = lists ? ctx->rep[r].flags.as<int>() : nullptr;
@@ -136,6 +137,12 @@ int publish_observables(tmdhip_ctx *ctx, const double *energies_dev, const doubl
   hipLaunchKernelGGL(observe_publish_kernel, dim3(1), dim3(128), 0, st, (int)nrep, energies_dev, ke_dev, fp, host_e, host_ke,
                      host_flags, const_cast<unsigned *>(host_seq), ctx->obs_seq);
   TMD_HIP(hipGetLastError());
+  return 0;
+}
+
+int publish_observables(tmdhip_ctx *ctx, const double *energies_dev, const double *ke_dev, bool lists, double *host_e,
+                        double *host_ke, int *host_flags, volatile unsigned *host_seq, hipStream_t st) {
+  TMD_TRY(launch_publish(ctx, energies_dev, ke_dev, lists, host_e, host_ke, host_flags, host_seq, st));
   return wait_observed(host_seq, ctx->obs_seq, st);
 }
 
@@ -919,6 +926,26 @@ int tmdhip_md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *desc, void *stream) {
     return fail("tmdhip_md_run: the state at entry was not saved (internal error)");
   }
   ctx->snap_pending = false;
+  // A call that returns energies is followed by tmdhip_md_observe (what Integrator.step does).  Its two launches — kinetic energy,
+  // report to the host — are enqueued HERE, behind the run's last kernel with no host round trip between them (small systems: the
+  // device idled ~20 us per call between the two C calls); tmdhip_md_observe(TMDHIP_OBSERVE_AFTER_RUN) then only waits for the
+  // sequence word.  (One replica on the lean fp32 kernel: the FINAL launch's fold kernel has reported already.)
+  const char *e_rep = std::getenv("TMDHIP_RUN_REPORTS");  // (0: tmdhip_md_observe launches them itself; A/B)
+  if (rc == 0 && desc->energies_dev && ctx->run_published_seq == 0 && ctx->rep.size() <= 16 && !(e_rep && std::atoi(e_rep) == 0)) {
+    ObsHost z;
+    TMD_TRY(obs_host_zone(ctx, z));
+    TMD_TRY(ctx->obs_ke.ensure(sizeof(double) * ctx->rep.size()));
+    if (ctx->ke_from_run != desc->vel_dev || ctx->ke_from_run_mass != desc->mass_dev) {
+      TMD_TRY(tmdhip_kinetic_energy(ctx->d.dtype, (int64_t)ctx->rep.size(), ctx->d.natoms, desc->vel_dev, desc->mass_dev,
+                                    ctx->obs_ke.as<double>(), stream));
+      ctx->ke_from_run = desc->vel_dev;
+      ctx->ke_from_run_mass = desc->mass_dev;
+    }
+    TMD_TRY(launch_publish(ctx, desc->energies_dev, ctx->obs_ke.as<double>(), ctx->algorithm == TMDHIP_ALGO_CELLLIST, z.e, z.ke, z.flags,
+                           z.seq, st));
+    ctx->run_published_seq = ctx->obs_seq;
+    ctx->run_published_energies = desc->energies_dev;
+  }
   return rc;
 }
 
