@@ -340,7 +340,7 @@ def test_replica_batched_md_matches_single_replica_runs():
     assert np.abs(pb[0] - pb[2]).max() > 1e-3
 
 
-@pytest.mark.parametrize("case", ["langevin", "nve", "langevin-switch", "nve-boxes", "nve-f64"])
+@pytest.mark.parametrize("case", ["langevin", "nve", "langevin-switch", "nve-boxes", "nve-f64", "nve-thrombin"])
 def test_replicas_of_a_celllist_context_in_one_launch_are_bit_identical(case, monkeypatch):
     """The reference's batch axis on the cell-list path (systems.py:6-18, forces.py:105,116): fp32 contexts with several
     replicas make ONE pair + step launch per MD step for all of them (round 6; every replica keeps its own neighbour state,
@@ -349,7 +349,9 @@ def test_replicas_of_a_celllist_context_in_one_launch_are_bit_identical(case, mo
     energies): positions, velocities and forces are bit-identical to the replica-by-replica loop of the same context
     (TMDHIP_BATCH_REPLICAS=0), the returned energies to 1e-12 / 2e-7 (sums of the same terms in another order), and — without
     thermostat, whose noise rows are numbered through the replicas of a context — to separate single-replica contexts.
-    fp64 contexts keep the loop (`f64`: batch and single-replica runs agree all the same)."""
+    fp64 contexts keep the loop (`f64`: batch and single-replica runs agree all the same).  `thrombin`: a heavy topology
+    (4 676-atom protein-ligand complex, all seven terms, open boundaries, cutoff 9 A) — the bonded force of every replica comes
+    from the wave-per-atom bonded kernel in front of the launch, on the final step with its energies."""
     import numpy as np
 
     from torchmd_amd.builders import tip3p_box, water_forcefield
@@ -361,16 +363,23 @@ def test_replicas_of_a_celllist_context_in_one_launch_are_bit_identical(case, mo
     dev = torch.device("cuda:0")
     dt = torch.float64 if case.endswith("f64") else torch.float32
     langevin = case.startswith("langevin")
-    mol, pos0, box0 = tip3p_box(12, seed=3)
-    n = mol.numAtoms
-    terms = ["lj", "electrostatics", "bonds", "angles"]
-    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
     rng = np.random.default_rng(5)
-    R = 3
+    if "thrombin" in case:
+        g = load("thrombin")
+        par = GoldenParameters(g, dt)
+        pos0, box0 = np.asarray(g["pos"], dtype=np.float64), np.zeros(3)
+        n = pos0.shape[0]
+        terms = ["bonds", "angles", "dihedrals", "impropers", "1-4", "electrostatics", "lj"]
+        R, kw, jitter, vscale = 2, dict(cutoff=9.0, algorithm="celllist"), 0.01, 0.01
+    else:
+        mol, pos0, box0 = tip3p_box(12, seed=3)
+        n = mol.numAtoms
+        terms = ["lj", "electrostatics", "bonds", "angles"]
+        par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+        R, kw, jitter, vscale = 3, dict(cutoff=9.0, rfa=True, **({"switch_dist": 7.5} if "switch" in case else {})), 0.05, 0.02
     scale = [1.0, 1.0, 1.0] if "boxes" not in case else [1.0, 1.004, 0.997]
-    starts = [(pos0 + 0.05 * rng.standard_normal(pos0.shape)) * scale[r] for r in range(R)]
-    vels = [0.02 * (1 + r) * rng.standard_normal(pos0.shape) for r in range(R)]
-    kw = dict(cutoff=9.0, rfa=True, **({"switch_dist": 7.5} if "switch" in case else {}))
+    starts = [(pos0 + jitter * rng.standard_normal(pos0.shape)) * scale[r] for r in range(R)]
+    vels = [vscale * (1 + r) * rng.standard_normal(pos0.shape) for r in range(R)]
     monkeypatch.setenv("TMDHIP_LPA", "16")  # (a context picks its lanes per atom from the atoms that share a launch: pin it)
 
     def run(idx, batch):
@@ -392,7 +401,7 @@ def test_replicas_of_a_celllist_context_in_one_launch_are_bit_identical(case, mo
 
     pb, vb, fb, ob, stb = run(list(range(R)), True)
     ps, vs, fs, os_, sts = run(list(range(R)), False)
-    assert stb["n_rebuilds"] > 1 and sts["batched_launches"] == 0
+    assert stb["n_rebuilds"] >= 1 and sts["batched_launches"] == 0 and stb["algorithm"] == "celllist"
     if dt == torch.float32:
         assert stb["batched_launches"] >= 58 and stb["final_steps_in_pair_launch"] == 2, stb  # 2 x (29 interior + 1 final) launches
         assert stb["steps_in_pair_launch"] >= 56
@@ -401,7 +410,7 @@ def test_replicas_of_a_celllist_context_in_one_launch_are_bit_identical(case, mo
     assert torch.equal(pb, ps) and torch.equal(vb, vs) and torch.equal(fb, fs)
     for a, b in zip(ob, os_):
         assert np.allclose(a[1], b[1], rtol=1e-12) and np.allclose(a[0], b[0], rtol=2e-7) and np.allclose(a[2], b[2], rtol=2e-7)
-    assert (pb[0] - pb[2]).abs().max().item() > 1e-3  # the replicas really differ
+    assert (pb[0] - pb[R - 1]).abs().max().item() > 1e-3  # the replicas really differ
     if not langevin:
         for r in range(R):
             p1, v1, f1, o1, _ = run([r], True)
@@ -948,3 +957,54 @@ def test_wrong_continuation_hint_is_rewound(monkeypatch):
     fresh.compute(s.pos, s.box, F2)
     assert torch.isfinite(s.forces).all()
     assert (F2 - s.forces).abs().max().item() < 2e-3
+
+
+def test_md_run_without_an_energy_buffer():
+    """C-ABI callers may pass `energies_dev = NULL` to tmdhip_md_run (include/tmdhip.h): no energies, no report, and — since the
+    call's first kernel takes the snapshot of the entry state and clears the energy buffer — nothing may be written through
+    the null pointer.  Same trajectory as a call with the buffer."""
+    import ctypes as C
+
+    import numpy as np
+
+    from torchmd_amd import _lib as L
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import TIMEFACTOR
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev = torch.device("cuda:0")
+    mol, pos, box = tip3p_box(12, seed=8)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=torch.float32)
+    out = []
+    for with_buffer in (True, False):
+        s = System(mol.numAtoms, 1, torch.float32, dev)
+        s.set_positions(pos[:, :, None])
+        s.set_box(box)
+        s.set_velocities(torch.tensor(0.01 * np.random.default_rng(1).standard_normal((1, mol.numAtoms, 3))))
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True)
+        f.compute(s.pos, s.box, s.forces)
+        eng = f._engine(s.pos)
+        masses = par.masses.to(dev, torch.float32).contiguous()
+        boxes = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(1, 3))
+        d = L.MdDesc()
+        d.struct_size = C.sizeof(L.MdDesc)
+        d.niter = 12
+        d.pos_dev, d.vel_dev, d.forces_dev = s.pos.data_ptr(), s.vel.data_ptr(), s.forces.data_ptr()
+        d.mass_dev = masses.data_ptr()
+        d.vcoeff_dev = None
+        d.box_host = boxes.ctypes.data_as(C.c_void_p)
+        d.dt, d.gamma = 1.0 / TIMEFACTOR, 0.0
+        d.seed, d.step0 = 1, 0
+        d.energies_dev = eng.ebuf.data_ptr() if with_buffer else None
+        d.continuation = 0
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(eng.lib.tmdhip_md_run(eng.ctx, C.byref(d), stream), "tmdhip_md_run")
+        torch.cuda.synchronize()
+        assert L.check(eng.lib.tmdhip_check(eng.ctx, 0, stream), "tmdhip_check") == 0
+        out.append((s.pos.clone(), s.vel.clone()))
+        f.close()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert torch.isfinite(out[1][0]).all()

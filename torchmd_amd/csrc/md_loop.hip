@@ -26,7 +26,7 @@ __global__ void md_step_kernel(MdStepArgs<R> s, PairConsts<R> c) {
         s.snap_vel[3 * i + k] = x.v[k];
         s.snap_f[3 * i + k] = x.f[k];
       }
-      if (i < s.nzero) s.zero[i] = 0.0;
+      if (s.zero && i < s.nzero) s.zero[i] = 0.0;
     }
   }
   md_step_atom<R, SECOND, LANGEVIN, FIRST, CHECK>(s, c, i, off, row0, x, none, false);
