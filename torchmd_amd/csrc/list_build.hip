@@ -989,6 +989,7 @@ static int enqueue_chain(tmdhip_ctx *ctx, Replica &rp, const R *pos, const PairC
   int *flags = rp.flags.as<int>();
   const int nb = (n + 255) / 256;
   PlaceArgs<R> P;
+  std::memset(&P, 0, sizeof(P));  // (padding bytes too: the batched chain compares table entries with memcmp)
   P.cell_of = T.cell_of->as<int>();
   P.cell_start = T.cell_start->as<int>();
   P.order_tmp = T.order_tmp->as<int>();
