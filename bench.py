@@ -193,7 +193,7 @@ def dry_run_c5(args, rank, world):
 C5_TRAFFIC_FILES = ("r06_c5_pmc_traffic.json", "r05_a_c5_pmc_traffic.json", "r04_c_c5_pmc_traffic.json", "r04_b_c5_pmc_traffic.json", "r04_c5_pmc_traffic.json", "r03_d_c5_pmc_traffic.json", "r03_c5_pmc_traffic.json")  # newest committed PMC pass first
 
 
-def c5_single_gpu(args, device, cpu_budget_s=15.0, steps=None, warmup=None):
+def c5_single_gpu(args, device, cpu_budget_s=15.0, steps=None, warmup=None, defer_cpu=False):
     """Config C5 on ONE GPU: the whole 10^6-atom argon box on the single-domain engine.  Returns the fields of a bench
     line (value, ms_per_step, roofline, cpu_baseline, ...): `--config c5 --gpus 1` prints them as its line, the default
     run embeds them as `secondary.c5`."""
@@ -220,12 +220,14 @@ def c5_single_gpu(args, device, cpu_budget_s=15.0, steps=None, warmup=None):
     warmup = args.warmup if warmup is None else warmup
     integ.step(max(warmup, 1))
     st0 = f.stats(s.pos)
+    replays0 = integ.replays
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ekin, epot, temp = integ.step(steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     st1 = f.stats(s.pos)
+    replays = integ.replays - replays0
     pair_ms, pair_launches = time_pair_launches(f, integ, s)
     pcut = f.count_pairs(s.pos, s.box)[0]
     # (as in the C3 line: the timed launches also make the MD step -> SURVEY 8(d)'s whole-step bytes)
@@ -258,10 +260,12 @@ def c5_single_gpu(args, device, cpu_budget_s=15.0, steps=None, warmup=None):
                     "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "note": "~30 FLOP per LJ-only pair"},
         },
         "list": {"rebuilds_in_timed_region": int(st1["n_rebuilds"] - st0["n_rebuilds"]),
+                 "rebuild_chains_left_out": int(st1["chains_skipped"] - st0["chains_skipped"]),
+                 "batches_rewound_and_repeated": int(replays),
                  "entries": int(st1["list_entries"]), "ncell": list(st1["ncell"]), "skin": st1["skin"]},
         "temperature_K": [float(temp[0])],
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and not defer_cpu:  # (defer_cpu: the caller runs the CPU legs behind all GPU legs)
         out["cpu_baseline"] = cpu_baseline_c5(natoms, budget_s=cpu_budget_s)
     f.close()
     del s, f, integ
@@ -433,16 +437,20 @@ def build_system(nside, device, dtype, seed, skin=None, skin_weights="mass", swi
     return mol, par, system, forces, box
 
 
-def cpu_baseline(par, system, box, budget_s=20.0):
+def host_state(system):
+    """Positions, velocities, forces and box of `system` on the host (what cpu_baseline starts from)."""
+    return tuple(t.detach().cpu().clone() for t in (system.pos, system.vel, system.forces, system.box))
+
+
+def cpu_baseline(par, state, box, budget_s=20.0):
     """Reference arithmetic on the host cores: the oracle's md_step (same torch CPU ops as the reference,
-    sparse candidate pair list as in SURVEY.md §8(d)-(ii)) on the same relaxed box.  The candidate-list
-    build is excluded from the timing (favourable to the CPU)."""
+    sparse candidate pair list as in SURVEY.md §8(d)-(ii)) on the same relaxed box (`state` = host_state() of it).  The
+    candidate-list build is excluded from the timing (favourable to the CPU).  Runs LAST in a bench run: its worker threads keep
+    spinning for a while behind their last parallel region, and a GPU leg whose host thread paces one launch ahead of the
+    device must not share the cores with them."""
     from oracle import torchmd_oracle as orc
 
-    pos = system.pos.detach().cpu().clone()
-    vel = system.vel.detach().cpu().clone()
-    frc = system.forces.detach().cpu().clone()
-    cbox = system.box.detach().cpu().clone()
+    pos, vel, frc, cbox = state
     masses = par.masses.to(pos.dtype).view(-1, 1)
     pairs = orc.candidate_pairs(pos[0].double().numpy(), box, CUTOFF + 0.6, orc.exclusion_pairs(par))
     dt, gamma, vcoeff = orc.integrator_constants(TIMESTEP_FS, 0.1, 300.0, masses)
@@ -685,13 +693,8 @@ def main():
     }
     if world > 1:
         out["rccl"] = rccl_info(world, args.backend)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cb = cpu_baseline(par, system, box, budget_s=15.0)
-        # quoted against the FASTER of the two CPU figures (the port timed here, the reference's own classes in the build container)
-        ref = cb.get("reference_in_build_container") or {}
-        best_cpu = max(cb["value"], ref.get("value") or 0.0)
-        out["speedup_vs_cpu_baseline"] = out["ns_per_day_per_replica"] / best_cpu
-        out["speedup_is_against"] = "port" if best_cpu == cb["value"] else "reference_in_build_container"
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    cpu_state = host_state(system) if want_cpu else None  # (the CPU legs run behind every GPU leg: see cpu_baseline)
     secondary = {}
     if rank == 0 and world == 1 and not args.no_secondary and args.switch_dist is None:
         # Secondary leg on the SAME box and state: the reference's production settings switch the LJ term from 7.5 A
@@ -730,12 +733,21 @@ def main():
         torch.cuda.empty_cache()
         try:
             # (at least 200 steps: the list of this box is rebuilt every ~80 steps, a 20-step window would hold none)
-            c5 = c5_single_gpu(args, device, cpu_budget_s=8.0, steps=max(args.steps, 200), warmup=max(args.warmup, 50))
+            c5 = c5_single_gpu(args, device, cpu_budget_s=8.0, steps=max(args.steps, 200), warmup=max(args.warmup, 50), defer_cpu=True)
             c5["metric"] = "ns/day, 1M-atom Lennard-Jones box, 9 A cutoff, 1 GPU (the cpu_baseline is extrapolated from a 125k-atom sample)"
             c5["config"] = {"workload": c5_workload(c5["natoms"], c5["box"]), "natoms": c5["natoms"], "timestep_fs": TIMESTEP_FS}
             secondary["c5"] = c5
         except Exception as exc:  # noqa: BLE001
             secondary["c5"] = {"error": f"{type(exc).__name__}: {exc}"[:500]}
+    if want_cpu:
+        out["cpu_baseline"] = cb = cpu_baseline(par, cpu_state, box, budget_s=15.0)
+        # quoted against the FASTER of the two CPU figures (the port timed here, the reference's own classes in the build container)
+        ref = cb.get("reference_in_build_container") or {}
+        best_cpu = max(cb["value"], ref.get("value") or 0.0)
+        out["speedup_vs_cpu_baseline"] = out["ns_per_day_per_replica"] / best_cpu
+        out["speedup_is_against"] = "port" if best_cpu == cb["value"] else "reference_in_build_container"
+        if isinstance(secondary.get("c5"), dict) and "natoms" in secondary["c5"]:
+            secondary["c5"]["cpu_baseline"] = cpu_baseline_c5(secondary["c5"]["natoms"], budget_s=8.0)
     if secondary:
         out["secondary"] = secondary
     if rank == 0:
