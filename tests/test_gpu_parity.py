@@ -1268,3 +1268,46 @@ def test_plain_evaluations_leave_the_rebuild_chain_out_and_recover(monkeypatch):
         for t in terms:
             assert abs(ea[t] - ec[t]) <= 1e-12 * max(1.0, abs(ec[t])), (k, t, ea[t], ec[t])
         assert torch.equal(Fa, Fc), k
+
+
+@pytest.mark.parametrize("kw", [dict(cutoff=9.0, rfa=True), dict(cutoff=9.0, rfa=True, switch_dist=7.5), dict(cutoff=8.0)],
+                         ids=["rf", "rf-switch", "coulomb"])
+def test_plain_evaluation_with_the_bonded_terms_in_the_pair_launch(kw, monkeypatch):
+    """`compute()` with energies on a cell-list context with a light topology (round 6, `tmdhip_compute`): the ENERGY variant of the
+    lean pair launch carries evaluation-only step blocks that add the bonded force of their atoms and leave the bonded energies,
+    and one kernel folds and reports — against the separate bonded / fold / report kernels (TMDHIP_FUSED_EVAL=0): forces bit for
+    bit (the same device functions in the same order), energies to fp64 round-off; and both against the oracle."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    dev = _dev()
+    mol, pos, box = tip3p_box(14, seed=31)  # 8 232 atoms
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=torch.float32)
+    rng = np.random.default_rng(4)
+    seq = [pos, pos + rng.normal(scale=0.02, size=pos.shape), pos + rng.normal(scale=0.04, size=pos.shape)]
+    b = box_tensor(box, 1, torch.float32, dev)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TMDHIP_FUSED_EVAL", fused)
+        f = Forces(par, terms=terms, algorithm="celllist", **kw)
+        res = []
+        for x in seq:
+            p = pos_tensor(x, 1, torch.float32, dev)
+            F = torch.full_like(p, 3.0)  # (must be overwritten)
+            res.append((f.compute(p, b, F, returnDetails=True)[0], F.cpu()))
+        out[fused] = res
+        f.close()
+    for (ea, Fa), (ec, Fc) in zip(out["1"], out["0"]):
+        assert torch.equal(Fa, Fc)
+        for t in terms:
+            assert abs(ea[t] - ec[t]) <= 1e-12 * max(1.0, abs(ec[t])), (t, ea[t], ec[t])
+    p = pos_tensor(seq[-1], 1, torch.float32)
+    pairs = orc.candidate_pairs(seq[-1], box, kw["cutoff"] + 0.6, orc.exclusion_pairs(par))
+    po, Fo, _ = orc.compute(par, p, box_tensor(box, 1, torch.float32), terms, pairs=pairs, **kw)
+    ea, Fa = out["1"][-1]
+    assert ((Fa - Fo).abs() / (1.0 + Fo.abs())).max().item() < 6e-5
+    for t in terms:
+        assert abs(ea[t] - po[0][t]) <= ERTOL["f32"] * EFAC * max(1.0, abs(po[0][t])), t

@@ -775,7 +775,7 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
   // slots | sequence word on a 64-byte line of its own
   const size_t ebytes = sizeof(double) * TMDHIP_NENERGY * nrep, fbytes = (sizeof(int) * F_COUNT * nrep + 7) / 8 * 8;
   const size_t seq_off = (ebytes + fbytes + sizeof(double) * nrep + 63) / 64 * 64;
-  TMD_TRY(ctx->sync_e.ensure(ebytes));
+  TMD_TRY(ctx->sync_e.ensure(ebytes + sizeof(double)));  // (+ one word the fused evaluation's fold kernel needs for a sum nobody reads)
   if (!ctx->sync_host) {
     TMD_HIP(hipHostMalloc(&ctx->sync_host, seq_off + 64, hipHostMallocMapped));
     std::memset(ctx->sync_host, 0, seq_off + 64);
@@ -783,6 +783,15 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
   double *he = (double *)ctx->sync_host;
   int *hf = (int *)((char *)ctx->sync_host + ebytes);
   double *e = ctx->sync_e.as<double>();
+  double *hk = (double *)((char *)ctx->sync_host + ebytes + fbytes);
+  volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->sync_host + seq_off);
+  const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
+  // one replica on the lean fp32 kernel with a light topology: pair + bonded in one launch, fold + report in a second (md_loop.hip)
+  const int fused = compute_fused_eval(ctx, pos_dev, box_host, forces_dev, e, e + TMDHIP_NENERGY * nrep, he, hk, hf, hseq, st);
+  if (fused < 0) return fused;
+  if (fused == 1) {
+    TMD_TRY(wait_observed(hseq, ctx->obs_seq, st));
+  } else {
   TMD_HIP(hipMemsetAsync(e, 0, ebytes, st));
   int flags = TMDHIP_WANT_ENERGY;
   if (forces_dev) {
@@ -794,10 +803,7 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
   TMD_TRY(tmdhip_compute_nonbonded(ctx, TMDHIP_ALL_REPLICAS, pos_dev, box_host, forces_dev, e,
                                    flags | kSpecChain | (forces_dev ? TMDHIP_OVERWRITE_FORCES : 0), stream));
   TMD_TRY(tmdhip_compute_bonded(ctx, TMDHIP_ALL_REPLICAS, pos_dev, box_host, forces_dev, e, flags, stream));
-  const bool lists = ctx->algorithm == TMDHIP_ALGO_CELLLIST;
   if (nrep <= 16) {  // results through host-mapped memory + a sequence word (md_loop.hip: observe_publish_kernel)
-    double *hk = (double *)((char *)ctx->sync_host + ebytes + fbytes);
-    volatile unsigned *hseq = (volatile unsigned *)((char *)ctx->sync_host + seq_off);
     TMD_TRY(publish_observables(ctx, e, nullptr, lists, he, hk, hf, hseq, st));  // the one host synchronisation of an energy evaluation
   } else {
     TMD_HIP(hipMemcpyAsync(he, e, ebytes, hipMemcpyDeviceToHost, st));
@@ -805,6 +811,7 @@ int tmdhip_compute(tmdhip_ctx *ctx, const void *pos_dev, const double *box_host,
       for (size_t r = 0; r < nrep; ++r)
         TMD_HIP(hipMemcpyAsync(hf + r * F_COUNT, ctx->rep[r].flags.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st));
     TMD_HIP(hipStreamSynchronize(st));  // the one host synchronisation of an energy evaluation
+  }
   }
   int verdict = 0;
   if (lists && ctx->algorithm == TMDHIP_ALGO_CELLLIST)

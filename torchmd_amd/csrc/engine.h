@@ -708,6 +708,7 @@ struct FusedLaunchT {
   const FusedStaticT<R> *fst;
   FusedStepT<R> step;
   bool langevin;
+  bool eval_only;  // a plain evaluation with energies: step blocks that only add the bonded force (FUSED = 5)
 };
 using FusedLaunch = FusedLaunchT<float>;
 
@@ -783,6 +784,10 @@ int upload_fused_static(Replica &rp, const FusedStaticT<R> &now, hipStream_t st)
 // can the pair launch of this replica integrate the next step itself?  (lean kernels, 4 .. 64 lanes per atom)
 template <typename R>
 bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairConsts<R> &c);
+// tmdhip_compute's two-launch evaluation (md_loop.hip) and the wait for a report's sequence word
+int compute_fused_eval(tmdhip_ctx *ctx, const void *pos_dev, const double *box, void *forces_dev, double *e_dev, double *scratch_ke,
+                       double *host_e, double *host_ke, int *host_flags, volatile unsigned *host_seq, hipStream_t st);
+int wait_observed(volatile unsigned *hseq, unsigned seq, hipStream_t st);
 // chain skipping: spin until the device has published sequence number `target` (Replica::hostpub[0]); false after 0.2 s
 bool wait_published(volatile unsigned *hp, unsigned target);
 // energies, kinetic energies and list flags of every replica through host-mapped memory + a sequence word the host

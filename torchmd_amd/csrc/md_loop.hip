@@ -173,7 +173,7 @@ static int obs_host_zone(tmdhip_ctx *ctx, ObsHost &z) {
 __global__ __launch_bounds__(kEnergySlots) void final_fold_publish_kernel(double *__restrict__ scratch, double *__restrict__ out,
                                                                           double *__restrict__ ke, const int *__restrict__ flags,
                                                                           double *host_e, double *host_ke, int *host_flags,
-                                                                          unsigned *host_seq, unsigned seq) {
+                                                                          unsigned *host_seq, unsigned seq, int accumulate) {
   __shared__ double part[kEnergySlots / 64][TMDHIP_NENERGY + 1];
   double *row = scratch + (size_t)threadIdx.x * kEnergyStride;
 #pragma unroll
@@ -189,8 +189,9 @@ __global__ __launch_bounds__(kEnergySlots) void final_fold_publish_kernel(double
 #pragma unroll
     for (int w = 0; w < kEnergySlots / 64; ++w) s += part[w][threadIdx.x];
     if (threadIdx.x < TMDHIP_NENERGY) {
-      const double e = out[threadIdx.x] + s;  // (the bonded kernel of a heavy topology has left its energies there already)
-      if (s != 0.0) out[threadIdx.x] = e;
+      // (accumulate: the bonded kernel of a heavy topology has left its energies there already; a plain evaluation overwrites)
+      const double e = accumulate ? out[threadIdx.x] + s : s;
+      if (s != 0.0 || !accumulate) out[threadIdx.x] = e;
       host_e[threadIdx.x] = e;
     } else {
       ke[0] = s;
@@ -291,6 +292,51 @@ bool fused_step_possible(const tmdhip_ctx *ctx, const Replica &rp, const PairCon
   return only_lj_el && ctx->d.ntypes <= kEntryTypes && rp.lg.lpa >= 4 && rp.lg.lpa <= 64 && kFastThreads / rp.lg.lpa <= 64;
 }
 
+
+// ---- a plain evaluation with energies in TWO launches behind the displacement test (tmdhip_compute, round 6) -------------------------
+// Cell-list contexts in fp32 with one replica and a light topology (water, ions): the ENERGY variant of the lean pair launch with
+// evaluation-only step blocks (FUSED = 5, md_step.h: FINAL = 2) that add the bonded force of their atoms to the pair force, store
+// the sum in the caller's array and leave the bonded energies in the scratch rows; then ONE kernel folds the rows and reports
+// energies and list flags to the caller's host-mapped zone.  The bonded kernel, its pass over the force array, the fold launch, the
+// report launch and the clearing of the energy buffer go away (5 launches -> 3 with the displacement test).  Returns 1 when the
+// evaluation was enqueued this way (the caller waits for ctx->obs_seq), 0 when the context does not qualify, < 0 on errors.
+int compute_fused_eval(tmdhip_ctx *ctx, const void *pos_dev, const double *box, void *forces_dev, double *e_dev, double *scratch_ke,
+                       double *host_e, double *host_ke, int *host_flags, volatile unsigned *host_seq, hipStream_t st) {
+  const char *e_on = std::getenv("TMDHIP_FUSED_EVAL");  // (0: the separate kernels; A/B, tests)
+  if (e_on && std::atoi(e_on) == 0) return 0;
+  if (ctx->d.dtype != TMDHIP_F32 || ctx->algorithm != TMDHIP_ALGO_CELLLIST || ctx->rep.size() != 1 || !forces_dev || ctx->d.terms == 0 ||
+      ctx->no_fused_once)
+    return 0;
+  Replica &rp = ctx->rep[0];
+  const PairConsts<float> c = make_consts<float>(ctx, box);
+  if (!rp.have_list || box[0] != rp.box[0] || box[1] != rp.box[1] || box[2] != rp.box[2] || !fused_step_possible<float>(ctx, rp, c)) return 0;
+  BondedArgs<float> A;
+  std::memset(&A, 0, sizeof(A));
+  if (tmd::bonded_inline_args(ctx, box, A) != 1) return 0;
+  FusedStaticT<float> now;
+  std::memset(&now, 0, sizeof(now));
+  now.s.n = ctx->d.natoms;
+  now.s.chk.flags = rp.flags.as<int>();
+  std::memcpy(&now.A, &A, sizeof(A));
+  now.has_bonded = 1;
+  now.nactive = ctx->nactive;
+  TMD_TRY(upload_fused_static(rp, now, st));
+  FusedLaunchT<float> fl{};
+  fl.fst = rp.fused_dev.as<FusedStaticT<float>>();
+  fl.langevin = false;
+  fl.eval_only = true;
+  fl.step.pos_in = (const float *)pos_dev;
+  fl.step.bonded = 1;
+  rp.n_compute++;
+  const int rc = compute_list<float>(ctx, rp, pos_dev, box, forces_dev, e_dev,
+                                     TMDHIP_WANT_FORCES | TMDHIP_WANT_ENERGY | TMDHIP_OVERWRITE_FORCES | kSpecChain, st, &fl);
+  if (rc != 0) return rc < 0 ? rc : fail("tmdhip_compute: the fused evaluation could not be enqueued");
+  if (++ctx->obs_seq == 0) ctx->obs_seq = 1;
+  hipLaunchKernelGGL(final_fold_publish_kernel, dim3(1), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), e_dev, scratch_ke,
+                     rp.flags.as<int>(), host_e, host_ke, host_flags, const_cast<unsigned *>(host_seq), ctx->obs_seq, 0);
+  TMD_HIP(hipGetLastError());
+  return 1;
+}
 
 // ---- the replicas of a cell-list context in one pair + step launch (pair_fast_kernel.h: list_pair_fast_f32_batch_kernel) ----
 __global__ void batch_upload_kernel(BatchRep v, BatchRep *dst) {
@@ -774,7 +820,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
               if (++ctx->obs_seq == 0) ctx->obs_seq = 1;
               hipLaunchKernelGGL(final_fold_publish_kernel, dim3(1), dim3(kEnergySlots), 0, st, ctx->escratch.as<double>(), en,
                                  ctx->obs_ke.as<double>(), rp.flags.as<int>(), z.e, z.ke, z.flags, const_cast<unsigned *>(z.seq),
-                                 ctx->obs_seq);
+                                 ctx->obs_seq, 1);
               ctx->run_published_seq = ctx->obs_seq;
               ctx->run_published_energies = en;
             } else {

@@ -125,8 +125,12 @@ __device__ __forceinline__ bool load_force_record(const __amdgpu_buffer_rsrc_t &
 // the kinetic-energy kernel that used to follow the last pair launch of every call.  Same device functions in the
 // same order: velocities and forces are bit-identical to the separate kernels; the energies are sums of the same
 // terms in another order (fp64 atomics).
+// FINAL = 2 (round 6): the step blocks of a PLAIN evaluation with energies (tmdhip_compute on a cell-list context with a light
+// topology): no velocities, no kick — the blocks evaluate the bonded records of their atoms, wait for the pair force, leave pair +
+// bonded force in the caller's array and the bonded energies in the scratch rows: the bonded kernel's launch, and its pass over
+// the force array, go away.
 constexpr int kKineticSlot = TMDHIP_NENERGY;  // (rows of kEnergyStride = 16 doubles: 8 per-term energies, then this)
-template <typename R, bool LANGEVIN, int APB, bool FINAL = false>
+template <typename R, bool LANGEVIN, int APB, int FINAL = 0>
 __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restrict__ fst, const FusedStepT<R> &fs,
                                                   const PairConsts<R> &c, int n, const typename Vec<R>::T4 *__restrict__ sorted,
                                                   const int *__restrict__ order, int j, int npair, R *s_lds,
@@ -156,7 +160,7 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
   // (a brick of a domain decomposition integrates the atoms it owns: the halo rows behind them are passive)
   const bool integrates = (w == 0 || !bonded) && exists && o < fst->nactive;
   AtomIn<R> x{};
-  if (integrates) {  // every load of the update but the force, in flight during the bonded part
+  if (integrates && FINAL != 2) {  // every load of the update but the force, in flight during the bonded part
     x.m = s.mass[o];
     x.vc = LANGEVIN ? s.vcoeff[o] : R(0);
     if (!FINAL) {
@@ -227,7 +231,19 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
       ok = false;  // no update from a stale record
     }
   }
-  if constexpr (FINAL) {
+  if constexpr (FINAL == 2) {
+    if (ok && forces_out) {  // the complete force of a plain evaluation
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        R fk = x.f[k];
+        if (fs.bonded != 0) fk += fb[k];
+        forces_out[3 * o + k] = fk;
+      }
+    }
+    return;
+  }
+  if constexpr (FINAL == 1) {
     // second half kick (+ thermostat) of the call's last step; the complete force goes to the caller's array (the same
     // sum the kick divides by the mass); kinetic energy of the new velocity, reduced over the wave (every lane is here)
     double ke = 0.0;

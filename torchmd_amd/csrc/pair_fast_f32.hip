@@ -58,8 +58,11 @@ int launch_pair_fast_f32(tmdhip_ctx *ctx, Replica &rp, const PairConsts<float> &
     fstep.fsort = rp.fsort.as<float4>();
     {
       constexpr int kNve = ENERGY ? 3 : 1, kLangevin = ENERGY ? 4 : 2;  // (with energies: the final step of a call)
+      constexpr int kEval = ENERGY ? 5 : 1;  // (a plain evaluation with energies; without ENERGY the branch is dead)
 #define TMD_LAUNCH_FUSED(L)            \
-  if (fl->langevin) {                  \
+  if (ENERGY && fl->eval_only) {       \
+    TMD_LAUNCH_FAST(L, kEval);         \
+  } else if (fl->langevin) {           \
     TMD_LAUNCH_FAST(L, kLangevin);     \
   } else {                             \
     TMD_LAUNCH_FAST(L, kNve);          \

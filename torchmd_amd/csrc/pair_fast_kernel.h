@@ -103,7 +103,8 @@ __device__ __forceinline__ void pair_fast_body(
   const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
 #endif
   // FUSED 1 / 2: interior steps (NVE / Langevin step blocks); 3 / 4: the LAST step of a call that wants energies (FINAL
-  // step blocks, md_step.h: second half kick + bonded energies + kinetic energy + the complete force)
+  // step blocks, md_step.h: second half kick + bonded energies + kinetic energy + the complete force); 5: a plain evaluation
+  // with energies (tmdhip_compute; step blocks that add the bonded force and leave the bonded energies: no velocities)
   static_assert(FUSED == 0 || (FUSED <= 2 && !ENERGY) || (FUSED >= 3 && ENERGY), "interior steps carry no energies, the final step does");
   static_assert(kFastThreads == 256, "step blocks are four waves");
   if (bid == 0 && threadIdx.x == 0) {
@@ -121,7 +122,7 @@ __device__ __forceinline__ void pair_fast_body(
   // pair blocks of the launch (FUSED: step blocks follow them)
   const unsigned npair = FUSED ? nblocks - (unsigned)fstep.nstep_blocks : nblocks;
   if (FUSED && bid >= npair) {
-    fused_step_blocks<float, FUSED == 2 || FUSED == 4, kFastThreads / LPA, (FUSED >= 3)>(
+    fused_step_blocks<float, FUSED == 2 || FUSED == 4, kFastThreads / LPA, (FUSED == 5 ? 2 : FUSED >= 3 ? 1 : 0)>(
         fst, fstep, c, n, sorted, order, (int)(bid - npair), (int)npair, reinterpret_cast<float *>(stab), forces, energies);
     return;
   }
