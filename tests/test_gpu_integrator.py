@@ -1008,3 +1008,83 @@ def test_md_run_without_an_energy_buffer():
         f.close()
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert torch.isfinite(out[1][0]).all()
+
+
+@pytest.mark.parametrize("trouble", ["overflow", "violation", "eighteen_replicas"])
+def test_replica_batch_recovers_like_the_loop(trouble, monkeypatch):
+    """The recovery paths of `Integrator.step` with the replicas of a cell-list context in one launch (round 6).
+    `overflow`: lists sized without slack overflow in a device-side rebuild of SOME replica -> the whole batch is rewound and
+    repeated (tmdhip_md_restore); `violation`: with the "near" report disabled an atom crosses its limit in a step whose chain
+    the host left out -> rewound and repeated with every chain.  Either way: no exception, nothing truncated at the end, the
+    forces of every replica are those of a fresh evaluation at its final positions.  `eighteen_replicas`: more replicas than one
+    launch holds (kBatchMax = 16: two launches per step), bit-identical to the replica loop."""
+    import numpy as np
+
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = torch.device("cuda:0"), torch.float32
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    if trouble == "overflow":
+        mol, pos, box = tip3p_box(14, seed=4)
+        com = pos.reshape(-1, 3, 3).mean(axis=1, keepdims=True)
+        pos = (pos.reshape(-1, 3, 3) + 0.15 * com).reshape(-1, 3)  # expanded lattice: the lists grow as it melts
+        box = box * 1.15
+        monkeypatch.setenv("TMDHIP_LPA", "8")
+        monkeypatch.setenv("TMDHIP_DEBUG_LIST_SLACK", "0")
+        R, steps = 2, 300
+    elif trouble == "violation":
+        mol, pos, box = tip3p_box(12, seed=6)
+        monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_NEAR", "2.0")  # nobody ever counts as near a limit
+        R, steps = 3, 60
+    else:
+        mol, pos, box = tip3p_box(12, seed=6)
+        R, steps = 18, 24
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    rng = np.random.default_rng(9)
+    # (jitter of at most 0.09 A per coordinate: more than ~0.3 A on every atom of flexible water blows the replica up)
+    starts = np.stack([pos + 0.03 * (r % 4) * rng.standard_normal(pos.shape) for r in range(R)], axis=2)
+
+    def run(batch):
+        monkeypatch.setenv("TMDHIP_BATCH_REPLICAS", "1" if batch else "0")
+        s = System(mol.numAtoms, R, dt, dev)
+        s.set_positions(starts)
+        s.set_box(box)
+        torch.manual_seed(5)
+        s.set_velocities(maxwell_boltzmann(par.masses, 300.0, R))
+        f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+        f.compute(s.pos, s.box, s.forces)
+        cap0 = f.stats(s.pos)["max_neighbours"]
+        torch.manual_seed(6)
+        integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+        out = integ.step(steps)
+        sts = [f.stats(s.pos, r) for r in range(R)]
+        res = (s.pos.clone(), s.vel.clone(), s.forces.clone(), out, sts, cap0, integ.replays)
+        f.close()
+        return res
+
+    pb, vb, fb, ob, stb, cap0, replays = run(True)
+    assert stb[0]["batched_launches"] > 0 and all(st["overflow"] == 0 for st in stb)
+    if trouble == "eighteen_replicas":
+        ps, vs, fs, os_, sts, _, replays_loop = run(False)
+        # (two launches per step: 16 + 2 replicas; the jittered starts are hot enough for an atom to outrun the 75 % "near" margin
+        # now and then: a rewind, if any, happens in both modes alike)
+        assert replays == replays_loop and stb[0]["batched_launches"] >= 2 * (steps - 1)
+        assert torch.equal(pb, ps) and torch.equal(vb, vs) and torch.equal(fb, fs)
+        assert np.allclose(ob[1], os_[1], rtol=1e-12)
+        return
+    assert replays >= 1  # the batch was rewound and repeated
+    if trouble == "overflow":
+        assert max(st["max_neighbours"] for st in stb) > cap0
+    # forces of the final state = a fresh evaluation's (fp32, hot start: FTOL_HOT of test_gpu_parity.py)
+    monkeypatch.delenv("TMDHIP_DEBUG_LIST_SLACK", raising=False)
+    fresh = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+    F2 = torch.zeros_like(pb)
+    fresh.compute(pb, torch.stack([torch.diag(torch.tensor(box, dtype=dt, device=dev))] * R), F2)
+    fresh.close()
+    assert torch.isfinite(pb).all() and (F2 - fb).abs().max().item() < 6e-4
+    assert all(100.0 < t < 3000.0 for t in ob[2])  # (jittered lattice starts are hot)
