@@ -92,10 +92,18 @@ __global__ __launch_bounds__(256, 2) void list_pair_lean_f64_kernel(
     const double dz = min_image_magic<EXACT>(pi.z - pjz, bz, ibz);
     const double r2 = norm2(dx, dy, dz);
     const bool hit = valid && (r2 <= r2max);
-    // 1/r: v_rsq_f64 (~2^-26 relative) + two Newton steps; rejected entries may produce inf/NaN, discarded below
+    // 1/r: v_rsq_f64 (~2^-26 relative) + one third-order correction (round 6; was two Newton steps: three fp64 operations more);
+    // rejected entries may produce inf/NaN, discarded below
     double rinv = __builtin_amdgcn_rsq(r2);
+#ifdef TMD_AB_NEWTON2
     rinv = rinv * __builtin_fma(-0.5 * r2 * rinv, rinv, 1.5);
     rinv = rinv * __builtin_fma(-0.5 * r2 * rinv, rinv, 1.5);
+#else
+    {  // one third-order step instead of two Newton steps: h = 1 - r2 y^2 ~ 2^-25, y (1 + h/2 + 3 h^2 / 8) is exact to 2^-76
+      const double h = __builtin_fma(-(r2 * rinv), rinv, 1.0);
+      rinv = __builtin_fma(rinv, h * __builtin_fma(h, 0.375, 0.5), rinv);
+    }
+#endif
     const double rinv2 = rinv * rinv;
     const double rinv6 = rinv2 * rinv2 * rinv2;
     double fs;  // (dE/dr) / r
