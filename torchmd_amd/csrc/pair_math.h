@@ -61,7 +61,18 @@ __device__ __forceinline__ double norm2(double dx, double dy, double dz) {
 }
 
 __device__ __forceinline__ float fast_rsqrt(float x) { return __frsqrt_rn(x); }
-__device__ __forceinline__ double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
+// fp64: the hardware seed (v_rsq_f64, ~2^-26 relative) + one third-order correction, y (1 + h/2 + 3 h^2/8) with h = 1 - x y^2:
+// exact to ~2^-76, i.e. to fp64 rounding (round 6: `1.0 / sqrt(x)` — a correctly rounded square root and a division — was most of
+// the all-pairs fp64 kernel's arithmetic: thrombin without cutoff, alanine dipeptide in fp64).  VALUE arithmetic only (see above).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+#ifdef TMD_AB_RSQRT_LIBM
+  return 1.0 / sqrt(x);
+#else
+  const double y = __builtin_amdgcn_rsq(x);
+  const double h = __builtin_fma(-(x * y), y, 1.0);
+  return __builtin_fma(y, h * __builtin_fma(h, 0.375, 0.5), y);
+#endif
+}
 
 // Energies e[0..3] = lj, electrostatics, repulsion, repulsioncg (TMDHIP_E_*).
 // Returns fscale such that force on i is  -d * fscale  and on j  +d * fscale
