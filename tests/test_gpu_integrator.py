@@ -1088,3 +1088,49 @@ def test_replica_batch_recovers_like_the_loop(trouble, monkeypatch):
     fresh.close()
     assert torch.isfinite(pb).all() and (F2 - fb).abs().max().item() < 6e-4
     assert all(100.0 < t < 3000.0 for t in ob[2])  # (jittered lattice starts are hot)
+
+
+def test_replicas_rebuilding_together_is_an_opt_in_with_valid_lists(monkeypatch):
+    """TMDHIP_REPLICA_REBUILDS=together (opt-in): every replica whose chain is in a batched launch rebuilds as soon as one of them
+    has to — builds of several replicas cost what one costs.  The lists are as complete as lists built on time, but their entries
+    come in another order, so a replica is no longer bit-identical to its run alone; checked here: the replicas rebuild in step
+    (same rebuild count), nothing overflows or is rewound, the aged lists hold exactly the pairs inside the cutoff, and the
+    forces of every replica's final state are those of a fresh evaluation."""
+    import numpy as np
+
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.integrator import Integrator, maxwell_boltzmann
+    from torchmd_amd.parameters import Parameters
+    from torchmd_amd.systems import System
+
+    dev, dt = torch.device("cuda:0"), torch.float32
+    monkeypatch.setenv("TMDHIP_REPLICA_REBUILDS", "together")
+    mol, pos, box = tip3p_box(12, seed=12)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    R = 4
+    s = System(mol.numAtoms, R, dt, dev)
+    s.set_positions(np.repeat(pos[:, :, None], R, axis=2))
+    s.set_box(box)
+    torch.manual_seed(2)
+    s.set_velocities(maxwell_boltzmann(par.masses, 300.0, R))  # (different velocities: the replicas drift apart)
+    f = Forces(par, terms=terms, cutoff=9.0, rfa=True, algorithm="celllist")
+    f.compute(s.pos, s.box, s.forces)
+    integ = Integrator(s, f, 1.0, dev, gamma=1.0, T=300.0)
+    integ.step(150)
+    integ.step(151)
+    sts = [f.stats(s.pos, r) for r in range(R)]
+    assert integ.replays == 0 and all(st["overflow"] == 0 for st in sts) and sts[0]["batched_launches"] >= 299
+    nreb = [st["n_rebuilds"] for st in sts]
+    assert max(nreb) - min(nreb) <= 2 and min(nreb) >= 20, nreb  # in step with each other
+    n_gpu = f.count_pairs(s.pos, s.box)  # through the run's own (aged) lists
+    aged = [f.stats(s.pos, r)["n_rebuilds"] for r in range(R)] == nreb
+    excl = orc.exclusion_pairs(par)
+    p = s.pos.detach().cpu()
+    for r in range(R):
+        pairs = orc.candidate_pairs(p[r].double().numpy(), box, 9.4, excl)
+        _, Fo, npairs = orc.compute(par, p[r:r + 1], s.box[r:r + 1].cpu(), terms, pairs=pairs, cutoff=9.0, rfa=True)
+        assert n_gpu[r] == npairs[0], (r, aged)
+        assert (s.forces[r].cpu() - Fo[0]).abs().max().item() < 6e-4  # (FTOL_HOT of test_gpu_parity.py)

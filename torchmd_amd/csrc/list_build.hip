@@ -916,11 +916,24 @@ struct ChainRepT {
 template <typename R>
 struct ChainSelT {
   int nsel;
+  int together;  // TMDHIP_REPLICA_REBUILDS=together: every replica of the launch rebuilds when ANY of them has asked (chain_any)
   int rep[kBatchMax];
   const R *pos[kBatchMax];
   const int *flag[kBatchMax];
   typename Vec<R>::T4 *sorted[kBatchMax];
 };
+// Opt-in (TMDHIP_REPLICA_REBUILDS=together): with R replicas somebody rebuilds on most steps, and every build is a ~40-us chain the
+// pair launch waits for.  Builds of several replicas in ONE launch cost what one costs, so letting every replica whose chain is in
+// the launch rebuild whenever any of them has to turns ~R/11 builds per step into ~1/9.  A list built early is as complete as one
+// built on time, but its entries come in another order: a replica's forces are then no longer bit-identical to its run alone
+// (same tolerance against the reference) — hence not the default.  The flag words are stable while a chain runs.
+template <typename R>
+__device__ __forceinline__ int chain_any(const ChainSelT<R> &sel, int y) {
+  if (!sel.together) return *sel.flag[y];
+  int any = 0;
+  for (int k = 0; k < sel.nsel; ++k) any |= *sel.flag[k];
+  return any;
+}
 // the entry's PlaceArgs with this launch's positions and target copy (dummy_a / dummy_b are "both copies": order does not matter)
 template <typename R>
 __device__ __forceinline__ PlaceArgs<R> chain_place_args(const ChainRepT<R> &A, const ChainSelT<R> &sel, int y) {
@@ -933,23 +946,26 @@ template <typename R>
 __global__ void bin_members_batch_kernel(int n, const ChainRepT<R> *__restrict__ tab, ChainSelT<R> sel) {
   const int y = blockIdx.y;
   const ChainRepT<R> &A = tab[sel.rep[y]];
-  bin_members_body<R>(n, sel.pos[y], A.g, A.cell_of, A.count, A.members, A.flags, sel.flag[y]);
+  const int go = chain_any(sel, y);
+  bin_members_body<R>(n, sel.pos[y], A.g, A.cell_of, A.count, A.members, A.flags, &go);
 }
 template <typename R>
 __global__ __launch_bounds__(256) void scan_place_batch_kernel(int n, const ChainRepT<R> *__restrict__ tab, ChainSelT<R> sel) {
   const int y = blockIdx.y;
   const ChainRepT<R> &A = tab[sel.rep[y]];
-  if (*sel.flag[y] == 0) return;
+  const int go = chain_any(sel, y);
+  if (go == 0) return;
   const PlaceArgs<R> P = chain_place_args(A, sel, y);
-  scan_place_body<R>(n, A.ncell, A.count, A.members, A.cell_start, P, sel.flag[y]);
+  scan_place_body<R>(n, A.ncell, A.count, A.members, A.cell_start, P, &go);
 }
 template <typename R>
 __global__ __launch_bounds__(1024) void prep_small_batch_kernel(int n, const ChainRepT<R> *__restrict__ tab, ChainSelT<R> sel) {
   const int y = blockIdx.y;
   const ChainRepT<R> &A = tab[sel.rep[y]];
-  if (*sel.flag[y] == 0) return;
+  const int go = chain_any(sel, y);
+  if (go == 0) return;
   const PlaceArgs<R> P = chain_place_args(A, sel, y);
-  prep_small_body<R>(n, sel.pos[y], A.g, A.ncell, A.cell_of, A.slot, A.cell_start, A.order_tmp, P, sel.flag[y]);
+  prep_small_body<R>(n, sel.pos[y], A.g, A.ncell, A.cell_of, A.slot, A.cell_start, A.order_tmp, P, &go);
 }
 template <typename R, bool WSKIN, int LPAS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void build_list_batch_kernel(
@@ -957,8 +973,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
   const int y = blockIdx.y;
   const ChainRepT<R> &A = tab[sel.rep[y]];
   if ((int)blockIdx.x >= A.build_blocks) return;
+  const int go = chain_any(sel, y);
   build_list_body<float, false, WSKIN, LPAS>(n, A.bsorted, A.binfo, A.cell_start, A.g, A.c, A.rlist2, A.rcut, excl_off, excl_idx, A.lg, A.nlist,
-                                         A.nneigh, A.flags + F_MAXN, sel.flag[y], A.ncell, A.nactive, A.type_in_entry, nullptr, A.split,
+                                         A.nneigh, A.flags + F_MAXN, &go, A.ncell, A.nactive, A.type_in_entry, nullptr, A.split,
                                          A.count_zero);
 }
 
@@ -1188,6 +1205,10 @@ int enqueue_chain_batch(tmdhip_ctx *ctx, int nsel, const int *reps, const R *con
     ChainSelT<R> sel;
     std::memset(&sel, 0, sizeof(sel));
     sel.nsel = gn;
+    {
+      const char *e = std::getenv("TMDHIP_REPLICA_REBUILDS");  // ("together": see chain_any; read per call)
+      sel.together = (e && std::strcmp(e, "together") == 0) ? 1 : 0;
+    }
     int max_cells = 0, max_blocks = 0;
     for (int k = 0; k < gn; ++k) {
       Replica &rp = ctx->rep[reps[g0 + k]];

@@ -877,10 +877,16 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
           std::vector<int> reps, par;
           std::vector<const float *> ps;
           std::vector<const double *> bx;
+          // (TMDHIP_REPLICA_REBUILDS=together, list_build.hip: chain_any — every replica is in the launch as soon as one is)
+          const char *e_tog = std::getenv("TMDHIP_REPLICA_REBUILDS");
+          bool any_chain = false;
+          for (int r = 0; r < nrep; ++r) any_chain = any_chain || batch_items[r].lo.chain;
+          const bool everybody = any_chain && e_tog && std::strcmp(e_tog, "together") == 0;
           for (int r = 0; r < nrep; ++r)
-            if (batch_items[r].lo.chain) {
+            if (batch_items[r].lo.chain || everybody) {
               reps.push_back(r);
-              par.push_back(batch_items[r].lo.chain_parity);
+              // (a replica whose chain the host had left out: compute_list has counted the step already)
+              par.push_back(batch_items[r].lo.chain ? batch_items[r].lo.chain_parity : (int)((ctx->rep[r].step - 1) & 1));
               ps.push_back(batch_items[r].pos);
               bx.push_back(batch_items[r].box);
             }
