@@ -1010,14 +1010,15 @@ def test_md_run_without_an_energy_buffer():
     assert torch.isfinite(out[1][0]).all()
 
 
-@pytest.mark.parametrize("trouble", ["overflow", "violation", "eighteen_replicas"])
+@pytest.mark.parametrize("trouble", ["overflow", "violation", "eighteen_replicas", "overflow_together", "violation_together"])
 def test_replica_batch_recovers_like_the_loop(trouble, monkeypatch):
     """The recovery paths of `Integrator.step` with the replicas of a cell-list context in one launch (round 6).
     `overflow`: lists sized without slack overflow in a device-side rebuild of SOME replica -> the whole batch is rewound and
     repeated (tmdhip_md_restore); `violation`: with the "near" report disabled an atom crosses its limit in a step whose chain
     the host left out -> rewound and repeated with every chain.  Either way: no exception, nothing truncated at the end, the
     forces of every replica are those of a fresh evaluation at its final positions.  `eighteen_replicas`: more replicas than one
-    launch holds (kBatchMax = 16: two launches per step), bit-identical to the replica loop."""
+    launch holds (kBatchMax = 16: two launches per step), bit-identical to the replica loop.  `*_together`: the same trouble with
+    the opt-in TMDHIP_REPLICA_REBUILDS=together (all replicas of a launch rebuild when one has to)."""
     import numpy as np
 
     from torchmd_amd.builders import tip3p_box, water_forcefield
@@ -1029,6 +1030,9 @@ def test_replica_batch_recovers_like_the_loop(trouble, monkeypatch):
     dev, dt = torch.device("cuda:0"), torch.float32
     terms = ["lj", "electrostatics", "bonds", "angles"]
     monkeypatch.setenv("TMDHIP_DEBUG_CHAIN_MIN_ENTRIES", "1")
+    if trouble.endswith("_together"):
+        monkeypatch.setenv("TMDHIP_REPLICA_REBUILDS", "together")
+        trouble = trouble.removesuffix("_together")
     if trouble == "overflow":
         mol, pos, box = tip3p_box(14, seed=4)
         com = pos.reshape(-1, 3, 3).mean(axis=1, keepdims=True)

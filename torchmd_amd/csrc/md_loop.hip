@@ -354,10 +354,15 @@ struct BatchItem {
   double box[3];
 };
 
-// TMDHIP_BATCH_REPLICAS=0: the replica-by-replica loop (A/B, tests; read per call)
+// TMDHIP_BATCH_REPLICAS=0: the replica-by-replica loop (A/B, tests; read per call); =2: the batched launch for a single replica
+// too (A/B of the batched kernel against the plain one on the same workload)
 static bool batch_replicas_on() {
   const char *e = std::getenv("TMDHIP_BATCH_REPLICAS");
   return !(e && std::atoi(e) == 0);
+}
+static int batch_replicas_min() {
+  const char *e = std::getenv("TMDHIP_BATCH_REPLICAS");
+  return e && std::atoi(e) == 2 ? 1 : 2;
 }
 
 // One launch for the replicas of `items` (all of the context's): table entries that changed are re-uploaded (stream-ordered
@@ -586,7 +591,7 @@ int md_run(tmdhip_ctx *ctx, const tmdhip_md_desc *d, hipStream_t st) {
     if constexpr (std::is_same<R, float>::value) {
       const bool want_e = it == d->niter - 1 && d->energies_dev;
       const bool interior = it + 1 < d->niter && !want_e, final_step = it + 1 == d->niter && want_e && final_on;
-      batching = first && nrep > 1 && ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0 && (interior || final_step) &&
+      batching = first && nrep >= batch_replicas_min() && ctx->algorithm == TMDHIP_ALGO_CELLLIST && ctx->d.terms != 0 && (interior || final_step) &&
                  batch_replicas_on();
       for (int r = 0; batching && r < nrep; ++r) {
         const Replica &rp = ctx->rep[r];

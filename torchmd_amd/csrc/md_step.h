@@ -130,7 +130,20 @@ __device__ __forceinline__ bool load_force_record(const __amdgpu_buffer_rsrc_t &
 // bonded force in the caller's array and the bonded energies in the scratch rows: the bonded kernel's launch, and its pass over
 // the force array, go away.
 constexpr int kKineticSlot = TMDHIP_NENERGY;  // (rows of kEnergyStride = 16 doubles: 8 per-term energies, then this)
-template <typename R, bool LANGEVIN, int APB, int FINAL = 0>
+// A read-only struct every lane reads at the same address, as scalar loads (constant address space).  For the plain kernel's
+// `__restrict__` kernel argument the compiler finds that by itself; the batched launch takes the pointer from its replica table,
+// and a pointer that was loaded from memory carries no such promise: the fields arrived by flat loads in VGPRs and the kernel
+// needed 124 registers (4 waves per SIMD) where the plain one needs 96 (5 waves).
+// (TABLE = false: the plain load — the plain kernels' code stays as it was measured.)
+template <bool TABLE, typename T>
+__device__ __forceinline__ T load_uniform(const T *p) {
+  if (!TABLE) return *p;
+  T v;
+  __builtin_memcpy(&v, (const __attribute__((address_space(4))) T *)p, sizeof(T));
+  return v;
+}
+
+template <typename R, bool LANGEVIN, int APB, int FINAL = 0, bool TABLE = false>
 __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restrict__ fst, const FusedStepT<R> &fs,
                                                   const PairConsts<R> &c, int n, const typename Vec<R>::T4 *__restrict__ sorted,
                                                   const int *__restrict__ order, int j, int npair, R *s_lds,
@@ -147,7 +160,7 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
   const int a = (xcd * g8 + kc) * APB + lane % APB;
   const bool exists = kc < g8 && a < n;
   const int o = exists ? order[a] : 0;
-  MdStepArgs<R> s = fst->s;
+  MdStepArgs<R> s = load_uniform<TABLE>(&fst->s);
   s.pos_in = fs.pos_in;
   s.pos_out = fs.pos_out;
   s.sorted = fs.sorted_out;
@@ -158,7 +171,7 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
   s.chk.parity = fs.parity;
   s.chk.skipped = 0;  // (unknown here: the next launch's first thread looks, kLmViolation)
   // (a brick of a domain decomposition integrates the atoms it owns: the halo rows behind them are passive)
-  const bool integrates = (w == 0 || !bonded) && exists && o < fst->nactive;
+  const bool integrates = (w == 0 || !bonded) && exists && o < load_uniform<TABLE>(&fst->nactive);
   AtomIn<R> x{};
   if (integrates && FINAL != 2) {  // every load of the update but the force, in flight during the bonded part
     x.m = s.mass[o];
@@ -182,7 +195,7 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
     R fx = 0, fy = 0, fz = 0;
     double ef[TMDHIP_NENERGY] = {0, 0, 0, 0, 0, 0, 0, 0};  // (dead on interior steps: only FINAL reads them)
     if (exists) {
-      const BondedArgs<R> A = fst->A;
+      const BondedArgs<R> A = load_uniform<TABLE>(&fst->A);
       const AtomRec<R> *rec = A.arec + (size_t)o * A.arec_stride;
       for (int k = w; k < A.arec_stride; k += kQuad) {
         const AtomRec<R> r = rec[k];
@@ -209,7 +222,7 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
     for (int k = 0; k < 3; ++k) fb[k] = (s_part[0][k][lane] + s_part[1][k][lane]) + (s_part[2][k][lane] + s_part[3][k][lane]);
   } else {
     if (fs.bonded == 2 && integrates) {
-      const R *fbond = fst->fbond;
+      const R *fbond = load_uniform<TABLE>(&fst->fbond);
 #pragma unroll
       for (int k = 0; k < 3; ++k) fb[k] = fbond[3 * o + k];
     }

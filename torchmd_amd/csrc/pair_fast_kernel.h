@@ -61,6 +61,9 @@ constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs
 #ifndef TMD_FAST_WAVES_ES
 #define TMD_FAST_WAVES_ES 4
 #endif
+#ifndef TMD_BATCH_WAVES  // (the batched kernel, below; A/B builds: 4 waves for every variant 67.8 us/step at C3, this 61.x)
+#define TMD_BATCH_WAVES fast_waves(ELEC, ENERGY, SWITCH)
+#endif
 constexpr int fast_waves(bool elec, bool energy, bool sw) {
   if (!elec) return kFastWaves + 1;
   return energy && sw ? TMD_FAST_WAVES_ES : energy ? TMD_FAST_WAVES_E : sw ? TMD_FAST_WAVES_S : kFastWaves;
@@ -88,7 +91,7 @@ static __device__ unsigned long long g_pair_timeline[4 * 65536];
 // launch.  list_pair_fast_f32_kernel passes blockIdx.x / gridDim.x and its own arguments; the replica-batched kernel
 // (list_pair_fast_f32_batch_kernel, round 6) the block's position inside its replica's share of the grid and that replica's
 // buffers from a device table.
-template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED>
+template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED, bool TABLE = false>
 __device__ __forceinline__ void pair_fast_body(
     const unsigned bid, const unsigned nblocks,
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
@@ -122,7 +125,7 @@ __device__ __forceinline__ void pair_fast_body(
   // pair blocks of the launch (FUSED: step blocks follow them)
   const unsigned npair = FUSED ? nblocks - (unsigned)fstep.nstep_blocks : nblocks;
   if (FUSED && bid >= npair) {
-    fused_step_blocks<float, FUSED == 2 || FUSED == 4, kFastThreads / LPA, (FUSED == 5 ? 2 : FUSED >= 3 ? 1 : 0)>(
+    fused_step_blocks<float, FUSED == 2 || FUSED == 4, kFastThreads / LPA, (FUSED == 5 ? 2 : FUSED >= 3 ? 1 : 0), TABLE>(
         fst, fstep, c, n, sorted, order, (int)(bid - npair), (int)npair, reinterpret_cast<float *>(stab), forces, energies);
     return;
   }
@@ -469,10 +472,12 @@ __global__ __launch_bounds__(kFastThreads, fast_waves(ELEC, ENERGY, SWITCH)) voi
 // what changes from launch to launch travels as a kernel argument (BatchLaunch).  Every replica keeps its own neighbour state,
 // rebuild flags and host reports: the block of a replica does exactly what it does in a launch of its own — results are
 // bit-identical to the replica-by-replica loop.
-// (Four waves per SIMD for every variant: with a replica's buffers in scalar registers on top of the loop's, the five-wave
-// build of the plain variant spills 88 bytes per lane.)
+// Waves per SIMD as the plain kernel's variants.  (First version: four waves for every variant, because the five-wave build of
+// the headline variant spilled 88 bytes per lane — the step blocks read the replica's FusedStatic, a pointer out of the table,
+// with flat loads into VGPRs.  Read through the constant address space (md_step.h: load_uniform) the fields are in SGPRs as
+// in the plain kernel: 96 VGPRs, no scratch; C3 as ONE replica through this kernel 67.8 -> 61.x us/step, the plain kernel's.)
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED>
-__global__ __launch_bounds__(kFastThreads, 4) void list_pair_fast_f32_batch_kernel(
+__global__ __launch_bounds__(kFastThreads, TMD_BATCH_WAVES) void list_pair_fast_f32_batch_kernel(
     int n, int ntypes, const float2 *__restrict__ tab, PairConsts<float> c, const BatchRep *__restrict__ reps, BatchLaunch bl) {
   static_assert(FUSED != 0, "the batched launch is an MD-step launch");
   const unsigned per_pair = (unsigned)bl.pair_blocks, per_step = (unsigned)bl.step_blocks;
@@ -501,7 +506,8 @@ __global__ __launch_bounds__(kFastThreads, 4) void list_pair_fast_f32_batch_kern
   fs.seq = bl.seq[r];
   fs.near_host = (bits & kBlReports) ? S.hostpub + 1 + (fs.seq & 1u) : nullptr;
   fs.parity = (bits & kBlNextParity) ? 1 : 0;
-  pair_fast_body<LPA, LJ, ELEC, ENERGY, SWITCH, FUSED>(
+  // (TABLE: the step blocks read the replica's FusedStatic through the constant address space, md_step.h: load_uniform)
+  pair_fast_body<LPA, LJ, ELEC, ENERGY, SWITCH, FUSED, true>(
       is_pair ? local : per_pair + local, per_pair + per_step, n, S.sorted[cs], S.stype, S.order, ntypes, tab, S.nlist, S.nneigh, S.maxn, c,
       S.forces, 1, S.escratch, (bits & kBlPublish) ? S.hostpub : nullptr, bl.pub[r], S.ext, S.lflags, (int)(bits & kBlLmodeMask), S.fst, fs,
       S.padgen);
