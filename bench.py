@@ -21,6 +21,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def usable_cpus():
+    """CPUs this process may really use: its affinity mask capped by the cgroup's CPU quota.  (The GPU boxes show 256 hardware
+    threads under a quota of 16 CPUs: torch's default of 128 worker threads exhausts the quota of a 100-ms period in ~12 ms and
+    EVERY thread of the process — the one that paces the GPU included — is stopped for the rest of it: legs of a bench run that
+    came out 3-4x slow, one run in ten.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            with open(path) as fh:
+                quota, period = parse(fh.read())
+            if period is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    period = fh.read().strip()
+            if quota not in ("max", "-1") and int(quota) > 0:
+                n = min(n, max(1, int(quota) // int(period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
+USABLE_CPUS = usable_cpus()
+# worker threads of the host-side libraries during the GPU legs (set before they are imported): well inside the quota
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_k, str(max(1, min(8, USABLE_CPUS // 2))))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -371,6 +400,8 @@ def cpu_baseline_c5(natoms_full, nside_sample=50, budget_s=15.0):
     pairs = orc.candidate_pairs(pos, box, CUTOFF + 0.6, None)
     dt, gamma, vcoeff = orc.integrator_constants(TIMESTEP_FS, 1.0, 85.0, masses)
     kw = dict(cutoff=CUTOFF, pairs=pairs)
+    gpu_leg_threads = torch.get_num_threads()
+    torch.set_num_threads(USABLE_CPUS)  # (all the CPUs the cgroup grants; the GPU legs are over)
     orc.md_step(par, p, vel, frc, cbox, masses, dt, ["lj"], gamma, vcoeff, **kw)  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
@@ -380,8 +411,9 @@ def cpu_baseline_c5(natoms_full, nside_sample=50, budget_s=15.0):
         if el > budget_s or n >= 50:
             break
     ratio = mol.numAtoms / float(natoms_full)
+    torch.set_num_threads(gpu_leg_threads)
     return {
-        "value": ns_per_day(n, el) * ratio, "unit": "ns/day", "cores": torch.get_num_threads(), "kind": "port",
+        "value": ns_per_day(n, el) * ratio, "unit": "ns/day", "cores": USABLE_CPUS, "kind": "port",
         "extrapolated": True, "s_per_step_sample": el / n,
         "source": "oracle (pinned port of the reference arithmetic; /root/reference does not exist on the GPU box)",
         "sample": f"{n} MD steps of a {mol.numAtoms}-atom argon box at the same density (oracle md_step, {len(pairs)} candidate "
@@ -459,9 +491,10 @@ def cpu_baseline(par, state, box, budget_s=20.0):
     # the best the host can do: a gather / scatter workload is oversubscribed by torch's default of one thread per
     # hardware thread (round 5: 2.48 s/step on 128 threads, the reference's classes on 8 threads 1.39 s/step) — one timed
     # step at 8 / 16 / 32 / all threads, the bounded sample with the fastest
+    # (never more threads than the cgroup lets run at once: beyond that they are only stopped and started)
     default_threads = torch.get_num_threads()
     tried = {}
-    for nt in sorted({min(t, default_threads) for t in (8, 16, 32, default_threads)}):
+    for nt in sorted({min(t, USABLE_CPUS) for t in (8, 16, 32, USABLE_CPUS)}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         orc.md_step(par, pos, vel, frc, cbox, masses, dt, TERMS, gamma, vcoeff, **kw)
@@ -490,7 +523,8 @@ def cpu_baseline(par, state, box, budget_s=20.0):
         "cores": threads_used,
         "threads_used": threads_used,
         "threads_tried_s_per_step": {str(k): v for k, v in tried.items()},
-        "host_hardware_threads": default_threads,
+        "host_hardware_threads": os.cpu_count(),
+        "host_usable_cpus": USABLE_CPUS,
         "kind": "port",
         "reference_in_build_container": ref,
         "source": "oracle (pinned port of the reference arithmetic; /root/reference does not exist on the GPU box)",
