@@ -7,6 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Worker threads of torch / numpy (set before they are imported): the GPU boxes show 256 hardware threads under a cgroup quota of
+# 16 CPUs — 128 worker threads only get the whole process throttled (bench.py: usable_cpus).
+if (os.cpu_count() or 1) > 16:
+    for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(_k, "8")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
