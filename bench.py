@@ -490,7 +490,7 @@ def cpu_baseline(par, state, box, budget_s=20.0):
     orc.md_step(par, pos, vel, frc, cbox, masses, dt, TERMS, gamma, vcoeff, **kw)  # warm-up
     # the best the host can do: a gather / scatter workload is oversubscribed by torch's default of one thread per
     # hardware thread (round 5: 2.48 s/step on 128 threads, the reference's classes on 8 threads 1.39 s/step) — one timed
-    # step at 8 / 16 / 32 / all threads, the bounded sample with the fastest
+    # step at 8 / 16 / 32 / all USABLE CPUs (the cgroup quota: 16 on the GPU boxes), the bounded sample with the fastest
     # (never more threads than the cgroup lets run at once: beyond that they are only stopped and started)
     default_threads = torch.get_num_threads()
     tried = {}
