@@ -279,28 +279,25 @@ __device__ __forceinline__ void fused_step_blocks(const FusedStaticT<R> *__restr
   }
   if (!ok) return;
   md_step_atom<R, true, LANGEVIN, true, true>(s, c, o, 0, s.row0, x, fb, fs.bonded != 0, LANGEVIN ? g : nullptr);
-  R *const dd_out = load_uniform<TABLE>(&fst->dd_out);
-  if (dd_out) {
+  // (TABLE: the batched launch of a context's replicas — bricks are stepped by tmdhip_dd_run's own launches, domain.hip)
+  if (!TABLE && fst->dd_out) {
     // brick of a domain decomposition (dd_own_kernel's extras, same expressions): the running maximum of the squared
     // displacement since the last migration and this atom's rows of the outgoing halo messages
 #pragma clang fp contract(off)
-    const R *const dd_ref = load_uniform<TABLE>(&fst->dd_ref), *const dd_shift = load_uniform<TABLE>(&fst->dd_shift);
-    unsigned *const dd_disp2 = load_uniform<TABLE>(&fst->dd_disp2);
-    const int *const dd_csr_off = load_uniform<TABLE>(&fst->dd_csr_off), *const dd_csr_row = load_uniform<TABLE>(&fst->dd_csr_row);
     R p[3], dd = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       p[k] = s.pos_out[3 * o + k];  // (this lane's own store of a moment ago)
-      const R d = p[k] - dd_ref[3 * o + k];
+      const R d = p[k] - fst->dd_ref[3 * o + k];
       dd += d * d;
     }
     const float d2 = sizeof(R) == 4 ? (float)dd : __double2float_ru((double)dd);
-    if (__float_as_uint(d2) > *dd_disp2) atomicMax(dd_disp2, __float_as_uint(d2));
-    const int s0 = dd_csr_off[o], s1 = dd_csr_off[o + 1];
+    if (__float_as_uint(d2) > *fst->dd_disp2) atomicMax(fst->dd_disp2, __float_as_uint(d2));
+    const int s0 = fst->dd_csr_off[o], s1 = fst->dd_csr_off[o + 1];
     for (int q2 = s0; q2 < s1; ++q2) {
-      const long long k = dd_csr_row[q2];
+      const long long k = fst->dd_csr_row[q2];
 #pragma unroll
-      for (int xk = 0; xk < 3; ++xk) dd_out[3 * k + xk] = p[xk] + dd_shift[3 * k + xk];
+      for (int xk = 0; xk < 3; ++xk) fst->dd_out[3 * k + xk] = p[xk] + fst->dd_shift[3 * k + xk];
     }
   }
 }
