@@ -47,6 +47,7 @@ def usable_cpus():
 
 USABLE_CPUS = usable_cpus()
 # worker threads of the host-side libraries during the GPU legs (set before they are imported): well inside the quota
+_THREADS_FROM_CALLER = "OMP_NUM_THREADS" in os.environ  # (torch.distributed.run sets 1 per rank)
 for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_k, str(max(1, min(8, USABLE_CPUS // 2))))
 
@@ -115,7 +116,9 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
-    env.setdefault("OMP_NUM_THREADS", "4")
+    if not _THREADS_FROM_CALLER:  # the ranks share this process's CPU quota
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            env[k] = str(max(1, min(4, USABLE_CPUS // (2 * args.gpus))))
     return subprocess.call(cmd, env=env)
 
 
