@@ -48,7 +48,8 @@ namespace tmd {
 // daee5f8, the record in profiles/r04_lds_gather_ab.txt.)
 constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs); measured at 4 / 6 / 7 / 8: docs/history/round3.md
 // Waves per SIMD a variant is compiled for.  Round 6: the variants with energies and / or the LJ switching function run the
-// pipelined loop too, at FOUR waves (110-120 VGPRs; at five they spill 36-104 bytes per lane).  C3, us per MD step /
+// pipelined loop too — those with energies at FOUR waves (110-120 VGPRs; at five they spill 36-104 bytes per lane), the
+// switched one without energies at five since its entries are evaluated one at a time (kEntriesAtOnce, below).  C3, us per MD step /
 // per compute() with energies (profiles/r06_variants_ab.txt): plain loop at five waves (round 5) 75.9 / 110.3 (switched),
 // pipelined at five 78.7 / 168.5, pipelined at four 72.6 / 102.4 (unswitched compute(): 110.3 -> 102.4).
 // (TMD_FAST_WAVES_ES / _E / _S: A/B builds)
@@ -56,7 +57,10 @@ constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs
 #define TMD_FAST_WAVES_E 4
 #endif
 #ifndef TMD_FAST_WAVES_S
-#define TMD_FAST_WAVES_S 4
+#define TMD_FAST_WAVES_S 5  // (with its entries evaluated one at a time, TMD_S_ENTRIES_AT_ONCE; all four at once: 4 waves)
+#endif
+#ifndef TMD_S_ENTRIES_AT_ONCE
+#define TMD_S_ENTRIES_AT_ONCE 1
 #endif
 #ifndef TMD_FAST_WAVES_ES
 #define TMD_FAST_WAVES_ES 4
@@ -102,6 +106,15 @@ __device__ __forceinline__ void pair_fast_body(
   constexpr int APW = 64 / LPA;
   constexpr int UNROLL = 4;
   constexpr bool kPipelined = ELEC;  // the software-pipelined loop over the unchecked groups (below)
+  // Entries of a group (one list word of a lane = 4 entries) evaluated at once.  Four for most variants: distances of all four,
+  // four v_rsq back to back, then the four force evaluations.  The SWITCH variant without energies takes them ONE at a time: the
+  // compiler then needs 92 VGPRs instead of 110 and the variant runs at five waves per SIMD without scratch (same arithmetic in
+  // the same order: results unchanged bit for bit).  C3 with the switch, same box: 71.2-71.6 -> 69.1-69.2 us/step, the launch
+  // 52.8-53.5 -> 50.8-51.1 us; two at a time at five waves (8 bytes of scratch outside the loop) 70.3-70.7.  The variants
+  // with energies keep four entries and four waves: one at a time at five waves they still spill 12-44 bytes and gain 1 %;
+  // the headline variant one at a time does not fit six waves either (80 VGPRs: 24 bytes of scratch).
+  constexpr int kEntriesAtOnce = (ELEC && SWITCH && !ENERGY) ? TMD_S_ENTRIES_AT_ONCE : UNROLL;
+  static_assert(kEntriesAtOnce == 1 || kEntriesAtOnce == 2 || kEntriesAtOnce == 4, "");
 #ifdef TMD_PAIR_TIMELINE
   const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
 #endif
@@ -248,18 +261,26 @@ __device__ __forceinline__ void pair_fast_body(
     constexpr int NU = (int)std::extent<std::remove_reference_t<decltype(tab)>>::value;
     static_assert(NU == 4, "a stage is one whole list word of a lane");
     float dx[NU], dy[NU], dz[NU], r2[NU], rinv[NU];
+    constexpr int HB = kEntriesAtOnce;  // (see kEntriesAtOnce above)
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int h0 = 0; h0 < NU; h0 += HB) {
+#pragma unroll
+    for (int u = h0; u < h0 + HB; ++u) {
       dx[u] = min_image_magic<EXACT>(pi.x - __uint_as_float(raw[u].x), vbx, vibx);
       dy[u] = min_image_magic<EXACT>(pi.y - __uint_as_float(raw[u].y), vby, viby);
       dz[u] = min_image_magic<EXACT>(pi.z - __uint_as_float(raw[u].z), vbz, vibz);
       r2[u] = norm2(dx[u], dy[u], dz[u]);
     }
-    asm("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7"
-        : "=&v"(rinv[0]), "=&v"(rinv[1]), "=&v"(rinv[2]), "=&v"(rinv[3])
-        : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]));
+    if constexpr (HB == NU) {
+      asm("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7"
+          : "=&v"(rinv[0]), "=&v"(rinv[1]), "=&v"(rinv[2]), "=&v"(rinv[3])
+          : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]));
+    } else {
+      if constexpr (HB == 2) asm("v_rsq_f32 %0, %2\n\tv_rsq_f32 %1, %3" : "=&v"(rinv[h0]), "=&v"(rinv[h0 + 1]) : "v"(r2[h0]), "v"(r2[h0 + 1]));
+      else asm("v_rsq_f32 %0, %1" : "=v"(rinv[h0]) : "v"(r2[h0]));
+    }
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int u = h0; u < h0 + HB; ++u) {
       const bool valid = UNCHECKED || (kk0 + u < myiters);  // padding words are garbage
       const float pjw = __uint_as_float(raw[u].w);
       const bool hit = valid && (r2[u] <= vr2max);
@@ -306,6 +327,8 @@ __device__ __forceinline__ void pair_fast_body(
       fx = __builtin_fmaf(-dx[u], fs, fx);
       fy = __builtin_fmaf(-dy[u], fs, fy);
       fz = __builtin_fmaf(-dz[u], fs, fz);
+    }
+    if (HB < NU) __builtin_amdgcn_sched_barrier(0);  // (one after the other: interleaved they need the registers again)
     }
   };
 
