@@ -48,19 +48,22 @@ namespace tmd {
 // daee5f8, the record in profiles/r04_lds_gather_ab.txt.)
 constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs); measured at 4 / 6 / 7 / 8: docs/history/round3.md
 // Waves per SIMD a variant is compiled for.  Round 6: the variants with energies and / or the LJ switching function run the
-// pipelined loop too — those with energies at FOUR waves (110-120 VGPRs; at five they spill 36-104 bytes per lane), the
-// switched one without energies at five since its entries are evaluated one at a time (kEntriesAtOnce, below).  C3, us per MD step /
+// pipelined loop too — at five waves with their entries evaluated one at a time (kEntriesAtOnce, below), except the variant
+// with the switch AND energies: four waves (120 VGPRs; at five it spills inside the loop).  C3, us per MD step /
 // per compute() with energies (profiles/r06_variants_ab.txt): plain loop at five waves (round 5) 75.9 / 110.3 (switched),
 // pipelined at five 78.7 / 168.5, pipelined at four 72.6 / 102.4 (unswitched compute(): 110.3 -> 102.4).
 // (TMD_FAST_WAVES_ES / _E / _S: A/B builds)
 #ifndef TMD_FAST_WAVES_E
-#define TMD_FAST_WAVES_E 4
+#define TMD_FAST_WAVES_E 5  // (entries one at a time, TMD_E_ENTRIES_AT_ONCE)
 #endif
 #ifndef TMD_FAST_WAVES_S
 #define TMD_FAST_WAVES_S 5  // (with its entries evaluated one at a time, TMD_S_ENTRIES_AT_ONCE; all four at once: 4 waves)
 #endif
 #ifndef TMD_S_ENTRIES_AT_ONCE
 #define TMD_S_ENTRIES_AT_ONCE 1
+#endif
+#ifndef TMD_E_ENTRIES_AT_ONCE
+#define TMD_E_ENTRIES_AT_ONCE 1
 #endif
 #ifndef TMD_FAST_WAVES_ES
 #define TMD_FAST_WAVES_ES 4
@@ -111,9 +114,11 @@ __device__ __forceinline__ void pair_fast_body(
   // compiler then needs 92 VGPRs instead of 110 and the variant runs at five waves per SIMD without scratch (same arithmetic in
   // the same order: results unchanged bit for bit).  C3 with the switch, same box: 71.2-71.6 -> 69.1-69.2 us/step, the launch
   // 52.8-53.5 -> 50.8-51.1 us; two at a time at five waves (8 bytes of scratch outside the loop) 70.3-70.7.  The variants
-  // with energies keep four entries and four waves: one at a time at five waves they still spill 12-44 bytes and gain 1 %;
+  // The variant with energies (no switch) likewise: 96 VGPRs, two loop-invariant values parked in scratch around the loop (8-12
+  // bytes, none inside it); FINAL launch of a call 54.2 -> 52.6 us, compute() with energies 82.8 -> 81.5.  Switch AND energies
+  // keeps four entries and four waves: one at a time at five waves it spills 44 bytes inside the loop;
   // the headline variant one at a time does not fit six waves either (80 VGPRs: 24 bytes of scratch).
-  constexpr int kEntriesAtOnce = (ELEC && SWITCH && !ENERGY) ? TMD_S_ENTRIES_AT_ONCE : UNROLL;
+  constexpr int kEntriesAtOnce = (ELEC && SWITCH && !ENERGY) ? TMD_S_ENTRIES_AT_ONCE : (ELEC && ENERGY && !SWITCH) ? TMD_E_ENTRIES_AT_ONCE : UNROLL;
   static_assert(kEntriesAtOnce == 1 || kEntriesAtOnce == 2 || kEntriesAtOnce == 4, "");
 #ifdef TMD_PAIR_TIMELINE
   const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
