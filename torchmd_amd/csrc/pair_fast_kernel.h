@@ -68,11 +68,17 @@ constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs
 #ifndef TMD_FAST_WAVES_ES
 #define TMD_FAST_WAVES_ES 4
 #endif
+#ifndef TMD_LJ_WAVES  // (LJ-only systems: the plain loop)
+#define TMD_LJ_WAVES (kFastWaves + 1)
+#endif
+#ifndef TMD_LJ_ENTRIES_AT_ONCE
+#define TMD_LJ_ENTRIES_AT_ONCE 4
+#endif
 #ifndef TMD_BATCH_WAVES  // (the batched kernel, below; A/B builds: 4 waves for every variant 67.8 us/step at C3, this 61.x)
 #define TMD_BATCH_WAVES fast_waves(ELEC, ENERGY, SWITCH)
 #endif
 constexpr int fast_waves(bool elec, bool energy, bool sw) {
-  if (!elec) return kFastWaves + 1;
+  if (!elec) return TMD_LJ_WAVES;
   return energy && sw ? TMD_FAST_WAVES_ES : energy ? TMD_FAST_WAVES_E : sw ? TMD_FAST_WAVES_S : kFastWaves;
 }
 // ---- the MD step inside the pair launch (FUSED variants; tmdhip_md_run, interior steps) -----------------------
@@ -118,7 +124,7 @@ __device__ __forceinline__ void pair_fast_body(
   // bytes, none inside it); FINAL launch of a call 54.2 -> 52.6 us, compute() with energies 82.8 -> 81.5.  Switch AND energies
   // keeps four entries and four waves: one at a time at five waves it spills 44 bytes inside the loop;
   // the headline variant one at a time does not fit six waves either (80 VGPRs: 24 bytes of scratch).
-  constexpr int kEntriesAtOnce = (ELEC && SWITCH && !ENERGY) ? TMD_S_ENTRIES_AT_ONCE : (ELEC && ENERGY && !SWITCH) ? TMD_E_ENTRIES_AT_ONCE : UNROLL;
+  constexpr int kEntriesAtOnce = (ELEC && SWITCH && !ENERGY) ? TMD_S_ENTRIES_AT_ONCE : (ELEC && ENERGY && !SWITCH) ? TMD_E_ENTRIES_AT_ONCE : (!ELEC && !ENERGY && !SWITCH) ? TMD_LJ_ENTRIES_AT_ONCE : UNROLL;
   static_assert(kEntriesAtOnce == 1 || kEntriesAtOnce == 2 || kEntriesAtOnce == 4, "");
 #ifdef TMD_PAIR_TIMELINE
   const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
