@@ -68,8 +68,8 @@ constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs
 #ifndef TMD_FAST_WAVES_ES
 #define TMD_FAST_WAVES_ES 4
 #endif
-#ifndef TMD_LJ_WAVES  // (LJ-only systems: the plain loop)
-#define TMD_LJ_WAVES (kFastWaves + 1)
+#ifndef TMD_LJ_WAVES  // (LJ-only systems: the plain loop; 10^6 argon atoms at 6 / 7 / 8 waves: 139.8 / 136.2-138.2 / 137.7-138.3 us/step)
+#define TMD_LJ_WAVES (kFastWaves + 2)
 #endif
 #ifndef TMD_LJ_ENTRIES_AT_ONCE
 #define TMD_LJ_ENTRIES_AT_ONCE 4
@@ -393,7 +393,7 @@ __device__ __forceinline__ void pair_fast_body(
     // requests it made a whole group's arithmetic earlier (counters of the unpipelined loop: 44 % of a wave's cycles
     // in s_waitcnt, 27 % issuing — at the ~5 cycles per instruction a wave can issue by itself, six such waves do
     // not fill the VALU pipe).  94 VGPRs: five waves per SIMD.
-    if constexpr (!kPipelined) {  // (LJ-only systems: short lists, the plain loop at one wave more per SIMD)
+    if constexpr (!kPipelined) {  // (LJ-only systems: short lists, the plain loop at two waves more per SIMD)
       for (; g < gfull; ++g) {
         v4u raw[UNROLL];
         unsigned tab[UNROLL];
@@ -485,8 +485,9 @@ __device__ __forceinline__ void pair_fast_body(
 }
 
 template <int LPA, bool LJ, bool ELEC, bool ENERGY, bool SWITCH, int FUSED = 0>
-// (LJ-only systems — liquid argon, short lists of ~90 entries — run the plain loop at one wave more per SIMD: 10^6 atoms
-// 175.5 -> 168.5 us/step; with charges the pipelined loop at 5 waves wins, docs/history/round3.md)
+// (LJ-only systems — liquid argon, short lists of ~90 entries — run the plain loop at more waves per SIMD: six, 10^6 atoms
+// 175.5 -> 168.5 us/step in round 3; seven since round 6, 139.8 -> 136-138; with charges the pipelined loop at 5 waves wins,
+// docs/history/round3.md)
 __global__ __launch_bounds__(kFastThreads, fast_waves(ELEC, ENERGY, SWITCH)) void list_pair_fast_f32_kernel(
     int n, const float4 *__restrict__ sorted, const int *__restrict__ stype, const int *__restrict__ order,
     int ntypes, const float2 *__restrict__ tab, const unsigned *__restrict__ nlist,
