@@ -11,6 +11,7 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 rm -f $O/bench_driver_flags.jsonl
 for i in 1 2 3 4 5 6; do python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 >> $O/bench_driver_flags.jsonl; done
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p_stats  # (a box may be handed out again with its /tmp)
 timeout 280 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -- python $R/bench.py --steps 400 --warmup 100 --relax-steps 600 --no-cpu-baseline --no-secondary > /tmp/p_stats.log 2>&1
 for f in $(find /tmp/p_stats -name "*_results.db"); do python $R/profiles/summarize_rocpd.py $f > $O/kernel_stats.csv; done
 cd $R

@@ -5,6 +5,7 @@ tag=${1:-c5}
 OUT=$R/gpurun_out/pmc_c5_$tag
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/c5_stats /tmp/c5_fetch /tmp/c5_write  # (a box may be handed out again with its /tmp)
 CMD="python $R/bench.py --config c5 --steps 120 --warmup 20 --no-cpu-baseline"
 timeout 280 rocprofv3 --kernel-trace --stats -d /tmp/c5_stats -- $CMD > /tmp/c5_stats.log 2>&1
 for f in $(find /tmp/c5_stats -name "*_results.db"); do python $R/profiles/summarize_rocpd.py $f > $OUT/kernel_stats.csv; done
