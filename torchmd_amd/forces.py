@@ -210,8 +210,9 @@ class _Engine:
             self.ctx = C.c_void_p()
 
     def __del__(self):
-        if sys.is_finalizing():
-            return  # never call into the HIP runtime during interpreter teardown
+        # never call into the HIP runtime during interpreter teardown (module globals may be gone by then: `sys` is None)
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
