@@ -79,7 +79,8 @@ __global__ void normal_fill_kernel(int64_t n, R *__restrict__ out, uint64_t seed
 }
 
 // integrator.py:8-31: grid = (blocks, replicas)
-template <typename R>
+// DIRECT: one block per replica (small systems) stores its sum — no clear of `ke` in front, no atomics
+template <typename R, bool DIRECT>
 __global__ __launch_bounds__(256) void kinetic_kernel(int64_t natoms, const R *__restrict__ vel,
                                                       const R *__restrict__ mass, double *__restrict__ ke) {
   const int r = blockIdx.y;
@@ -93,7 +94,10 @@ __global__ __launch_bounds__(256) void kinetic_kernel(int64_t natoms, const R *_
   __shared__ double part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(&ke[r], part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    if (DIRECT) ke[r] = part[0] + part[1] + part[2] + part[3];
+    else unsafeAtomicAdd(&ke[r], part[0] + part[1] + part[2] + part[3]);
+  }
 }
 
 inline dim3 blocks_for(int64_t n, int t) { return dim3((unsigned)((n + t - 1) / t)); }
@@ -164,14 +168,23 @@ int tmdhip_kinetic_energy(int dtype, int64_t nreplicas, int64_t natoms, const vo
   TMD_TRY(check(dtype, nreplicas, natoms));
   if (!vel || !mass || !ke) return fail("tmdhip_kinetic_energy: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (natoms <= 8192) {  // small systems (launch-bound): one block per replica, one launch instead of a clear + a launch
+    dim3 grid(1, (unsigned)nreplicas);
+    if (dtype == TMDHIP_F32)
+      hipLaunchKernelGGL((kinetic_kernel<float, true>), grid, dim3(256), 0, st, natoms, (const float *)vel, (const float *)mass, ke);
+    else
+      hipLaunchKernelGGL((kinetic_kernel<double, true>), grid, dim3(256), 0, st, natoms, (const double *)vel, (const double *)mass, ke);
+    TMD_HIP(hipGetLastError());
+    return 0;
+  }
   TMD_HIP(hipMemsetAsync(ke, 0, sizeof(double) * nreplicas, st));
   const unsigned nb = (unsigned)std::min<int64_t>((natoms + 255) / 256, 256);
   dim3 grid(nb, (unsigned)nreplicas);
   if (dtype == TMDHIP_F32)
-    hipLaunchKernelGGL((kinetic_kernel<float>), grid, dim3(256), 0, st, natoms, (const float *)vel,
+    hipLaunchKernelGGL((kinetic_kernel<float, false>), grid, dim3(256), 0, st, natoms, (const float *)vel,
                        (const float *)mass, ke);
   else
-    hipLaunchKernelGGL((kinetic_kernel<double>), grid, dim3(256), 0, st, natoms, (const double *)vel,
+    hipLaunchKernelGGL((kinetic_kernel<double, false>), grid, dim3(256), 0, st, natoms, (const double *)vel,
                        (const double *)mass, ke);
   TMD_HIP(hipGetLastError());
   return 0;
