@@ -744,12 +744,15 @@ def main():
                          skin_weights=None if args.skin_weights == "none" else "mass", **({} if args.skin is None else {"skin": args.skin}))
             fsw.compute(system.pos, system.box, system.forces)
             isw = Integrator(system, fsw, TIMESTEP_FS, device, gamma=0.1, T=300.0)
-            isw.step(max(args.warmup, 50))
+            # (a fresh context behind ~0.3 s of host-side set-up: 500 untimed steps = 35 ms bring the clocks back up — with 50 the
+            # launch of this leg averaged 53.4 us against 50.9 in a long run)
+            sw_warm = max(args.warmup, 500)
+            isw.step(sw_warm)
             sw_steps = max(args.steps, 200)
             lsw = c3_leg(fsw, isw, system, natoms, sw_steps, fan, pmc=args.nside == 32, switched=True)
             secondary["c3_switch"] = {
                 "metric": "ns/day, the same water box with the LJ switching function from 7.5 A (the reference's production settings)",
-                "value": ns_per_day(sw_steps, lsw["elapsed"]), "unit": "ns/day", "steps": sw_steps, "warmup": max(args.warmup, 50),
+                "value": ns_per_day(sw_steps, lsw["elapsed"]), "unit": "ns/day", "steps": sw_steps, "warmup": sw_warm,
                 "ms_per_step": lsw["elapsed"] / sw_steps * 1e3, "dtype": "f32",
                 "config": {"workload": "C3 box, terms and thermostat as the headline + switch_dist 7.5 A (explicit-force flavour of "
                            "forces.py:410-412)", "natoms": natoms, "timestep_fs": TIMESTEP_FS},
