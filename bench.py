@@ -48,8 +48,9 @@ def usable_cpus():
 USABLE_CPUS = usable_cpus()
 # worker threads of the host-side libraries during the GPU legs (set before they are imported): well inside the quota
 _THREADS_FROM_CALLER = "OMP_NUM_THREADS" in os.environ  # (torch.distributed.run sets 1 per rank)
+_n_threads = os.environ.get("OMP_NUM_THREADS") or str(max(1, min(8, USABLE_CPUS // 2)))
 for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ.setdefault(_k, str(max(1, min(8, USABLE_CPUS // 2))))
+    os.environ.setdefault(_k, _n_threads)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -717,3 +717,20 @@ def test_launch_timeline_tool_on_a_synthetic_trace(tmp_path):
     lines = {int(ln.split()[0].rstrip("+")): ln.split() for ln in out.splitlines() if ln.startswith("   ") or ln.startswith("  1")}
     assert float(lines[0][1]) == 50.0 and int(lines[0][4]) == 3
     assert float(lines[1][1]) == 44.0 and int(lines[4][4]) == 3 and 5 not in lines
+
+
+def test_bench_caps_worker_threads_at_the_cpu_quota(tmp_path):
+    """bench.py: worker threads of torch / numpy are capped at what the cgroup lets run at once (the GPU boxes: 256 hardware
+    threads under a quota of 16 CPUs — 128 threads had every thread of the process throttled, the one pacing the GPU included).
+    A fresh interpreter imports bench with no thread variables set: the environment it leaves and torch's thread count are within
+    `usable_cpus()`, which is within the affinity mask; a caller's OMP_NUM_THREADS (torch.distributed.run sets 1) is respected."""
+    code = ("import os, json, sys; sys.path.insert(0, %r); import bench, torch; "
+            "print(json.dumps({'usable': bench.USABLE_CPUS, 'omp': os.environ['OMP_NUM_THREADS'], 'torch': torch.get_num_threads(), "
+            "'aff': len(os.sched_getaffinity(0))}))" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    out = json.loads(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    assert 1 <= out["usable"] <= out["aff"]
+    assert 1 <= int(out["omp"]) <= max(1, min(8, out["usable"] // 2)) and out["torch"] <= max(1, out["usable"])
+    env["OMP_NUM_THREADS"] = "1"
+    out = json.loads(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    assert out["omp"] == "1" and out["torch"] == 1
