@@ -46,6 +46,12 @@ namespace tmd {
 // (Measured and not kept, round 4: the gathers of the pipelined loop landing in LDS — `buffer_load_dwordx4 ... lds`, two
 // stages of 4 KB per wave, four waves per SIMD — 49.2-50.5 against 45.6-46.9 us, identical checksums; the code is in commit
 // daee5f8, the record in profiles/r04_lds_gather_ab.txt.)
+#ifndef TMD_FAST_WAVES_BASE  // (A/B builds, with TMD_BASE_ENTRIES_AT_ONCE)
+#define TMD_FAST_WAVES_BASE 5
+#endif
+#ifndef TMD_BASE_ENTRIES_AT_ONCE
+#define TMD_BASE_ENTRIES_AT_ONCE 4
+#endif
 constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs); measured at 4 / 6 / 7 / 8: docs/history/round3.md
 // Waves per SIMD a variant is compiled for.  Round 6: the variants with energies and / or the LJ switching function run the
 // pipelined loop too — at five waves with their entries evaluated one at a time (kEntriesAtOnce, below), except the variant
@@ -79,7 +85,7 @@ constexpr int kFastWaves = 5;  // waves per SIMD of the pipelined loop (94 VGPRs
 #endif
 constexpr int fast_waves(bool elec, bool energy, bool sw) {
   if (!elec) return TMD_LJ_WAVES;
-  return energy && sw ? TMD_FAST_WAVES_ES : energy ? TMD_FAST_WAVES_E : sw ? TMD_FAST_WAVES_S : kFastWaves;
+  return energy && sw ? TMD_FAST_WAVES_ES : energy ? TMD_FAST_WAVES_E : sw ? TMD_FAST_WAVES_S : TMD_FAST_WAVES_BASE;
 }
 // ---- the MD step inside the pair launch (FUSED variants; tmdhip_md_run, interior steps) -----------------------
 // Between two force evaluations an MD step is per-atom work on the force just computed: second half kick of step
@@ -123,8 +129,9 @@ __device__ __forceinline__ void pair_fast_body(
   // The variant with energies (no switch) likewise: 96 VGPRs, two loop-invariant values parked in scratch around the loop (8-12
   // bytes, none inside it); FINAL launch of a call 54.2 -> 52.6 us, compute() with energies 82.8 -> 81.5.  Switch AND energies
   // keeps four entries and four waves: one at a time at five waves it spills 44 bytes inside the loop;
-  // the headline variant one at a time does not fit six waves either (80 VGPRs: 24 bytes of scratch).
-  constexpr int kEntriesAtOnce = (ELEC && SWITCH && !ENERGY) ? TMD_S_ENTRIES_AT_ONCE : (ELEC && ENERGY && !SWITCH) ? TMD_E_ENTRIES_AT_ONCE : (!ELEC && !ENERGY && !SWITCH) ? TMD_LJ_ENTRIES_AT_ONCE : UNROLL;
+  // the headline variant one at a time fits six waves with 24 bytes parked around the loop, and is slower there (same box:
+  // 65.7-66.0 against 63.5-63.8 us/step): five waves, four at once, as since round 3.
+  constexpr int kEntriesAtOnce = (ELEC && SWITCH && !ENERGY) ? TMD_S_ENTRIES_AT_ONCE : (ELEC && ENERGY && !SWITCH) ? TMD_E_ENTRIES_AT_ONCE : (!ELEC && !ENERGY && !SWITCH) ? TMD_LJ_ENTRIES_AT_ONCE : (ELEC && !ENERGY && !SWITCH) ? TMD_BASE_ENTRIES_AT_ONCE : UNROLL;
   static_assert(kEntriesAtOnce == 1 || kEntriesAtOnce == 2 || kEntriesAtOnce == 4, "");
 #ifdef TMD_PAIR_TIMELINE
   const unsigned long long tl_t0 = wall_clock64(), tl_c0 = __builtin_readcyclecounter();
