@@ -1189,13 +1189,13 @@ int enqueue_chain_batch(tmdhip_ctx *ctx, int nsel, const int *reps, const R *con
     return 0;
   }
   {
-    // TMDHIP_REPLICA_REBUILDS=together: every replica of the launch builds at once, the chip is as full as under one big box —
+    // Many replicas in one launch (always so with TMDHIP_REPLICA_REBUILDS=together): the chip is as full as under one big box —
     // where ONE block per cell is the fastest cut (T = 54 us x blocks per cell + 111 us at C3's 6 859 cells,
     // profiles/r06_build_experiments.txt); the two blocks per cell of a small grid are for a replica that rebuilds alone.
-    const char *e = std::getenv("TMDHIP_REPLICA_REBUILDS");
+    // (Which block builds an atom's row does not change the row: the lists are the same entry for entry.)
     long cells = 0;
     for (int k = 0; k < nsel; ++k) cells += plan[k].ncell;
-    if (e && std::strcmp(e, "together") == 0 && cells >= 3000 && !std::getenv("TMDHIP_BUILD_SPLIT") && !std::getenv("TMDHIP_BATCH_BUILD_SPLIT"))
+    if (cells >= 3000 && !std::getenv("TMDHIP_BUILD_SPLIT") && !std::getenv("TMDHIP_BATCH_BUILD_SPLIT"))
       for (int k = 0; k < nsel; ++k) {
         plan[k].split = 1;
         plan[k].build_blocks = plan[k].ncell;
