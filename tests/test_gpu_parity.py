@@ -1031,9 +1031,11 @@ def test_replica_batch_matches_single_replica_calls(which):
     assert abs(pots_b[0]["lj"] - pots_b[2]["lj"]) > 1e-3
 
 
-@pytest.mark.parametrize("mode", ["reference", "exact"])
-def test_lean_kernel_switching_variants(mode):
-    """LJ switching in the lean list kernels (both force flavours, with and without energies) on the 5 184-atom water
+@pytest.mark.parametrize("mode,lpa", [("reference", 0), ("exact", 0), ("reference", 4), ("reference", 16), ("reference", 32), ("reference", 64)])
+def test_lean_kernel_switching_variants(mode, lpa, monkeypatch):
+    """(`lpa` > 0: the same with the lanes per atom pinned — every LPA instantiation of the SWITCH and SWITCH + ENERGY variants, which
+    evaluate the entries of a list word one at a time since round 6 — instead of the launcher's choice.)
+    LJ switching in the lean list kernels (both force flavours, with and without energies) on the 5 184-atom water
     box: fp32 against fp64 (LJ only: the switched LJ force vanishes at the cutoff, so the handful of pairs whose
     cutoff decision differs between fp32 and fp64 coordinates does not matter) and BOTH against the oracle on the same
     tensors — `reference` = the oracle's explicit forces (forces.py:399-413 with the extra 1/r of 410-412), `exact` = its
@@ -1044,6 +1046,8 @@ def test_lean_kernel_switching_variants(mode):
     from torchmd_amd.forces import Forces
     from torchmd_amd.parameters import Parameters
 
+    if lpa:
+        monkeypatch.setenv("TMDHIP_LPA", str(lpa))
     dev = _dev()
     mol, pos, box = tip3p_box(12, seed=17)
     terms = ["lj"]
