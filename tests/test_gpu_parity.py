@@ -1315,3 +1315,34 @@ def test_plain_evaluation_with_the_bonded_terms_in_the_pair_launch(kw, monkeypat
     assert ((Fa - Fo).abs() / (1.0 + Fo.abs())).max().item() < 6e-5
     for t in terms:
         assert abs(ea[t] - po[0][t]) <= ERTOL["f32"] * EFAC * max(1.0, abs(po[0][t])), t
+
+
+@pytest.mark.parametrize("lpa", [4, 8, 16, 32, 64])
+def test_lean_kernel_energy_variant_at_every_lane_count(lpa, monkeypatch):
+    """The ENERGY variant of the lean fp32 list kernel (an evaluation with per-term energies: `compute()`, the last step of a
+    `step()` call) evaluates the entries of a list word one at a time since round 6 (five waves per SIMD): every lanes-per-atom
+    instantiation on the 5 184-atom water box, LJ + reaction field + bonded terms, against the oracle — forces (with energies
+    and forces only), per-term energies, in-cutoff pair count."""
+    from oracle import torchmd_oracle as orc
+    from torchmd_amd.builders import tip3p_box, water_forcefield
+    from torchmd_amd.forces import Forces
+    from torchmd_amd.parameters import Parameters
+
+    monkeypatch.setenv("TMDHIP_LPA", str(lpa))
+    dev, dt = _dev(), torch.float32
+    mol, pos, box = tip3p_box(12, seed=23)
+    terms = ["lj", "electrostatics", "bonds", "angles"]
+    par = Parameters(water_forcefield(mol), mol, terms, precision=dt)
+    kw = dict(cutoff=9.0, rfa=True)
+    f = Forces(par, terms=terms, algorithm="celllist", **kw)
+    p, b = pos_tensor(pos, 1, dt, dev), box_tensor(box, 1, dt, dev)
+    F, F_only = torch.zeros_like(p), torch.zeros_like(p)
+    pots = f.compute(p, b, F, returnDetails=True)
+    f._evaluate(p, b, F_only, False, True)
+    n_gpu = f.count_pairs(p, b)
+    pairs = orc.candidate_pairs(pos, box, 9.6, orc.exclusion_pairs(par))
+    po, Fo, npairs = orc.compute(par, pos_tensor(pos, 1, dt), box_tensor(box, 1, dt), terms, pairs=pairs, **kw)
+    assert n_gpu == npairs
+    assert max((F.cpu() - Fo).abs().max().item(), (F_only.cpu() - Fo).abs().max().item()) < 3e-4  # (FTOL of the fp32 list path)
+    for t in terms:
+        assert abs(pots[0][t] - po[0][t]) <= ERTOL["f32"] * EFAC * max(1.0, abs(po[0][t])), (t, pots[0][t], po[0][t])
